@@ -1,0 +1,110 @@
+"""Pins oracle/ref_cpu.py against outputs of the reference modules themselves (tests/golden/*.npz,
+made by tools/gen_golden.py in the build container).  Integer outputs must be identical; float outputs
+are produced by the same torch-CPU kernels and are compared to 1e-6 (bit-exact on the generating host)."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from icepy4d_amd import synthetic
+from oracle import ref_cpu as o
+
+SP_SD = synthetic.superpoint_state_dict(0)
+
+
+def sha(t):
+    return hashlib.sha256(t.detach().contiguous().numpy().tobytes()).hexdigest()
+
+
+def close(a, b, tol=1e-6):
+    a = a.numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    np.testing.assert_allclose(a, np.asarray(b), rtol=0, atol=tol)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_superpoint_stages(tag):
+    g = load_golden(f"g1_superpoint_{tag}")
+    x = o.frame_to_tensor(g["image"])
+    k = int(g["max_k"])
+    with torch.inference_mode():
+        tr = {}
+        out = o.superpoint_lg(x, SP_SD, k, trace=tr)
+        close(tr["feat"][0, ::16, ::3, ::5], g["feat_sample"])
+        close(tr["score_map"][0], g["score_map"])
+        close(tr["nms"][0], g["nms4"], 0)
+        close(o.simple_nms(tr["score_map"], 3)[0], g["nms3"], 0)
+        close(tr["dense"][0, ::32], g["dense_sample"])
+        assert np.array_equal(out["keypoints"].numpy(), g["keypoints"])
+        close(out["keypoint_scores"], g["keypoint_scores"], 0)
+        close(out["descriptors"], g["descriptors"])
+        assert np.array_equal(out["image_size"].numpy(), g["image_size"])
+        sg = o.superpoint_sg(x[None], SP_SD, 3, 0.001, -1 if tag == "b" else 50)
+        assert np.array_equal(sg["keypoints"].numpy(), g["sg_keypoints"])
+        close(sg["scores"], g["sg_scores"], 0)
+        close(sg["descriptors"], g["sg_descriptors"])
+    if sha(tr["feat"]) != str(g["feat_sha"]):
+        pytest.skip("encoder output equal to 1e-6 but not bit-identical on this host CPU")
+
+
+@pytest.mark.parametrize("ci", range(6))
+def test_lightglue(ci):
+    g = load_golden(f"g2_lightglue_{ci}")
+    sd = synthetic.lightglue_state_dict(0, str(g["variant"]))
+    f = synthetic.synthetic_features(int(g["seed"]), int(g["m"]), int(g["n"]))
+    f0 = dict(keypoints=torch.from_numpy(f["kpts0"]), descriptors=torch.from_numpy(f["desc0"]), image_size=torch.from_numpy(f["size0"]))
+    f1 = dict(keypoints=torch.from_numpy(f["kpts1"]), descriptors=torch.from_numpy(f["desc1"]), image_size=torch.from_numpy(f["size1"]))
+    with torch.inference_mode():
+        tr = {}
+        out = o.lightglue(f0, f1, sd, depth_confidence=float(g["depth_confidence"]),
+                          width_confidence=float(g["width_confidence"]), trace=tr)
+        e0 = o.lg_posenc(o.lg_normalize_keypoints(f0["keypoints"], f0["image_size"])[None], sd)
+        close(e0[:, 0, 0], g["encoding0"])
+        s0 = o.lg_self_block(sd, 0, f0["descriptors"][None], e0)
+        close(s0[0], g["self0"])
+        close(tr["layers"][0]["desc0"], g["cross0"])
+        close(tr["layers"][0]["desc1"], g["cross1"])
+        sc, sim = o.lg_log_assignment(sd, 0, tr["layers"][0]["desc0"][None], tr["layers"][0]["desc1"][None])
+        close(sim[0], g["sim_l0"], 1e-5)
+        close(sc[0], g["scores_l0"], 1e-5)
+    assert out["stop"] == int(g["stop"])
+    for key in ("matches0", "matches1", "matches", "prune0", "prune1"):
+        assert np.array_equal(out[key].numpy(), g[key]), key
+    for key in ("matching_scores0", "matching_scores1", "scores"):
+        close(out[key], g[key])
+
+
+@pytest.mark.parametrize("ci", range(3))
+def test_superglue(ci):
+    g = load_golden(f"g3_superglue_{ci}")
+    sd = synthetic.superglue_state_dict(0, str(g["variant"]))
+    f = synthetic.synthetic_features(int(g["seed"]), int(g["m"]), int(g["n"]))
+    data = dict(keypoints0=torch.from_numpy(f["kpts0"]), keypoints1=torch.from_numpy(f["kpts1"]),
+                scores0=torch.from_numpy(f["scores0"]), scores1=torch.from_numpy(f["scores1"]),
+                descriptors0=torch.from_numpy(f["desc0"].T.copy()), descriptors1=torch.from_numpy(f["desc1"].T.copy()),
+                shape0=(480, 640), shape1=(480, 640))
+    with torch.inference_mode():
+        tr = {}
+        out = o.superglue(data, sd, sinkhorn_iterations=int(g["iters"]), match_threshold=0.3, trace=tr)
+        close(tr["kenc0"], g["kenc0"])
+        ot = o.log_optimal_transport(torch.from_numpy(g["ot_in"])[None], sd["bin_score"], int(g["iters"]))
+        close(ot[0], g["ot_out"], 1e-5)
+    for key in ("matches0", "matches1"):
+        assert np.array_equal(out[key].numpy(), g[key]), key
+    for key in ("matching_scores0", "matching_scores1"):
+        close(out[key], g[key])
+
+
+def test_assets_pair_config1():
+    """BASELINE config 1: assets pair, 2048 keypoints, CPU path."""
+    g = load_golden("g5_assets")
+    lg_sd = synthetic.lightglue_state_dict(0, "passthrough")
+    F0, F1, m0, mconf, out = o.match_images_lightglue(g["gray0"], g["gray1"], SP_SD, lg_sd, max_keypoints=2048)
+    assert np.array_equal(F0[0], g["keypoints0"]) and np.array_equal(F1[0], g["keypoints1"])
+    close(F0[2], g["scores0"], 0)
+    close(F0[1].T[::16], g["desc0_sample"])
+    assert np.array_equal(m0, g["matches0"])
+    close(out["matching_scores0"], g["matching_scores0"])
+    assert out["stop"] == int(g["stop"])
+    assert np.array_equal(out["prune0"].numpy(), g["prune0"])

@@ -1,0 +1,285 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE modules (imported from /root/reference,
+build container only) on seeded weights and inputs.  Nothing of the reference travels: only the
+input/output vectors written here are committed.  Re-run: `python tools/gen_golden.py`.
+
+Un-vendored dependencies of the reference that are absent here (cv2, kornia, easydict, tkinter) are
+replaced by empty stub modules; no code path that would *call* them is exercised (gray uint8 inputs,
+Quality.HIGH, GeometricVerification.NONE).  Weight loaders (`torch.hub.load_state_dict_from_url`,
+`torch.load` of the stripped .pth files) are patched to return nothing, then the seeded state dicts of
+`icepy4d_amd.synthetic` are installed with `load_state_dict`.
+"""
+import hashlib
+import logging
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+REF_SRC = "/root/reference/src"
+OUT = os.path.join(ROOT, "tests", "golden")
+
+from icepy4d_amd import synthetic  # noqa: E402
+
+
+def install_stubs():
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    stub("cv2")
+    k = stub("kornia")
+    k.feature = stub("kornia.feature", DISK=object)
+    k.color = stub("kornia.color")
+    k.geometry = stub("kornia.geometry")
+
+    class EasyDict(dict):
+        def __init__(self, d=None, **kw):
+            super().__init__()
+            for key, v in {**(d or {}), **kw}.items():
+                self[key] = v
+
+        def __setitem__(self, key, v):
+            if isinstance(v, dict) and not isinstance(v, EasyDict):
+                v = EasyDict(v)
+            super().__setitem__(key, v)
+
+        def __getattr__(self, key):
+            try:
+                return self[key]
+            except KeyError:
+                raise AttributeError(key)
+
+        __setattr__ = __setitem__
+
+    stub("easydict", EasyDict=EasyDict)
+    import matplotlib
+    matplotlib.use = lambda *a, **k: None
+    torch.hub.load_state_dict_from_url = lambda *a, **k: None
+    _load = torch.load
+    torch.load = lambda f, *a, **k: None if str(f).endswith(".pth") else _load(f, *a, **k)
+    _lsd = torch.nn.Module.load_state_dict
+
+    def load_state_dict(self, sd, *a, **k):
+        return None if sd is None else _lsd(self, sd, *a, **k)
+
+    torch.nn.Module.load_state_dict = load_state_dict
+
+
+def sha(t) -> str:
+    a = t.detach().cpu().contiguous().numpy() if isinstance(t, torch.Tensor) else np.ascontiguousarray(t)
+    return hashlib.sha256(a.tobytes()).hexdigest()
+
+
+def npy(t):
+    return t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+
+
+def save(name, **arrays):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **{k: npy(v) for k, v in arrays.items()})
+    print(f"wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+def noise_image(seed, h, w):
+    return synthetic.band_limited_noise(np.random.default_rng(seed), h, w)
+
+
+def main():
+    logging.disable(logging.CRITICAL)
+    install_stubs()
+    sys.path.insert(0, REF_SRC)
+    torch.set_num_threads(8)
+    from icepy4d.thirdparty.LightGlue.lightglue import superpoint as r_sp, lightglue as r_lg
+    from icepy4d.thirdparty.SuperGlue.models import superpoint as r_sgsp, superglue as r_sg
+
+    sp_sd = synthetic.superpoint_state_dict(0)
+
+    # ---------------- G1: SuperPoint, stage by stage, both flavours ----------------
+    for tag, (h, w), k, seed in (("a", (96, 128), 64, 11), ("b", (136, 200), 2000, 12)):
+        img = noise_image(seed, h, w)
+        x = torch.tensor(img / 255.0, dtype=torch.float)[None, None]
+        net = r_sp.SuperPoint(max_num_keypoints=k).eval()
+        net.load_state_dict(sp_sd)
+        with torch.inference_mode():
+            feat = x
+            for nm in ("conv1a", "conv1b"):
+                feat = net.relu(getattr(net, nm)(feat))
+            feat = net.pool(feat)
+            for nm in ("conv2a", "conv2b"):
+                feat = net.relu(getattr(net, nm)(feat))
+            feat = net.pool(feat)
+            for nm in ("conv3a", "conv3b"):
+                feat = net.relu(getattr(net, nm)(feat))
+            feat = net.pool(feat)
+            for nm in ("conv4a", "conv4b"):
+                feat = net.relu(getattr(net, nm)(feat))
+            sc = net.convPb(net.relu(net.convPa(feat)))
+            sc = torch.nn.functional.softmax(sc, 1)[:, :-1]
+            b, _, hc, wc = sc.shape
+            sc = sc.permute(0, 2, 3, 1).reshape(b, hc, wc, 8, 8).permute(0, 1, 3, 2, 4).reshape(b, hc * 8, wc * 8)
+            nms4 = r_sp.simple_nms(sc, 4)
+            nms3 = r_sgsp.simple_nms(sc, 3)
+            dense = torch.nn.functional.normalize(net.convDb(net.relu(net.convDa(feat))), p=2, dim=1)
+            out = net.extract(x[0], resize=None)
+            sg_net = r_sgsp.SuperPoint({"nms_radius": 3, "keypoint_threshold": 0.001, "max_keypoints": -1 if tag == "b" else 50}).eval()
+            sg_net.load_state_dict(sp_sd)
+            sg_out = sg_net({"image": x})
+        save(f"g1_superpoint_{tag}", image=img, max_k=k,
+             feat_sha=sha(feat), feat_sample=feat[0, ::16, ::3, ::5],
+             score_map=sc[0], nms4=nms4[0], nms3=nms3[0],
+             dense_sha=sha(dense), dense_sample=dense[0, ::32],
+             keypoints=out["keypoints"][0], keypoint_scores=out["keypoint_scores"][0],
+             descriptors=out["descriptors"][0], image_size=out["image_size"][0],
+             sg_keypoints=sg_out["keypoints"][0], sg_scores=sg_out["scores"][0], sg_descriptors=sg_out["descriptors"][0])
+
+    # ---------------- G2: LightGlue on synthetic features ----------------
+    cases = [("default", 128, 128, {}), ("passthrough", 128, 128, {}), ("passthrough", 300, 257, {}),
+             ("earlystop", 128, 128, {}), ("prune", 300, 257, {"depth_confidence": -1}),
+             ("passthrough", 96, 160, {"width_confidence": -1, "depth_confidence": -1})]
+    for ci, (variant, m, n, conf) in enumerate(cases):
+        sd = synthetic.lightglue_state_dict(0, variant)
+        net = r_lg.LightGlue(features="superpoint", **conf).eval()
+        net.load_state_dict(sd)
+        f = synthetic.synthetic_features(ci, m, n)
+        data = {"image0": {"keypoints": torch.from_numpy(f["kpts0"])[None], "descriptors": torch.from_numpy(f["desc0"])[None],
+                           "image_size": torch.from_numpy(f["size0"])[None]},
+                "image1": {"keypoints": torch.from_numpy(f["kpts1"])[None], "descriptors": torch.from_numpy(f["desc1"])[None],
+                           "image_size": torch.from_numpy(f["size1"])[None]}}
+        with torch.inference_mode():
+            out = net(data)
+            # layer-0 descriptors and the layer-0 assignment for stage tests
+            e0 = net.posenc(r_lg.normalize_keypoints(data["image0"]["keypoints"], data["image0"]["image_size"]))
+            e1 = net.posenc(r_lg.normalize_keypoints(data["image1"]["keypoints"], data["image1"]["image_size"]))
+            s0 = net.transformers[0].self_attn(data["image0"]["descriptors"], e0)
+            s1 = net.transformers[0].self_attn(data["image1"]["descriptors"], e1)
+            c0, c1 = net.transformers[0].cross_attn(s0, s1)
+            sc0, sim0 = net.log_assignment[0](c0, c1)
+        print(f"  LG case {ci} {variant} {m}x{n}: stop={out['stop']} matches={int((out['matches0'] > -1).sum())} "
+              f"pruned0={int((out['prune0'] < out['stop']).sum()) if conf.get('width_confidence', 1) > 0 else 0}")
+        save(f"g2_lightglue_{ci}", variant=variant, m=m, n=n,
+             depth_confidence=conf.get("depth_confidence", 0.95), width_confidence=conf.get("width_confidence", 0.99),
+             seed=ci, encoding0=e0[:, 0, 0], self0=s0[0], cross0=c0[0], cross1=c1[0],
+             sim_l0=sim0[0], scores_l0=sc0[0],
+             matches0=out["matches0"][0], matches1=out["matches1"][0],
+             matching_scores0=out["matching_scores0"][0], matching_scores1=out["matching_scores1"][0],
+             stop=out["stop"], matches=out["matches"][0], scores=out["scores"][0],
+             prune0=out["prune0"][0], prune1=out["prune1"][0])
+
+    # ---------------- G3: SuperGlue on synthetic features ----------------
+    for ci, (variant, m, n, iters) in enumerate((("default", 128, 128, 20), ("passthrough", 200, 150, 20),
+                                                 ("passthrough", 128, 128, 100))):
+        sd = synthetic.superglue_state_dict(0, variant)
+        net = r_sg.SuperGlue({"sinkhorn_iterations": iters, "match_threshold": 0.3, "weights": "outdoor"}).eval()
+        net.load_state_dict(sd)
+        f = synthetic.synthetic_features(100 + ci, m, n)
+        data = {"keypoints0": torch.from_numpy(f["kpts0"])[None], "keypoints1": torch.from_numpy(f["kpts1"])[None],
+                "scores0": torch.from_numpy(f["scores0"])[None], "scores1": torch.from_numpy(f["scores1"])[None],
+                "descriptors0": torch.from_numpy(f["desc0"].T.copy())[None], "descriptors1": torch.from_numpy(f["desc1"].T.copy())[None],
+                "image0": torch.zeros(1, 1, 480, 640), "image1": torch.zeros(1, 1, 480, 640)}
+        with torch.inference_mode():
+            out = net(data)
+            kn0 = r_sg.normalize_keypoints(data["keypoints0"], data["image0"].shape)
+            kenc0 = data["descriptors0"] + net.kenc(kn0, data["scores0"])
+            rs = np.random.default_rng(77 + ci)
+            zin = torch.from_numpy(rs.normal(0, 2, size=(1, m, n)).astype(np.float32))
+            ot = r_sg.log_optimal_transport(zin, net.bin_score, iters)
+        print(f"  SG case {ci} {variant} {m}x{n} it={iters}: matches={int((out['matches0'] > -1).sum())}")
+        save(f"g3_superglue_{ci}", variant=variant, m=m, n=n, iters=iters, seed=100 + ci,
+             kenc0=kenc0[0], ot_in=zin[0], ot_out=ot[0],
+             matches0=out["matches0"][0], matches1=out["matches1"][0],
+             matching_scores0=out["matching_scores0"][0], matching_scores1=out["matching_scores1"][0])
+
+    # ---------------- G4: the wrapper classes (tile modes, quirks q1/q4/q5/q6) ----------------
+    from icepy4d.matching import matchers as r_m
+    from icepy4d.matching.enums import GeometricVerification, Quality, TileSelection
+    lg_sd = synthetic.lightglue_state_dict(0, "passthrough")
+    sg_sd = synthetic.superglue_state_dict(0, "passthrough")
+    _orig_sp_init = r_sp.SuperPoint.__init__
+    _orig_lg_init = r_lg.LightGlue.__init__
+
+    def sp_init(self, **conf):
+        _orig_sp_init(self, **conf)
+        self.load_state_dict(sp_sd)
+
+    def lg_init(self, *a, **k):
+        _orig_lg_init(self, *a, **k)
+        self.load_state_dict(lg_sd)
+
+    r_sp.SuperPoint.__init__ = sp_init
+    r_lg.LightGlue.__init__ = lg_init
+    import builtins
+    _print = builtins.print
+    img0, img1 = synthetic.translated_pair(3, 200, 304)
+    cfg = dict(geometric_verification=GeometricVerification.NONE, max_keypoints=256)
+    res = {}
+    builtins.print = lambda *a, **k: None
+    try:
+        m = r_m.LightGlueMatcher({"force_cpu": True})
+        m.match(img0, img1, quality=Quality.HIGH, tile_selection=TileSelection.NONE, **cfg)
+        res.update(lg_none_mkpts0=m.mkpts0, lg_none_mkpts1=m.mkpts1, lg_none_desc0=m.descriptors0,
+                   lg_none_scores0=m.scores0, lg_none_mconf=m.mconf)
+        m = r_m.LightGlueMatcher({"force_cpu": True})
+        m.match(img0, img1, quality=Quality.HIGH, tile_selection=TileSelection.GRID, grid=[2, 2], overlap=20,
+                save_dir="/tmp/gen_golden_lg", **cfg)
+        res.update(lg_grid_mkpts0=m.mkpts0, lg_grid_mkpts1=m.mkpts1, lg_grid_desc0=m.descriptors0, lg_grid_desc1=m.descriptors1,
+                   lg_grid_scores0=m.scores0, lg_grid_scores1=m.scores1, lg_grid_mconf=m.mconf)
+        sgm = r_m.SuperGlueMatcher({"weights": "outdoor", "keypoint_threshold": 0.001, "max_keypoints": 256,
+                                    "match_threshold": 0.3, "force_cpu": True})
+        sgm.matcher.superpoint.load_state_dict(sp_sd)
+        sgm.matcher.superglue.load_state_dict(sg_sd)
+        sgm.match(img0, img1, quality=Quality.HIGH, tile_selection=TileSelection.NONE,
+                  geometric_verification=GeometricVerification.NONE)
+        res.update(sg_none_mkpts0=sgm.mkpts0, sg_none_mkpts1=sgm.mkpts1, sg_none_desc0=sgm.descriptors0,
+                   sg_none_scores0=sgm.scores0, sg_none_mconf=sgm.mconf)
+        sgm.reset()
+        sgm.match(img0, img1, quality=Quality.HIGH, tile_selection=TileSelection.EXHAUSTIVE, grid=[1, 2], overlap=10,
+                  geometric_verification=GeometricVerification.NONE, save_dir="/tmp/gen_golden_sg")
+        res.update(sg_exh_mkpts0=sgm.mkpts0, sg_exh_mkpts1=sgm.mkpts1, sg_exh_scores0=sgm.scores0, sg_exh_mconf=sgm.mconf)
+        t = r_m.Tiler(grid=[2, 3], overlap=15, origin=[0, 0])
+        lims, origin = t.compute_limits_by_grid(img0)
+        res.update(tiler_limits=np.array([lims[i] for i in sorted(lims)]), tiler_patch=t.extract_patch(img0, lims[4]))
+    finally:
+        builtins.print = _print
+    for k_, v_ in res.items():
+        print("   ", k_, None if v_ is None else np.asarray(v_).shape)
+    save("g4_wrappers", image0=img0, image1=img1, **res)
+
+    # ---------------- G5: assets pair (config 1), decoded here with PIL ----------------
+    from PIL import Image
+    a0 = np.asarray(Image.open("/root/reference/assets/img/cam1/IMG_2637.jpg").convert("RGB"))
+    a1 = np.asarray(Image.open("/root/reference/assets/img/cam2/IMG_1112.jpg").convert("RGB"))
+
+    def gray(rgb):  # pinned fp32 formula, rounded to u8 (the jpeg never travels)
+        f = rgb.astype(np.float32)
+        return np.clip(np.rint((0.299 * f[..., 0] + 0.587 * f[..., 1]) + 0.114 * f[..., 2]), 0, 255).astype(np.uint8)
+
+    g0, g1 = gray(a0), gray(a1)
+    lg_def = synthetic.lightglue_state_dict(0, "passthrough")
+    r_lg.LightGlue.__init__ = _orig_lg_init
+    r_sp.SuperPoint.__init__ = _orig_sp_init
+    ext = r_sp.SuperPoint(max_num_keypoints=2048).eval()
+    ext.load_state_dict(sp_sd)
+    mt = r_lg.LightGlue(features="superpoint").eval()
+    mt.load_state_dict(lg_def)
+    with torch.inference_mode():
+        f0 = ext.extract(torch.tensor(g0[None] / 255.0, dtype=torch.float), resize=None)
+        f1 = ext.extract(torch.tensor(g1[None] / 255.0, dtype=torch.float), resize=None)
+        o = mt({"image0": f0, "image1": f1})
+    print(f"  assets: kpts {f0['keypoints'].shape[1]}/{f1['keypoints'].shape[1]} stop={o['stop']} matches={int((o['matches0'] > -1).sum())}")
+    save("g5_assets", gray0=g0, gray1=g1, keypoints0=f0["keypoints"][0], keypoints1=f1["keypoints"][0],
+         scores0=f0["keypoint_scores"][0], scores1=f1["keypoint_scores"][0],
+         desc0_sha=sha(f0["descriptors"][0]), desc0_sample=f0["descriptors"][0][::16],
+         matches0=o["matches0"][0], matching_scores0=o["matching_scores0"][0], stop=o["stop"],
+         prune0=o["prune0"][0], prune1=o["prune1"][0])
+
+
+if __name__ == "__main__":
+    main()
