@@ -1,0 +1,108 @@
+// Context object behind the C ABI: host copies of the state-dict tensors, packed device weights, workspaces.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/icematch.h"
+#include "kernels.h"
+
+namespace im {
+
+std::vector<float> pack_conv3x3(const float* w, int cout, int cin);  // [cout][cin][3][3] -> [cin/16][9][cout][16]
+
+struct SuperPointW {
+    bool ready = false;
+    float* c1a_w = nullptr; float* c1a_b = nullptr;          // [9][64], [64]
+    float* cw[10] = {nullptr}; float* cb[10] = {nullptr};     // conv1b..conv4b, convPa, convDa (packed slabs)
+    float* pb_w = nullptr; float* pb_b = nullptr;             // convPb [65][256], [65]
+    float* db_w = nullptr; float* db_b = nullptr;             // convDb [256][256], [256]
+};
+
+struct LightGlueW {
+    bool ready = false;
+    float* wr = nullptr;                    // posenc.Wr [32][2]
+    // per layer (9): contiguous blocks so that a device-side layer index can select them
+    float* qkv_w = nullptr; float* qkv_b = nullptr;      // [L][768][256] rows permuted to [q|k|v][head][d], [L][768]
+    float* out_w = nullptr; float* out_b = nullptr;      // [L][256][256]
+    float* sf0_w = nullptr; float* sf0_b = nullptr;      // self ffn.0 [L][512][512]
+    float* sln_g = nullptr; float* sln_b = nullptr;      // [L][512]
+    float* sf3_w = nullptr; float* sf3_b = nullptr;      // [L][256][512]
+    float* cqk_w = nullptr; float* cqk_b = nullptr;      // cross to_qk [L][256][256]
+    float* cv_w = nullptr;  float* cv_b = nullptr;
+    float* co_w = nullptr;  float* co_b = nullptr;
+    float* cf0_w = nullptr; float* cf0_b = nullptr;
+    float* cln_g = nullptr; float* cln_b = nullptr;
+    float* cf3_w = nullptr; float* cf3_b = nullptr;
+    float* fp_w = nullptr;  float* fp_b = nullptr;       // log_assignment.final_proj [L][256][256], [L][256]
+    float* ma_w = nullptr;  float* ma_b = nullptr;       // matchability [L][256], [L]
+    float* tc_w = nullptr;  float* tc_b = nullptr;       // token_confidence [L-1][256], [L-1]
+    float thr[16] = {0};                                 // confidence_thresholds (host)
+};
+
+struct SuperGlueW {
+    bool ready = false;
+    float* kenc_w[5] = {nullptr}; float* kenc_b[5] = {nullptr};  // BN folded; layer 0 K padded 3 -> 32
+    float* proj_w = nullptr; float* proj_b = nullptr;    // [18][3][256][256] head-major output rows, [18][3][256]
+    float* merge_w = nullptr; float* merge_b = nullptr;  // [18][256][256] head-major input columns
+    float* mlp0_w = nullptr; float* mlp0_b = nullptr;    // [18][512][512] BN folded, second half of K head-major-agnostic
+    float* mlp3_w = nullptr; float* mlp3_b = nullptr;    // [18][256][512]
+    float* fp_w = nullptr; float* fp_b = nullptr;        // final_proj [256][256]
+    float bin_score = 1.f;
+};
+
+}  // namespace im
+
+struct im_ctx {
+    int device = 0;
+    std::string err;
+    std::map<std::string, std::vector<float>> host_w;  // "model/key" -> data
+    std::vector<void*> allocs;
+    im::SuperPointW sp;
+    im::LightGlueW lg;
+    im::SuperGlueW sg;
+
+    // reserved workspace
+    int max_h = 0, max_w = 0, max_images = 0, max_kpts = 0;
+    struct Workspace* ws = nullptr;
+
+    int fail(int code, const char* fmt, ...) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof(buf), fmt, ap);
+        va_end(ap);
+        err = buf;
+        return code;
+    }
+    template <typename T>
+    T* dalloc(size_t n) {
+        void* p = nullptr;
+        if (hipMalloc(&p, n * sizeof(T) + 256) != hipSuccess) return nullptr;
+        allocs.push_back(p);
+        return reinterpret_cast<T*>(p);
+    }
+    float* upload(const std::vector<float>& v) {
+        float* p = dalloc<float>(v.size());
+        if (p && hipMemcpy(p, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+        return p;
+    }
+    void free_all();
+};
+
+#define IM_CHECK_CTX(ctx)                                \
+    do {                                                 \
+        if (!(ctx)) return -1;                           \
+        if (hipSetDevice((ctx)->device) != hipSuccess) return (ctx)->fail(-3, "hipSetDevice failed"); \
+    } while (0)
+
+#define IM_HIP(ctx, expr)                                                                                   \
+    do {                                                                                                    \
+        hipError_t _e = (expr);                                                                             \
+        if (_e != hipSuccess)                                                                               \
+            return (ctx)->fail(-100 - (int)_e, "%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+    } while (0)

@@ -1,0 +1,184 @@
+// fp32 "NT" GEMM on the f32-input matrix cores (v_mfma_f32_32x32x2_f32) with fused epilogues.
+//
+//   C_z[m][n] = epi( sum_k A_z[m][k] * W[n][k] )          A: [M][K] row-major, W: [N][K] row-major
+//
+// Used for every nn.Linear / Conv1d(k=1) / 1x1 Conv2d of the path (reference call sites:
+// `lightglue/lightglue.py:153,160,162,192-193,212,277-281`, `lightglue/superpoint.py:169,204`,
+// `SuperGlue/models/superglue.py:51-61,104-116,276-280`) and for the keypoint x keypoint score matrix
+// (`lightglue/lightglue.py:280`, `superglue.py:279`).
+//
+// Tiling: 256 threads = 4 waves in a 2x2 grid; each wave owns (BM/2)x(BN/2) of the block tile as
+// 32x32 MFMA tiles. K is consumed in slabs of 32 staged through LDS (row stride 36 floats: the
+// ds_read_b128 fragment reads are bank-conflict free). The contraction index inside a slab is
+// permuted (lane-half h reads k = 16h .. 16h+15 contiguously) so that one 16-byte LDS read feeds four
+// MFMAs; A and B use the same permutation, so the product is unchanged up to summation order.
+// Global loads of slab t+1 are issued before the MFMAs of slab t (register staging).
+#include "common.h"
+#include "kernels.h"
+
+namespace im {
+
+static constexpr int BK = 32;
+static constexpr int LDS_LD = BK + 4;
+
+template <int BM, int BN, int EPI>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
+    if (a.active && *a.active == 0) return;
+    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int MB = WM / 32, NB = WN / 32;
+    constexpr int A_IT = BM / 32, B_IT = BN / 32;  // float4 loads per thread per slab
+    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDS_LD];
+    float* sA = smem;
+    float* sB = smem + BM * LDS_LD;
+
+    const int z = blockIdx.z;
+    const int M = a.m_ptr ? a.m_ptr[z] : a.m_max;
+    const int Nlive = a.n_ptr ? min(*a.n_ptr, a.N) : a.N;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    if (m0 >= M || n0 >= Nlive) return;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 31, hh = lane >> 5;
+    const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+
+    const int sel = a.sel ? *a.sel : 0;
+    const float* Wp = a.W + (long)z * a.w_bstride + (long)sel * a.w_sel_stride;
+    const float* bias = a.bias ? a.bias + (long)sel * a.bias_sel_stride : nullptr;
+    const float* A0 = a.A + (long)z * a.a_bstride;
+    const float* A1 = a.A1 ? a.A1 + (long)z * a.a1_bstride : nullptr;
+
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[A_IT], rb[B_IT];
+    auto load_slab = [&](int k0) {
+        const float* src = A0;
+        int ld = a.lda, kk = k0;
+        if (A1 && k0 >= a.ksplit) { src = A1; ld = a.lda1; kk = k0 - a.ksplit; }
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            int idx = tid + it * 256;
+            int row = m0 + (idx >> 3), c4 = idx & 7;
+            ra[it] = (row < M) ? *reinterpret_cast<const float4*>(src + (long)row * ld + kk + c4 * 4)
+                               : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) {
+            int idx = tid + it * 256;
+            int row = n0 + (idx >> 3), c4 = idx & 7;
+            rb[it] = (row < Nlive) ? *reinterpret_cast<const float4*>(Wp + (long)row * a.ldw + k0 + c4 * 4)
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_slab = [&]() {
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            int idx = tid + it * 256;
+            *reinterpret_cast<float4*>(sA + (idx >> 3) * LDS_LD + (idx & 7) * 4) = ra[it];
+        }
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) {
+            int idx = tid + it * 256;
+            *reinterpret_cast<float4*>(sB + (idx >> 3) * LDS_LD + (idx & 7) * 4) = rb[it];
+        }
+    };
+
+    load_slab(0);
+    for (int k0 = 0; k0 < a.K; k0 += BK) {
+        store_slab();
+        __syncthreads();
+        if (k0 + BK < a.K) load_slab(k0 + BK);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float4 fa[MB], fb[NB];
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+                fa[i] = *reinterpret_cast<const float4*>(sA + (wm0 + i * 32 + c) * LDS_LD + hh * 16 + t * 4);
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+                fb[j] = *reinterpret_cast<const float4*>(sB + (wn0 + j * 32 + c) * LDS_LD + hh * 16 + t * 4);
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    acc[i][j] = mfma32(fa[i].x, fb[j].x, acc[i][j]);
+                    acc[i][j] = mfma32(fa[i].y, fb[j].y, acc[i][j]);
+                    acc[i][j] = mfma32(fa[i].z, fb[j].z, acc[i][j]);
+                    acc[i][j] = mfma32(fa[i].w, fb[j].w, acc[i][j]);
+                }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds column n = .. + c, rows acc_row(r, hh)
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int col = n0 + wn0 + j * 32 + c;
+            const bool col_ok = col < Nlive;
+            const float bv = (bias && col_ok) ? bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm0 + i * 32 + acc_row(r, hh);
+                float val = acc[i][j][r] + bv;
+                if constexpr (EPI == EPI_QKV_ROPE) {
+                    // rotary (`lightglue/lightglue.py:49-57`): pairs (2i, 2i+1) share a frequency;
+                    // out = t * cos + rotate_half(t) * sin, rotate_half: (x0, x1) -> (-x1, x0)
+                    float partner = __shfl_xor(val, 1);
+                    if (row < M && col_ok) {
+                        const int which = col >> 8, hd = col & 255, head = hd >> 6, d = hd & 63;
+                        float outv = val;
+                        if (which < 2) {
+                            const long e = (long)z * a.enc_bstride + (long)row * 32 + (d >> 1);
+                            const float cs = a.cs[e], sn = a.sn[e];
+                            outv = (d & 1) ? (val * cs) + (partner * sn) : (val * cs) + ((-partner) * sn);
+                        }
+                        float* dst = which == 0 ? a.q : (which == 1 ? a.k : a.v);
+                        dst[(long)z * a.head_bstride + (long)head * a.head_stride + (long)row * 64 + d] = outv;
+                    }
+                } else if (row < M && col_ok) {
+                    if constexpr (EPI == EPI_BIAS) {
+                        a.C[(long)z * a.c_bstride + (long)row * a.ldc + col] = a.alpha * val;
+                    } else if constexpr (EPI == EPI_BIAS_RELU) {
+                        a.C[(long)z * a.c_bstride + (long)row * a.ldc + col] = fmaxf(val, 0.f);
+                    } else if constexpr (EPI == EPI_BIAS_RESID) {
+                        const float rv = a.R[(long)z * a.r_bstride + (long)row * a.ldr + col];
+                        a.C[(long)z * a.c_bstride + (long)row * a.ldc + col] = rv + val;
+                    } else if constexpr (EPI == EPI_HEADS) {
+                        a.q[(long)z * a.head_bstride + (long)(col >> 6) * a.head_stride + (long)row * 64 + (col & 63)] = a.alpha * val;
+                    }
+                }
+            }
+        }
+}
+
+hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
+    if (a.K % BK != 0 || (a.A1 && a.ksplit % BK != 0)) return hipErrorInvalidValue;
+    const int bm = a.big_tile ? 128 : 64, bn = bm;
+    dim3 grid((a.N + bn - 1) / bn, (a.m_max + bm - 1) / bm, a.batch), block(256);
+    if (grid.y == 0 || grid.x == 0) return hipSuccess;
+#define IM_GEMM_CASE(E)                                                                  \
+    case E:                                                                              \
+        if (a.big_tile) hipLaunchKernelGGL((gemm_nt_kernel<128, 128, E>), grid, block, 0, s, a); \
+        else hipLaunchKernelGGL((gemm_nt_kernel<64, 64, E>), grid, block, 0, s, a);      \
+        break;
+    switch (a.epi) {
+        IM_GEMM_CASE(EPI_BIAS)
+        IM_GEMM_CASE(EPI_BIAS_RESID)
+        IM_GEMM_CASE(EPI_HEADS)
+        IM_GEMM_CASE(EPI_QKV_ROPE)
+        IM_GEMM_CASE(EPI_BIAS_RELU)
+        default: return hipErrorInvalidValue;
+    }
+#undef IM_GEMM_CASE
+    return hipGetLastError();
+}
+
+}  // namespace im

@@ -1,0 +1,71 @@
+// Internal launch API of libicematch (C++ side; the public boundary is include/icematch.h).
+// All pointers are device pointers unless stated. Dynamic sizes (keypoint counts) live in device
+// memory so that no launch needs a host round trip: grids are sized for the maximum and blocks
+// beyond the live count exit.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace im {
+
+// ------------------------------------------------------------------ gemm.hip
+enum GemmEpi {
+    EPI_BIAS = 0,       // C = alpha * (acc + bias)
+    EPI_BIAS_RESID = 1, // C = R + (acc + bias)
+    EPI_HEADS = 2,      // head-major store: q[z][col / 64][row][col % 64] = alpha * (acc + bias)
+    EPI_QKV_ROPE = 3,   // N = 768 = [q | k | v] x [head][64]; rotary on q, k; head-major stores
+    EPI_BIAS_RELU = 4,  // C = max(acc + bias, 0)
+};
+
+struct GemmArgs {
+    // C_z[m][n] = epi(sum_k A_z[m][k] * W[n][k]),  A row-major (K contiguous), W row-major [N][K]
+    const float* A = nullptr;  long a_bstride = 0;  int lda = 0;
+    const float* A1 = nullptr; long a1_bstride = 0; int lda1 = 0; int ksplit = 0;  // k >= ksplit reads A1[m][k - ksplit]
+    const float* W = nullptr;  int ldw = 0; long w_bstride = 0;
+    const float* bias = nullptr;
+    const int* sel = nullptr; long w_sel_stride = 0; long bias_sel_stride = 0;     // W += *sel * stride
+    int N = 0, K = 0;
+    int m_max = 0;                 // rows the grid covers
+    const int* m_ptr = nullptr;    // live rows per batch element (device), or null => m_max
+    int m_ptr_xor = 0;             // rows taken from m_ptr[z ^ m_ptr_xor]
+    const int* n_ptr = nullptr;    // live columns (device) for the score GEMM, or null => N
+    const int* active = nullptr;   // device flag, 0 => kernel is a no-op
+    int batch = 1;
+    float alpha = 1.f;
+    float* C = nullptr; long c_bstride = 0; int ldc = 0;
+    const float* R = nullptr; long r_bstride = 0; int ldr = 0;
+    float* q = nullptr; float* k = nullptr; float* v = nullptr; long head_bstride = 0; long head_stride = 0;
+    const float* cs = nullptr; const float* sn = nullptr; long enc_bstride = 0;    // rotary tables [rows][32]
+    int epi = EPI_BIAS;
+    int big_tile = 0;              // 128x128 block tile (score GEMM) instead of 64x64
+};
+hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
+
+// ------------------------------------------------------------------ attention.hip
+struct AttnArgs {
+    // out[z][row][head * 64 + d] = softmax_j(scale * q_z[head][row] . k_y[head][j]) v_y[head][j],  y = cross ? z ^ 1 : z
+    const float* q = nullptr; const float* k = nullptr; const float* v = nullptr;
+    long bstride = 0; long hstride = 0;         // [z][head][row][64]
+    float* out = nullptr; long out_bstride = 0; int ldo = 256;
+    const int* n_ptr = nullptr;                 // n_ptr[z] live points of image z
+    int n_max = 0; int batch = 2; int heads = 4; int cross = 0;
+    float scale = 1.f;
+    const int* active = nullptr;
+};
+hipError_t launch_flash_attn(const AttnArgs& a, hipStream_t s);
+
+// ------------------------------------------------------------------ conv.hip
+struct ConvArgs {
+    const float* in = nullptr;   // NHWC [B][H][W][Cin]
+    const float* w = nullptr;    // packed [Cin / 16][9][Cout][16]
+    const float* bias = nullptr; // [Cout]
+    float* out = nullptr;        // NHWC [B][Ho][Wo][Cout], Ho = pool ? H / 2 : H
+    int B = 1, H = 0, W = 0, Cin = 0, Cout = 0;
+    int pool = 0;                // fused 2x2 max-pool (floor) after bias + ReLU
+    int relu = 1;
+};
+hipError_t launch_conv3x3(const ConvArgs& a, hipStream_t s);
+// conv1a: u8 gray [B][H][W] -> (x / 255) * w + b, ReLU -> NHWC [B][H][W][64]; w packed [9][64]
+hipError_t launch_conv1a(const uint8_t* img, const float* w, const float* bias, float* out, int B, int H, int W, hipStream_t s);
+
+}  // namespace im

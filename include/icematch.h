@@ -1,0 +1,115 @@
+/* libicematch — C ABI of the MI355X (gfx950) learned extraction + matching hot path.
+ *
+ * The reference (franioli/icepy4d) is pure Python: its "plugin" seam for this path is
+ * `ImageMatcherBase._match_images(image0, image1, **config)` (`src/icepy4d/matching/matchers.py:276-302`),
+ * implemented by `LightGlueMatcher._match_images` (`:1226-1304`) and `SuperGlueMatcher._match_images`
+ * (`:892-940`), which call torch modules.  This library is what those two methods bind instead of torch:
+ * the host side (`icepy4d_amd/matching/matchers.py`, ctypes) keeps the reference's class / method names.
+ *
+ * Conventions
+ *   - every `d_*` pointer is a DEVICE pointer owned by the caller (e.g. a torch tensor); `h_*` is host memory
+ *   - `stream` is a `hipStream_t` passed as void*; calls only enqueue work (no host sync) unless stated
+ *   - return value: 0 = ok, negative = error (see `im_last_error`); no exceptions cross the boundary
+ *   - a context is not re-entrant: use one context per (process, device, stream)
+ *   - dynamic sizes (keypoint counts) stay in device memory: `d_n*` are `int32` device scalars
+ */
+#ifndef ICEMATCH_H
+#define ICEMATCH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct im_ctx im_ctx;
+
+/* ---- context ------------------------------------------------------------------------------------ */
+int im_version(void);
+/* Binds to HIP device `device` (replaces `.to(device)` at `matchers.py:852, 1256-1258`). */
+int im_ctx_create(int device, im_ctx** out);
+void im_ctx_destroy(im_ctx* ctx);
+const char* im_last_error(im_ctx* ctx);
+/* Allocates every workspace for images up to max_h x max_w, `max_images` images per call and `max_kpts`
+ * keypoints per image. Must be called before any forward; may be called again to grow. Synchronises. */
+int im_ctx_reserve(im_ctx* ctx, int max_h, int max_w, int max_images, int max_kpts);
+
+/* ---- weights: tensors are passed under their OFFICIAL state-dict key names --------------------------
+ * model: "superpoint" (`lightglue/superpoint.py:118-137` == `SuperGlue/models/superpoint.py:122-140`),
+ *        "lightglue"  (`lightglue/lightglue.py:350-373`), "superglue" (`SuperGlue/models/superglue.py:221-242`).
+ * `h_data` is host fp32, `numel` elements, torch-contiguous layout. Replaces `load_state_dict`
+ * (`lightglue/superpoint.py:139-140`, `lightglue/lightglue.py:376-392`, `superglue.py:244-247`). */
+int im_set_tensor(im_ctx* ctx, const char* model, const char* key, const float* h_data, size_t numel);
+/* Checks that every tensor of `model` was provided, re-packs (conv slabs, head-major q/k/v, folded BatchNorm)
+ * and uploads. Synchronises. */
+int im_finalize_weights(im_ctx* ctx, const char* model);
+
+/* ---- SuperPoint: `SuperPoint.extract` / `.forward` -----------------------------------------------
+ * (`lightglue/superpoint.py:146-231`, `SuperGlue/models/superpoint.py:151-220`).
+ * d_gray: uint8 [n_images][h][w].  flavour 0 = LightGlue (border := -1 before threshold), 1 = SuperGlue.
+ * max_kpts <= 0 means unlimited (bounded by the reserved max_kpts).
+ * Outputs (row stride = reserved max_kpts): d_kpts [n_images][max_kpts][2] (x, y), d_scores [n_images][max_kpts],
+ * d_desc [n_images][max_kpts][256] (L2-normalised), d_n [n_images]. */
+int im_superpoint_forward(im_ctx* ctx, const uint8_t* d_gray, int n_images, int h, int w,
+                          int nms_radius, float threshold, int border, int max_kpts, int flavour,
+                          float* d_kpts, float* d_scores, float* d_desc, int32_t* d_n, void* stream);
+
+/* ---- LightGlue: `LightGlue._forward` on the reference's CPU path (`lightglue/lightglue.py:436-556`) ----
+ * Inputs for image 0/1 are the two slices of the SuperPoint outputs above (same strides, n_images = 2).
+ * h_size: host [2][2] = (W, H) of image 0 and 1 (`image_size`, `lightglue/superpoint.py:229`).
+ * Outputs: d_matches [2][max_kpts] int32 (-1 = none; row 0 = matches0, row 1 = matches1),
+ * d_mscores [2][max_kpts], d_prune [2][max_kpts] int32, d_info int32[4] = {stop, n0_final, n1_final, 0}. */
+typedef struct {
+    float depth_confidence;  /* <= 0 disables early stop   (`lightglue.py:317`) */
+    float width_confidence;  /* <= 0 disables point pruning (`lightglue.py:318`) */
+    float filter_threshold;  /* `lightglue.py:319` */
+    int n_layers;            /* 9 */
+} im_lightglue_conf;
+int im_lightglue_forward(im_ctx* ctx, const float* d_kpts, const float* d_desc, const int32_t* d_n,
+                         const float* h_size, const im_lightglue_conf* conf,
+                         int32_t* d_matches, float* d_mscores, int32_t* d_prune, int32_t* d_info, void* stream);
+
+/* ---- SuperGlue: `SuperGlue.forward` (`SuperGlue/models/superglue.py:250-305`) ---------------------------
+ * d_desc rows are [max_kpts][256] (the transposed view of the reference's [256, K]); h_shape: host [2][2] = (H, W)
+ * of the image tensors (`data['image0'].shape`). Outputs as for LightGlue (d_info = {0, n0, n1, 0}). */
+typedef struct {
+    int sinkhorn_iterations; /* icepy4d default 20 (`matchers.py:857`) */
+    float match_threshold;   /* icepy4d default 0.3 (`matchers.py:864`) */
+    int n_layers;            /* 18 */
+} im_superglue_conf;
+int im_superglue_forward(im_ctx* ctx, const float* d_kpts, const float* d_scores, const float* d_desc,
+                         const int32_t* d_n, const float* h_shape, const im_superglue_conf* conf,
+                         int32_t* d_matches, float* d_mscores, int32_t* d_info, void* stream);
+
+/* ---- stage entry points (what the stage-isolated parity tests call; also usable on their own) ----------- */
+/* C[m][n] = alpha * (sum_k A[m][k] W[n][k] + bias[n]); fp32 MFMA GEMM. bias may be NULL. big_tile: 128x128 tiles. */
+int im_gemm_nt(im_ctx* ctx, const float* d_a, const float* d_w, const float* d_bias, float* d_c,
+               int m, int n, int k, float alpha, int big_tile, void* stream);
+/* 3x3 conv, NHWC fp32, weights in torch layout [cout][cin][3][3] on the HOST (packed + uploaded inside; synchronises) */
+int im_conv3x3(im_ctx* ctx, const float* d_in, const float* h_weight, const float* h_bias, float* d_out,
+               int b, int h, int w, int cin, int cout, int relu, int pool, void* stream);
+/* fp32 flash attention: q, k, v [batch][heads][n_max][64]; out [batch][n_max][heads*64]; cross: kv of image z^1 */
+int im_flash_attn(im_ctx* ctx, const float* d_q, const float* d_k, const float* d_v, float* d_out,
+                  const int32_t* d_n, int n_max, int batch, int heads, int cross, float scale, void* stream);
+/* `simple_nms` (`lightglue/superpoint.py:50-65`): d_scores, d_out [n_images][h][w] */
+int im_nms(im_ctx* ctx, const float* d_scores, float* d_out, int n_images, int h, int w, int radius, void* stream);
+/* border / threshold / row-major compaction / top-k (`lightglue/superpoint.py:177-200`) on an NMS map */
+int im_select_topk(im_ctx* ctx, const float* d_nms, int n_images, int h, int w, int border, float threshold,
+                   int max_kpts, float* d_kpts, float* d_scores, int32_t* d_n, void* stream);
+/* `sample_descriptors` (`lightglue/superpoint.py:75-87`) incl. the dense per-cell L2 normalisation (`:205`):
+ * d_dense_raw = convDb output, NHWC [n_images][hc][wc][256]; d_desc [n_images][max_kpts][256] */
+int im_sample_descriptors(im_ctx* ctx, const float* d_dense_raw, int n_images, int hc, int wc,
+                          const float* d_kpts, const int32_t* d_n, float* d_desc, void* stream);
+/* `sigmoid_log_double_softmax` + `filter_matches` (`lightglue/lightglue.py:253-306`) on a given similarity matrix:
+ * d_sim [m][ld], d_z0 [m], d_z1 [n] -> d_matches [2][max(m,n)] int32 etc. (compact index space) */
+int im_assign_from_sim(im_ctx* ctx, const float* d_sim, int m, int n, int ld, const float* d_z0, const float* d_z1,
+                       float threshold, int32_t* d_m0, int32_t* d_m1, float* d_ms0, float* d_ms1, void* stream);
+/* `log_optimal_transport` (`SuperGlue/models/superglue.py:152-186`): d_scores [m][ld] -> d_out [(m+1)][(n+1)] */
+int im_log_optimal_transport(im_ctx* ctx, const float* d_scores, int m, int n, int ld, float bin_score, int iters,
+                             float* d_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ICEMATCH_H */

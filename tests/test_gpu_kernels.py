@@ -1,0 +1,96 @@
+"""Stage-isolated parity of the MFMA kernels (through the C ABI) against plain torch fp32 references.
+fp32 tolerance: the kernels accumulate in a different order than torch-CPU, so results agree to ~1e-6
+relative to the dot-product magnitude; the tests allow 2e-5 absolute on O(1) values (north_star: 1e-4)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from icepy4d_amd import _lib
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    c = _lib.Context(0)
+    yield c
+    c.close()
+
+
+def dev(a):
+    return torch.as_tensor(a).cuda().contiguous()
+
+
+@pytest.mark.parametrize("m,n,k,big", [(64, 64, 32, 0), (100, 65, 256, 0), (4096, 256, 512, 0), (300, 257, 256, 1), (1024, 768, 256, 1)])
+def test_gemm_nt(ctx, m, n, k, big):
+    from icepy4d_amd._lib import ptr, stream_ptr
+    g = torch.Generator().manual_seed(m + n)
+    a = torch.randn(m, k, generator=g)
+    w = torch.randn(n, k, generator=g) / k ** 0.5
+    b = torch.randn(n, generator=g)
+    ref = 0.5 * (a.double() @ w.double().t() + b.double())
+    da, dw, db = dev(a), dev(w), dev(b)
+    dc = torch.full((m, n), float("nan"), device="cuda")
+    ctx.call("im_gemm_nt", ptr(da), ptr(dw), ptr(db), ptr(dc), m, n, k, 0.5, big, stream_ptr())
+    torch.cuda.synchronize()
+    err = (dc.cpu().double() - ref).abs().max().item()
+    assert err < 2e-5, err
+
+
+def test_gemm_asymmetric_layout(ctx):
+    """A = I with an asymmetric W catches a transposed C-write (guide: MFMA layout check)."""
+    from icepy4d_amd._lib import ptr, stream_ptr
+    n = 64
+    a = torch.eye(n)
+    w = torch.arange(n * n, dtype=torch.float32).reshape(n, n)
+    dc = torch.zeros(n, n, device="cuda")
+    da, dw = dev(a), dev(w)  # keep alive: a temporary would be freed and its address reused
+    ctx.call("im_gemm_nt", ptr(da), ptr(dw), None, ptr(dc), n, n, n, 1.0, 0, stream_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(dc.cpu(), w.t())
+
+
+@pytest.mark.parametrize("cin,cout,h,w,pool", [(16, 64, 8, 32, 0), (64, 64, 37, 70, 0), (64, 128, 40, 64, 1), (128, 256, 17, 33, 0), (64, 64, 31, 47, 1)])
+def test_conv3x3(ctx, cin, cout, h, w, pool):
+    from icepy4d_amd._lib import ptr, stream_ptr
+    g = torch.Generator().manual_seed(cin + cout + h)
+    x = torch.randn(2, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    b = torch.randn(cout, generator=g)
+    ref = F.relu(F.conv2d(x.double(), wt.double(), b.double(), padding=1))
+    if pool:
+        ref = F.max_pool2d(ref, 2, 2)
+    dx = dev(x.permute(0, 2, 3, 1))
+    ho, wo = ref.shape[-2:]
+    dout = torch.full((2, ho, wo, cout), float("nan"), device="cuda")
+    ctx.call("im_conv3x3", ptr(dx), ptr(wt.contiguous()), ptr(b), ptr(dout), 2, h, w, cin, cout, 1, pool, stream_ptr())
+    torch.cuda.synchronize()
+    err = (dout.cpu().permute(0, 3, 1, 2).double() - ref).abs().max().item()
+    assert err < 2e-5, err
+
+
+@pytest.mark.parametrize("n0,n1,cross", [(128, 128, 0), (300, 257, 0), (300, 257, 1), (1000, 77, 1), (64, 1, 1)])
+def test_flash_attn(ctx, n0, n1, cross):
+    from icepy4d_amd._lib import ptr, stream_ptr
+    nmax, heads = 1024, 4
+    g = torch.Generator().manual_seed(n0 * 7 + n1)
+    q = torch.randn(2, heads, nmax, 64, generator=g)
+    k = torch.randn(2, heads, nmax, 64, generator=g)
+    v = torch.randn(2, heads, nmax, 64, generator=g)
+    ns = [n0, n1]
+    scale = 0.125
+    dout = torch.full((2, nmax, heads * 64), float("nan"), device="cuda")
+    dn = torch.tensor(ns, dtype=torch.int32, device="cuda")
+    dq, dk, dv = dev(q), dev(k), dev(v)
+    ctx.call("im_flash_attn", ptr(dq), ptr(dk), ptr(dv), ptr(dout), ptr(dn), nmax, 2, heads, cross, scale, stream_ptr())
+    torch.cuda.synchronize()
+    out = dout.cpu()
+    for z in range(2):
+        y = z ^ 1 if cross else z
+        qq, kk, vv = q[z, :, :ns[z]].double(), k[y, :, :ns[y]].double(), v[y, :, :ns[y]].double()
+        att = torch.softmax(qq @ kk.transpose(-1, -2) * scale, -1) @ vv  # [h, n, 64]
+        ref = att.transpose(0, 1).reshape(ns[z], heads * 64)
+        err = (out[z, :ns[z]].double() - ref).abs().max().item()
+        assert err < 2e-5, (z, err)
+        assert torch.isnan(out[z, ns[z]:]).all()  # rows beyond the live count are untouched
