@@ -18,12 +18,12 @@ _lib: Optional[C.CDLL] = None
 
 
 class LightGlueConf(C.Structure):
-    _fields_ = [("depth_confidence", C.c_float), ("width_confidence", C.c_float),
-                ("filter_threshold", C.c_float), ("n_layers", C.c_int)]
+    _fields_ = [("depth_confidence", C.c_double), ("width_confidence", C.c_double),
+                ("filter_threshold", C.c_double), ("n_layers", C.c_int)]
 
 
 class SuperGlueConf(C.Structure):
-    _fields_ = [("sinkhorn_iterations", C.c_int), ("match_threshold", C.c_float), ("n_layers", C.c_int)]
+    _fields_ = [("sinkhorn_iterations", C.c_int), ("match_threshold", C.c_double), ("n_layers", C.c_int)]
 
 
 _P = C.c_void_p

@@ -154,7 +154,8 @@ __global__ __launch_bounds__(256) void conv1a_kernel(const uint8_t* __restrict__
     const float4 bv = *reinterpret_cast<const float4*>(bias + cg * 4);
     const uint8_t* im = img + (long)b * H * W;
     const long npix = (long)H * W;
-    for (long pix = (long)blockIdx.x * 64 + (threadIdx.x >> 4); pix < npix; pix += (long)gridDim.x * 64) {
+    for (long p0 = (long)blockIdx.x * 64; p0 < npix; p0 += (long)gridDim.x * 64)
+    for (long pix = p0 + (threadIdx.x >> 4); pix < min(p0 + 64, npix); pix += 16) {
         const int y = (int)(pix / W), x = (int)(pix - (long)y * W);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll

@@ -1,0 +1,448 @@
+// LightGlue glue kernels: positional encoding, LayerNorm+GELU, token confidence / matchability, early-stop and
+// point-pruning decisions (taken on the device: no host round trip per layer), order-preserving compaction,
+// and the assignment stage (double log-softmax, mutual nearest neighbour). HBM-bound: wave-per-row reductions,
+// coalesced column sweeps; integer atomics only (deterministic).
+#include "common.h"
+#include "lg_misc.h"
+
+namespace im {
+
+// ---------------------------------------------------------------------------------------------------------
+// normalize_keypoints + LearnableFourierPositionalEncoding (`lightglue/lightglue.py:23-35, 60-74`)
+__global__ __launch_bounds__(256) void posenc_kernel(const float* __restrict__ kpts, long kp_bstride, const int* __restrict__ n_ptr,
+                                                      const float* __restrict__ wr, float4 sizes, float* __restrict__ cs,
+                                                      float* __restrict__ sn, long enc_bstride) {
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int i = t >> 5, f = t & 31;
+    if (i >= n_ptr[b]) return;
+    const float sw = b == 0 ? sizes.x : sizes.z, sh = b == 0 ? sizes.y : sizes.w;
+    const float scale = fmaxf(sw, sh) / 2.f;
+    const float kx = (kpts[(long)b * kp_bstride + i * 2] - sw / 2.f) / scale;
+    const float ky = (kpts[(long)b * kp_bstride + i * 2 + 1] - sh / 2.f) / scale;
+    const float proj = kx * wr[f * 2] + ky * wr[f * 2 + 1];
+    cs[(long)b * enc_bstride + (long)i * 32 + f] = cosf(proj);
+    sn[(long)b * enc_bstride + (long)i * 32 + f] = sinf(proj);
+}
+
+hipError_t launch_posenc(const float* kpts, long kp_bstride, const int* n_ptr, int n_max, const float* wr,
+                         const float* h_size, float* cs, float* sn, long enc_bstride, hipStream_t s) {
+    float4 sizes = make_float4(h_size[0], h_size[1], h_size[2], h_size[3]);
+    hipLaunchKernelGGL(posenc_kernel, dim3((n_max * 32 + 255) / 256, 2), dim3(256), 0, s, kpts, kp_bstride, n_ptr, wr, sizes, cs, sn, enc_bstride);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// LayerNorm(512, eps 1e-5, affine) + exact-erf GELU in place (`lightglue/lightglue.py:144-149`). Wave per row.
+__global__ __launch_bounds__(256) void layernorm_gelu_kernel(float* __restrict__ h, long bstride, const int* __restrict__ n_ptr,
+                                                              const float* __restrict__ g, const float* __restrict__ be,
+                                                              const int* __restrict__ active) {
+    if (active && *active == 0) return;
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_ptr[b]) return;
+    float* p = h + (long)b * bstride + (long)row * 512;
+    float4 v0 = *reinterpret_cast<float4*>(p + lane * 4);
+    float4 v1 = *reinterpret_cast<float4*>(p + 256 + lane * 4);
+    const float mean = wave_sum(v0.x + v0.y + v0.z + v0.w + v1.x + v1.y + v1.z + v1.w) * (1.f / 512.f);
+    float d[8] = {v0.x - mean, v0.y - mean, v0.z - mean, v0.w - mean, v1.x - mean, v1.y - mean, v1.z - mean, v1.w - mean};
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ss += d[i] * d[i];
+    const float rstd = rsqrtf(wave_sum(ss) * (1.f / 512.f) + 1e-5f);
+    const float4 g0 = *reinterpret_cast<const float4*>(g + lane * 4), g1 = *reinterpret_cast<const float4*>(g + 256 + lane * 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(be + lane * 4), b1 = *reinterpret_cast<const float4*>(be + 256 + lane * 4);
+    const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+    const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    float o[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float y = d[i] * rstd * gg[i] + bb[i];
+        o[i] = 0.5f * y * (1.f + erff(y * 0.70710678118654752440f));
+    }
+    *reinterpret_cast<float4*>(p + lane * 4) = make_float4(o[0], o[1], o[2], o[3]);
+    *reinterpret_cast<float4*>(p + 256 + lane * 4) = make_float4(o[4], o[5], o[6], o[7]);
+}
+
+hipError_t launch_layernorm_gelu(float* h, long bstride, const int* n_ptr, int n_max, const float* g, const float* be,
+                                 const int* active, hipStream_t s) {
+    hipLaunchKernelGGL(layernorm_gelu_kernel, dim3((n_max + 3) / 4, 2), dim3(256), 0, s, h, bstride, n_ptr, g, be, active);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Row dot products with up to two 256-vectors (wave per row):
+//   out0 = act0(x . w0 + b0)   token confidence (`lightglue/lightglue.py:77-89`) or matchability logit (`:281-282`)
+//   out1 = sigmoid(x . w1 + b1) matchability (`:284-285`)
+// and an integer count of rows with out0 < thr (the early-stop statistic, `:571-579`).
+__global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ x, long bstride, const int* __restrict__ n_ptr,
+                                                      const float* __restrict__ w0, const float* __restrict__ b0, int act0,
+                                                      const float* __restrict__ w1, const float* __restrict__ b1,
+                                                      const int* __restrict__ sel, float* __restrict__ out0,
+                                                      float* __restrict__ out1, long out_bstride, float thr,
+                                                      int* __restrict__ counter, const int* __restrict__ active) {
+    if (active && *active == 0) return;
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_ptr[b]) return;
+    const int l = sel ? *sel : 0;
+    const float4 v = *reinterpret_cast<const float4*>(x + (long)b * bstride + (long)row * 256 + lane * 4);
+    if (w0) {
+        const float4 w = *reinterpret_cast<const float4*>(w0 + (long)l * 256 + lane * 4);
+        float d = wave_sum(v.x * w.x + v.y * w.y + v.z * w.z + v.w * w.w) + b0[l];
+        if (act0) d = sigmoidf(d);
+        if (lane == 0) {
+            out0[(long)b * out_bstride + row] = d;
+            if (counter && d < thr) atomicAdd(counter, 1);
+        }
+    }
+    if (w1) {
+        const float4 w = *reinterpret_cast<const float4*>(w1 + (long)l * 256 + lane * 4);
+        const float d = sigmoidf(wave_sum(v.x * w.x + v.y * w.y + v.z * w.z + v.w * w.w) + b1[l]);
+        if (lane == 0) out1[(long)b * out_bstride + row] = d;
+    }
+}
+
+hipError_t launch_rowdot(const float* x, long bstride, const int* n_ptr, int n_max, const float* w0, const float* b0, int act0,
+                         const float* w1, const float* b1, const int* sel, float* out0, float* out1, long out_bstride,
+                         float thr, int* counter, const int* active, hipStream_t s) {
+    hipLaunchKernelGGL(rowdot_kernel, dim3((n_max + 3) / 4, 2), dim3(256), 0, s, x, bstride, n_ptr, w0, b0, act0, w1, b1, sel,
+                       out0, out1, out_bstride, thr, counter, active);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Early stop (`check_if_stop`, `lightglue/lightglue.py:571-579`) and point pruning (`get_pruning_mask` +
+// `torch.where` compaction, `:495-510, 563-569`) decided on the device. One block handles both images in turn.
+// When the matcher is (or becomes) inactive it emits identity keep lists so that the static ping-pong of the
+// descriptor buffers stays valid.
+__global__ __launch_bounds__(1024) void stop_prune_kernel(LGState* __restrict__ st, int layer, int do_stop, int do_prune,
+                                                           float depth_conf, float keep_thr, float conf_thr,
+                                                           const float* __restrict__ conf, const float* __restrict__ msc,
+                                                           long vec_bstride, const int* __restrict__ ind_cur,
+                                                           int* __restrict__ ind_next, int* __restrict__ keep_idx,
+                                                           int* __restrict__ prune, long idx_bstride) {
+    __shared__ int part[1024];
+    __shared__ int sh_active;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        int act = st->active;
+        if (act && do_stop) {
+            const float ratio = 1.0f - (float)st->cnt[layer] / (float)(st->n_orig[0] + st->n_orig[1]);
+            if (ratio > depth_conf) {
+                act = 0;
+                st->active = 0;
+                st->stop_layer = layer;
+            }
+        }
+        sh_active = act;
+    }
+    __syncthreads();
+    const bool live = sh_active != 0 && do_prune;
+    for (int b = 0; b < 2; ++b) {
+        const int n = st->n[b];
+        const int per = (n + 1023) / 1024;
+        const int lo = min(tid * per, n), hi = min(lo + per, n);
+        const float* cf = conf + (long)b * vec_bstride;
+        const float* ms = msc + (long)b * vec_bstride;
+        int cnt = 0;
+        for (int e = lo; e < hi; ++e) {
+            bool keep = true;
+            if (live) {
+                keep = ms[e] > keep_thr;
+                if (do_stop) keep = keep || (cf[e] <= conf_thr);
+            }
+            cnt += keep;
+        }
+        part[tid] = cnt;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            int v = (tid >= off) ? part[tid - off] : 0;
+            __syncthreads();
+            part[tid] += v;
+            __syncthreads();
+        }
+        int pos = part[tid] - cnt;
+        const int total = part[1023];
+        const int* ic = ind_cur + (long)b * idx_bstride;
+        int* in = ind_next + (long)b * idx_bstride;
+        int* ki = keep_idx + (long)b * idx_bstride;
+        int* pr = prune + (long)b * idx_bstride;
+        for (int e = lo; e < hi; ++e) {
+            bool keep = true;
+            if (live) {
+                keep = ms[e] > keep_thr;
+                if (do_stop) keep = keep || (cf[e] <= conf_thr);
+            }
+            if (keep) {
+                const int orig = ic[e];
+                ki[pos] = e;
+                in[pos] = orig;
+                if (live) pr[orig] += 1;
+                ++pos;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) st->n[b] = total;
+        __syncthreads();
+    }
+}
+
+hipError_t launch_stop_prune(LGState* st, int layer, int do_stop, int do_prune, float depth_conf, float keep_thr,
+                             float conf_thr, const float* conf, const float* msc, long vec_bstride, const int* ind_cur,
+                             int* ind_next, int* keep_idx, int* prune, long idx_bstride, hipStream_t s) {
+    hipLaunchKernelGGL(stop_prune_kernel, dim3(1), dim3(1024), 0, s, st, layer, do_stop, do_prune, depth_conf, keep_thr, conf_thr,
+                       conf, msc, vec_bstride, ind_cur, ind_next, keep_idx, prune, idx_bstride);
+    return hipGetLastError();
+}
+
+// dst[p] = src[keep_idx[p]] for descriptor rows (256) and rotary tables (2 x 32); wave per row
+__global__ __launch_bounds__(256) void gather_rows_kernel(const LGState* __restrict__ st, const int* __restrict__ keep_idx,
+                                                           long idx_bstride, const float* __restrict__ x_src,
+                                                           float* __restrict__ x_dst, long x_bstride,
+                                                           const float* __restrict__ cs_src, float* __restrict__ cs_dst,
+                                                           const float* __restrict__ sn_src, float* __restrict__ sn_dst,
+                                                           long enc_bstride) {
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= st->n[b]) return;
+    const int e = keep_idx[(long)b * idx_bstride + p];
+    *reinterpret_cast<float4*>(x_dst + (long)b * x_bstride + (long)p * 256 + lane * 4) =
+        *reinterpret_cast<const float4*>(x_src + (long)b * x_bstride + (long)e * 256 + lane * 4);
+    if (lane < 8)
+        *reinterpret_cast<float4*>(cs_dst + (long)b * enc_bstride + (long)p * 32 + lane * 4) =
+            *reinterpret_cast<const float4*>(cs_src + (long)b * enc_bstride + (long)e * 32 + lane * 4);
+    else if (lane < 16)
+        *reinterpret_cast<float4*>(sn_dst + (long)b * enc_bstride + (long)p * 32 + (lane - 8) * 4) =
+            *reinterpret_cast<const float4*>(sn_src + (long)b * enc_bstride + (long)e * 32 + (lane - 8) * 4);
+}
+
+hipError_t launch_gather_rows(const LGState* st, int n_max, const int* keep_idx, long idx_bstride, const float* x_src,
+                              float* x_dst, long x_bstride, const float* cs_src, float* cs_dst, const float* sn_src,
+                              float* sn_dst, long enc_bstride, hipStream_t s) {
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((n_max + 3) / 4, 2), dim3(256), 0, s, st, keep_idx, idx_bstride, x_src, x_dst,
+                       x_bstride, cs_src, cs_dst, sn_src, sn_dst, enc_bstride);
+    return hipGetLastError();
+}
+
+__global__ void lg_init_kernel(LGState* st, const int* __restrict__ n_in, int* __restrict__ ind, int* __restrict__ prune,
+                               long idx_bstride, int n_max, int* __restrict__ out_m, float* __restrict__ out_s, long out_bstride) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const int n = min(n_in[b], n_max);
+        st->n[b] = n;
+        st->n_orig[b] = n;
+        if (b == 0) {
+            st->active = 1;
+            st->stop_layer = -1;
+            for (int l = 0; l < 16; ++l) st->cnt[l] = 0;
+        }
+    }
+    if (i < n_max) {
+        ind[(long)b * idx_bstride + i] = i;
+        prune[(long)b * idx_bstride + i] = 1;
+        out_m[(long)b * out_bstride + i] = -1;
+        out_s[(long)b * out_bstride + i] = 0.f;
+    }
+}
+
+hipError_t launch_lg_init(LGState* st, const int* n_in, int* ind, int* prune, long idx_bstride, int n_max, int* out_m,
+                          float* out_s, long out_bstride, hipStream_t s) {
+    hipLaunchKernelGGL(lg_init_kernel, dim3((n_max + 255) / 256, 2), dim3(256), 0, s, st, n_in, ind, prune, idx_bstride, n_max, out_m, out_s, out_bstride);
+    return hipGetLastError();
+}
+
+// sel = last executed layer: stop_layer if the matcher stopped early, else n_layers - 1 (`lightglue.py:512-513`)
+__global__ void lg_select_layer_kernel(LGState* st, int n_layers, int* sel, int* info) {
+    const int last = st->stop_layer >= 0 ? st->stop_layer : n_layers - 1;
+    *sel = last;
+    info[0] = last + 1;
+    info[1] = st->n[0];
+    info[2] = st->n[1];
+    info[3] = 0;
+    st->active = 1;  // the assignment stage always runs
+}
+
+hipError_t launch_lg_select_layer(LGState* st, int n_layers, int* sel, int* info, hipStream_t s) {
+    hipLaunchKernelGGL(lg_select_layer_kernel, dim3(1), dim3(1), 0, s, st, n_layers, sel, info);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Assignment (`sigmoid_log_double_softmax` + `filter_matches`, `lightglue/lightglue.py:253-306`) on a
+// materialised similarity matrix sim [m][ld].
+//   score(i, j) = ((x - rmax_i) - rlog_i) + ((x - cmax_j) - clog_j) + (lz0_i + lz1_j)
+// (same association as the reference: log_softmax rows + log_softmax columns, then + certainties).
+
+// wave per row: max, then sum exp(x - max) (torch's log_softmax order), plus lz = logsigmoid(z)
+__global__ __launch_bounds__(256) void row_lse_kernel(const float* __restrict__ sim, int ld, const int* __restrict__ m_ptr,
+                                                       const int* __restrict__ n_ptr, float* __restrict__ rmax,
+                                                       float* __restrict__ rlog) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int m = *m_ptr, n = *n_ptr;
+    if (i >= m) return;
+    const float* p = sim + (long)i * ld;
+    float mx = -INFINITY;
+    for (int j = lane; j < n; j += 64) mx = fmaxf(mx, p[j]);
+    mx = wave_max(mx);
+    float s = 0.f;
+    for (int j = lane; j < n; j += 64) s += expf(p[j] - mx);
+    s = wave_sum(s);
+    if (lane == 0) { rmax[i] = mx; rlog[i] = logf(s); }
+}
+
+static constexpr int COL_STRIP = 128;
+
+// thread per column, strip of COL_STRIP rows: online (max, sum)
+__global__ __launch_bounds__(256) void col_lse_partial_kernel(const float* __restrict__ sim, int ld, const int* __restrict__ m_ptr,
+                                                               const int* __restrict__ n_ptr, float2* __restrict__ part, int kmax) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int m = *m_ptr, n = *n_ptr;
+    const int i0 = blockIdx.y * COL_STRIP;
+    if (j >= n || i0 >= m) return;
+    const int i1 = min(i0 + COL_STRIP, m);
+    float mx = -INFINITY;
+    for (int i = i0; i < i1; ++i) mx = fmaxf(mx, sim[(long)i * ld + j]);
+    float s = 0.f;
+    for (int i = i0; i < i1; ++i) s += expf(sim[(long)i * ld + j] - mx);
+    part[(long)blockIdx.y * kmax + j] = make_float2(mx, s);
+}
+
+__global__ __launch_bounds__(256) void col_lse_combine_kernel(const float2* __restrict__ part, int kmax, const int* __restrict__ m_ptr,
+                                                               const int* __restrict__ n_ptr, float* __restrict__ cmax,
+                                                               float* __restrict__ clog) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int m = *m_ptr, n = *n_ptr;
+    if (j >= n) return;
+    const int ns = (m + COL_STRIP - 1) / COL_STRIP;
+    float mx = -INFINITY;
+    for (int s = 0; s < ns; ++s) mx = fmaxf(mx, part[(long)s * kmax + j].x);
+    float sum = 0.f;
+    for (int s = 0; s < ns; ++s) {
+        const float2 p = part[(long)s * kmax + j];
+        sum += p.y * expf(p.x - mx);
+    }
+    cmax[j] = mx;
+    clog[j] = logf(sum);
+}
+
+__global__ __launch_bounds__(256) void logsig_kernel(const float* __restrict__ z, long bstride, const LGState* __restrict__ st,
+                                                      float* __restrict__ lz) {
+    const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i < st->n[b]) lz[(long)b * bstride + i] = log_sigmoid(z[(long)b * bstride + i]);
+}
+
+__device__ __forceinline__ float assign_score(float x, float rm, float rl, float cm, float cl, float l0, float l1) {
+    return (((x - rm) - rl) + ((x - cm) - cl)) + (l0 + l1);
+}
+
+// wave per row: argmax over columns, first index among ties (torch.max semantics)
+__global__ __launch_bounds__(256) void row_argmax_kernel(const float* __restrict__ sim, int ld, const int* __restrict__ m_ptr,
+                                                          const int* __restrict__ n_ptr, const float* __restrict__ rmax,
+                                                          const float* __restrict__ rlog, const float* __restrict__ cmax,
+                                                          const float* __restrict__ clog, const float* __restrict__ lz0,
+                                                          const float* __restrict__ lz1, int* __restrict__ ridx,
+                                                          float* __restrict__ rval) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int m = *m_ptr, n = *n_ptr;
+    if (i >= m) return;
+    const float* p = sim + (long)i * ld;
+    const float rm = rmax[i], rl = rlog[i], l0 = lz0[i];
+    float best = -INFINITY;
+    int bj = 0x7fffffff;
+    for (int j = lane; j < n; j += 64) {
+        const float v = assign_score(p[j], rm, rl, cmax[j], clog[j], l0, lz1[j]);
+        if (v > best || (bj == 0x7fffffff)) { best = v; bj = j; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(best, off);
+        const int oj = __shfl_xor(bj, off);
+        if (ov > best || (ov == best && oj < bj)) { best = ov; bj = oj; }
+    }
+    if (lane == 0) { ridx[i] = bj; rval[i] = best; }
+}
+
+// thread per column, strip of rows: running best (strict > keeps the first row), merged with a 64-bit atomicMax
+// on (ordered score bits, ~row): max is order independent => deterministic
+__global__ __launch_bounds__(256) void col_argmax_kernel(const float* __restrict__ sim, int ld, const int* __restrict__ m_ptr,
+                                                          const int* __restrict__ n_ptr, const float* __restrict__ rmax,
+                                                          const float* __restrict__ rlog, const float* __restrict__ cmax,
+                                                          const float* __restrict__ clog, const float* __restrict__ lz0,
+                                                          const float* __restrict__ lz1, unsigned long long* __restrict__ cbest) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int m = *m_ptr, n = *n_ptr;
+    const int i0 = blockIdx.y * COL_STRIP;
+    if (j >= n || i0 >= m) return;
+    const int i1 = min(i0 + COL_STRIP, m);
+    const float cm = cmax[j], cl = clog[j], l1 = lz1[j];
+    float best = -INFINITY;
+    int bi = -1;
+    for (int i = i0; i < i1; ++i) {
+        const float v = assign_score(sim[(long)i * ld + j], rmax[i], rlog[i], cm, cl, lz0[i], l1);
+        if (v > best || bi < 0) { best = v; bi = i; }
+    }
+    const unsigned long long key = ((unsigned long long)f2ord(best) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)bi);
+    atomicMax(cbest + j, key);
+}
+
+// mutual check + threshold (`filter_matches`), then scatter to the original index space (`lightglue.py:528-539`)
+__global__ __launch_bounds__(256) void filter_scatter_kernel(const int* __restrict__ m_ptr, const int* __restrict__ n_ptr,
+                                                              const int* __restrict__ ridx, const float* __restrict__ rval,
+                                                              const unsigned long long* __restrict__ cbest, float th,
+                                                              const int* __restrict__ ind0, const int* __restrict__ ind1,
+                                                              int* __restrict__ out_m0, int* __restrict__ out_m1,
+                                                              float* __restrict__ out_s0, float* __restrict__ out_s1) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int m = *m_ptr, n = *n_ptr;
+    auto col_of = [&](int j) { return (int)(0xFFFFFFFFu - (unsigned)(cbest[j] & 0xFFFFFFFFull)); };
+    if (blockIdx.y == 0) {
+        if (t >= m) return;
+        const int j = ridx[t];
+        const bool mutual = col_of(j) == t;
+        const float ms = mutual ? expf(rval[t]) : 0.f;
+        const bool valid = mutual && ms > th;
+        const int o = ind0 ? ind0[t] : t;
+        out_m0[o] = valid ? (ind1 ? ind1[j] : j) : -1;
+        out_s0[o] = ms;
+    } else {
+        if (t >= n) return;
+        const int i = col_of(t);
+        const bool mutual1 = ridx[i] == t;
+        const bool mutual0 = mutual1;  // col_of(ridx[i]) == i  <=>  ridx[i] == t when i = col_of(t)
+        const float ms0 = mutual0 ? expf(rval[i]) : 0.f;
+        const float ms1 = mutual1 ? ms0 : 0.f;
+        const bool valid1 = mutual1 && (mutual0 && ms0 > th);
+        const int o = ind1 ? ind1[t] : t;
+        out_m1[o] = valid1 ? (ind0 ? ind0[i] : i) : -1;
+        out_s1[o] = ms1;
+    }
+}
+
+hipError_t launch_assign(const AssignArgs& a, hipStream_t s) {
+    const int kr = a.m_max, kc = a.n_max;
+    hipError_t e = hipMemsetAsync(a.cbest, 0, sizeof(unsigned long long) * kc, s);
+    if (e != hipSuccess) return e;
+    const int nstrips = (kr + COL_STRIP - 1) / COL_STRIP;
+    hipLaunchKernelGGL(row_lse_kernel, dim3((kr + 3) / 4), dim3(256), 0, s, a.sim, a.ld, a.m_ptr, a.n_ptr, a.rmax, a.rlog);
+    hipLaunchKernelGGL(col_lse_partial_kernel, dim3((kc + 255) / 256, nstrips), dim3(256), 0, s, a.sim, a.ld, a.m_ptr, a.n_ptr, a.part, kc);
+    hipLaunchKernelGGL(col_lse_combine_kernel, dim3((kc + 255) / 256), dim3(256), 0, s, a.part, kc, a.m_ptr, a.n_ptr, a.cmax, a.clog);
+    hipLaunchKernelGGL(row_argmax_kernel, dim3((kr + 3) / 4), dim3(256), 0, s, a.sim, a.ld, a.m_ptr, a.n_ptr, a.rmax, a.rlog, a.cmax,
+                       a.clog, a.lz0, a.lz1, a.ridx, a.rval);
+    hipLaunchKernelGGL(col_argmax_kernel, dim3((kc + 255) / 256, nstrips), dim3(256), 0, s, a.sim, a.ld, a.m_ptr, a.n_ptr, a.rmax, a.rlog,
+                       a.cmax, a.clog, a.lz0, a.lz1, a.cbest);
+    const int kk = kr > kc ? kr : kc;
+    hipLaunchKernelGGL(filter_scatter_kernel, dim3((kk + 255) / 256, 2), dim3(256), 0, s, a.m_ptr, a.n_ptr, a.ridx, a.rval, a.cbest,
+                       a.threshold, a.ind0, a.ind1, a.out_m0, a.out_m1, a.out_s0, a.out_s1);
+    return hipGetLastError();
+}
+
+hipError_t launch_logsig(const float* z, long bstride, const LGState* st, int n_max, float* lz, hipStream_t s) {
+    hipLaunchKernelGGL(logsig_kernel, dim3((n_max + 255) / 256, 2), dim3(256), 0, s, z, bstride, st, lz);
+    return hipGetLastError();
+}
+
+}  // namespace im

@@ -1,0 +1,477 @@
+// Model-level orchestration behind the C ABI: workspace, weight packing, SuperPoint and LightGlue forward
+// passes as a fixed sequence of kernel launches on one stream (no host synchronisation inside a forward:
+// keypoint counts, early-stop and pruning state live in device memory).
+#include <cmath>
+#include <cstring>
+
+#include "ctx.h"
+#include "lg_misc.h"
+#include "sp_post.h"
+#include "workspace.h"
+
+using namespace im;
+
+static const char* SP_CONV3[10] = {"conv1b", "conv2a", "conv2b", "conv3a", "conv3b", "conv4a", "conv4b", "convPa", "convDa", nullptr};
+static const int SP_CIN[9] = {64, 64, 64, 64, 128, 128, 128, 128, 128};
+static const int SP_COUT[9] = {64, 64, 64, 128, 128, 128, 128, 256, 256};
+
+static const std::vector<float>* find_w(im_ctx* ctx, const std::string& model, const std::string& key, size_t numel) {
+    auto it = ctx->host_w.find(model + "/" + key);
+    if (it == ctx->host_w.end()) {
+        ctx->fail(-20, "weights: missing tensor %s of model %s", key.c_str(), model.c_str());
+        return nullptr;
+    }
+    if (it->second.size() != numel) {
+        ctx->fail(-21, "weights: tensor %s has %zu elements, expected %zu", key.c_str(), it->second.size(), numel);
+        return nullptr;
+    }
+    return &it->second;
+}
+
+#define GETW(var, model, key, numel)                           \
+    const std::vector<float>* var = find_w(ctx, model, key, numel); \
+    if (!var) return -20
+
+static int finalize_superpoint(im_ctx* ctx) {
+    SuperPointW& w = ctx->sp;
+    {
+        GETW(cw, "superpoint", "conv1a.weight", 64 * 9);
+        GETW(cb, "superpoint", "conv1a.bias", 64);
+        std::vector<float> p(9 * 64);
+        for (int co = 0; co < 64; ++co)
+            for (int t = 0; t < 9; ++t) p[t * 64 + co] = (*cw)[co * 9 + t];
+        w.c1a_w = ctx->upload(p);
+        w.c1a_b = ctx->upload(*cb);
+    }
+    for (int i = 0; SP_CONV3[i]; ++i) {
+        const std::string nm = SP_CONV3[i];
+        GETW(cw, "superpoint", nm + ".weight", (size_t)SP_COUT[i] * SP_CIN[i] * 9);
+        GETW(cb, "superpoint", nm + ".bias", (size_t)SP_COUT[i]);
+        w.cw[i] = ctx->upload(pack_conv3x3(cw->data(), SP_COUT[i], SP_CIN[i]));
+        w.cb[i] = ctx->upload(*cb);
+        if (!w.cw[i] || !w.cb[i]) return ctx->fail(-22, "weights: upload failed");
+    }
+    GETW(pbw, "superpoint", "convPb.weight", 65 * 256);
+    GETW(pbb, "superpoint", "convPb.bias", 65);
+    GETW(dbw, "superpoint", "convDb.weight", 256 * 256);
+    GETW(dbb, "superpoint", "convDb.bias", 256);
+    w.pb_w = ctx->upload(*pbw); w.pb_b = ctx->upload(*pbb);
+    w.db_w = ctx->upload(*dbw); w.db_b = ctx->upload(*dbb);
+    if (!w.pb_w || !w.pb_b || !w.db_w || !w.db_b || !w.c1a_w || !w.c1a_b) return ctx->fail(-22, "weights: upload failed");
+    w.ready = true;
+    return 0;
+}
+
+static int finalize_lightglue(im_ctx* ctx) {
+    LightGlueW& w = ctx->lg;
+    const int L = 9;
+    auto cat = [&](const char* fmt, size_t numel, std::vector<float>& dst, int count) -> int {
+        dst.clear();
+        for (int i = 0; i < count; ++i) {
+            char key[160];
+            snprintf(key, sizeof(key), fmt, i);
+            const std::vector<float>* t = find_w(ctx, "lightglue", key, numel);
+            if (!t) return -20;
+            dst.insert(dst.end(), t->begin(), t->end());
+        }
+        return 0;
+    };
+    std::vector<float> buf;
+#define CAT_UP(dstptr, fmt, numel, count)        \
+    if (cat(fmt, numel, buf, count)) return -20; \
+    dstptr = ctx->upload(buf);                   \
+    if (!dstptr) return ctx->fail(-22, "weights: upload failed")
+
+    {
+        GETW(wr, "lightglue", "posenc.Wr.weight", 64);
+        w.wr = ctx->upload(*wr);
+    }
+    // Wqkv rows: original index head*192 + d*3 + which  ->  which*256 + head*64 + d  (`lightglue.py:155`)
+    {
+        std::vector<float> qw, qb, pw((size_t)L * 768 * 256), pb((size_t)L * 768);
+        if (cat("transformers.%d.self_attn.Wqkv.weight", 768 * 256, qw, L)) return -20;
+        if (cat("transformers.%d.self_attn.Wqkv.bias", 768, qb, L)) return -20;
+        for (int l = 0; l < L; ++l)
+            for (int h = 0; h < 4; ++h)
+                for (int d = 0; d < 64; ++d)
+                    for (int which = 0; which < 3; ++which) {
+                        const int src = h * 192 + d * 3 + which, dst = which * 256 + h * 64 + d;
+                        memcpy(&pw[((size_t)l * 768 + dst) * 256], &qw[((size_t)l * 768 + src) * 256], 256 * sizeof(float));
+                        pb[(size_t)l * 768 + dst] = qb[(size_t)l * 768 + src];
+                    }
+        w.qkv_w = ctx->upload(pw);
+        w.qkv_b = ctx->upload(pb);
+    }
+    CAT_UP(w.out_w, "transformers.%d.self_attn.out_proj.weight", 256 * 256, L);
+    CAT_UP(w.out_b, "transformers.%d.self_attn.out_proj.bias", 256, L);
+    CAT_UP(w.sf0_w, "transformers.%d.self_attn.ffn.0.weight", 512 * 512, L);
+    CAT_UP(w.sf0_b, "transformers.%d.self_attn.ffn.0.bias", 512, L);
+    CAT_UP(w.sln_g, "transformers.%d.self_attn.ffn.1.weight", 512, L);
+    CAT_UP(w.sln_b, "transformers.%d.self_attn.ffn.1.bias", 512, L);
+    CAT_UP(w.sf3_w, "transformers.%d.self_attn.ffn.3.weight", 256 * 512, L);
+    CAT_UP(w.sf3_b, "transformers.%d.self_attn.ffn.3.bias", 256, L);
+    CAT_UP(w.cqk_w, "transformers.%d.cross_attn.to_qk.weight", 256 * 256, L);
+    CAT_UP(w.cqk_b, "transformers.%d.cross_attn.to_qk.bias", 256, L);
+    CAT_UP(w.cv_w, "transformers.%d.cross_attn.to_v.weight", 256 * 256, L);
+    CAT_UP(w.cv_b, "transformers.%d.cross_attn.to_v.bias", 256, L);
+    CAT_UP(w.co_w, "transformers.%d.cross_attn.to_out.weight", 256 * 256, L);
+    CAT_UP(w.co_b, "transformers.%d.cross_attn.to_out.bias", 256, L);
+    CAT_UP(w.cf0_w, "transformers.%d.cross_attn.ffn.0.weight", 512 * 512, L);
+    CAT_UP(w.cf0_b, "transformers.%d.cross_attn.ffn.0.bias", 512, L);
+    CAT_UP(w.cln_g, "transformers.%d.cross_attn.ffn.1.weight", 512, L);
+    CAT_UP(w.cln_b, "transformers.%d.cross_attn.ffn.1.bias", 512, L);
+    CAT_UP(w.cf3_w, "transformers.%d.cross_attn.ffn.3.weight", 256 * 512, L);
+    CAT_UP(w.cf3_b, "transformers.%d.cross_attn.ffn.3.bias", 256, L);
+    CAT_UP(w.fp_w, "log_assignment.%d.final_proj.weight", 256 * 256, L);
+    CAT_UP(w.fp_b, "log_assignment.%d.final_proj.bias", 256, L);
+    CAT_UP(w.ma_w, "log_assignment.%d.matchability.weight", 256, L);
+    CAT_UP(w.ma_b, "log_assignment.%d.matchability.bias", 1, L);
+    CAT_UP(w.tc_w, "token_confidence.%d.token.0.weight", 256, L - 1);
+    CAT_UP(w.tc_b, "token_confidence.%d.token.0.bias", 1, L - 1);
+#undef CAT_UP
+    {
+        GETW(thr, "lightglue", "confidence_thresholds", (size_t)L);
+        for (int i = 0; i < L; ++i) w.thr[i] = (*thr)[i];
+    }
+    if (!w.wr || !w.qkv_w || !w.qkv_b) return ctx->fail(-22, "weights: upload failed");
+    w.ready = true;
+    return 0;
+}
+
+int finalize_superglue(im_ctx* ctx);  // superglue.hip
+
+extern "C" {
+
+int im_set_tensor(im_ctx* ctx, const char* model, const char* key, const float* h_data, size_t numel) {
+    IM_CHECK_CTX(ctx);
+    if (!model || !key || !h_data) return ctx->fail(-1, "im_set_tensor: null argument");
+    ctx->host_w[std::string(model) + "/" + key].assign(h_data, h_data + numel);
+    return 0;
+}
+
+int im_finalize_weights(im_ctx* ctx, const char* model) {
+    IM_CHECK_CTX(ctx);
+    const std::string m = model ? model : "";
+    int rc;
+    if (m == "superpoint") rc = finalize_superpoint(ctx);
+    else if (m == "lightglue") rc = finalize_lightglue(ctx);
+    else if (m == "superglue") rc = finalize_superglue(ctx);
+    else return ctx->fail(-23, "im_finalize_weights: unknown model '%s'", m.c_str());
+    if (rc) return rc;
+    IM_HIP(ctx, hipDeviceSynchronize());
+    return 0;
+}
+
+int im_ctx_reserve(im_ctx* ctx, int max_h, int max_w, int max_images, int max_kpts) {
+    IM_CHECK_CTX(ctx);
+    if (max_h < 8 || max_w < 8 || max_images < 1 || max_kpts < 1) return ctx->fail(-30, "im_ctx_reserve: bad sizes");
+    if (ctx->ws && max_h <= ctx->max_h && max_w <= ctx->max_w && max_images <= ctx->max_images && max_kpts == ctx->max_kpts) return 0;
+    IM_HIP(ctx, hipDeviceSynchronize());
+    if (ctx->ws) {
+        for (void* p : ctx->ws->allocs) hipFree(p);
+        delete ctx->ws;
+        ctx->ws = nullptr;
+    }
+    Workspace* ws = new Workspace();
+    const long B = max_images;
+    const long H8 = (max_h / 8) * 8, W8 = (max_w / 8) * 8, cells = (H8 / 8) * (W8 / 8), K = max_kpts;
+    bool ok = true;
+    auto A = [&](auto*& p, size_t n) {
+        using T = std::remove_reference_t<decltype(*p)>;
+        void* q = nullptr;
+        if (hipMalloc(&q, n * sizeof(T) + 256) != hipSuccess) { ok = false; p = nullptr; return; }
+        ws->allocs.push_back(q);
+        p = reinterpret_cast<T*>(q);
+    };
+    A(ws->act0, (size_t)B * max_h * max_w * 64);
+    A(ws->act1, (size_t)B * (max_h / 2) * (max_w / 2) * 64);
+    A(ws->logits, (size_t)B * cells * 65);
+    A(ws->dense, (size_t)B * cells * 256);
+    A(ws->smap, (size_t)B * H8 * W8);
+    A(ws->nms, (size_t)B * H8 * W8);
+    A(ws->rest, (size_t)B * H8 * W8);
+    A(ws->mask, (size_t)B * H8 * W8);
+    A(ws->supp, (size_t)B * H8 * W8);
+    A(ws->counts, (size_t)B * ((H8 * W8 + 1023) / 1024 + 1));
+    A(ws->n_cand, (size_t)B);
+    A(ws->keys, (size_t)B * H8 * W8);
+    for (int i = 0; i < 2; ++i) {
+        A(ws->x[i], (size_t)2 * K * 256);
+        A(ws->cs[i], (size_t)2 * K * 32);
+        A(ws->sn[i], (size_t)2 * K * 32);
+        A(ws->ind[i], (size_t)2 * K);
+    }
+    A(ws->q, (size_t)2 * K * 256); A(ws->k, (size_t)2 * K * 256); A(ws->v, (size_t)2 * K * 256);
+    A(ws->att, (size_t)2 * K * 256); A(ws->msg, (size_t)2 * K * 256); A(ws->h, (size_t)2 * K * 512);
+    A(ws->conf, (size_t)2 * K); A(ws->msc, (size_t)2 * K); A(ws->keep_idx, (size_t)2 * K); A(ws->prune, (size_t)2 * K);
+    A(ws->md, (size_t)2 * K * 256); A(ws->z, (size_t)2 * K); A(ws->lz, (size_t)2 * K);
+    A(ws->sim, (size_t)(K + 1) * (K + 1));
+    A(ws->sim2, (size_t)1);
+    A(ws->rmax, (size_t)K + 1); A(ws->rlog, (size_t)K + 1); A(ws->cmax, (size_t)K + 1); A(ws->clog, (size_t)K + 1);
+    A(ws->part, (size_t)((K + 127) / 128 + 1) * (K + 1));
+    A(ws->ridx, (size_t)K + 1); A(ws->rval, (size_t)K + 1); A(ws->cbest, (size_t)K + 1);
+    A(ws->st, (size_t)1); A(ws->sel, (size_t)4);
+    A(ws->uv, (size_t)4 * (K + 1));
+    if (!ok) {
+        for (void* p : ws->allocs) hipFree(p);
+        delete ws;
+        return ctx->fail(-31, "im_ctx_reserve: out of device memory (%d x %d, %d images, %d keypoints)", max_h, max_w, max_images, max_kpts);
+    }
+    ctx->ws = ws;
+    ctx->max_h = max_h; ctx->max_w = max_w; ctx->max_images = max_images; ctx->max_kpts = max_kpts;
+    IM_HIP(ctx, hipMemset(ws->st, 0, sizeof(LGState)));
+    IM_HIP(ctx, hipMemset(ws->sel, 0, 4 * sizeof(int)));
+    IM_HIP(ctx, hipDeviceSynchronize());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ SuperPoint
+int im_superpoint_forward(im_ctx* ctx, const uint8_t* d_gray, int n_images, int h, int w, int nms_radius, float threshold,
+                          int border, int max_kpts, int flavour, float* d_kpts, float* d_scores, float* d_desc, int32_t* d_n,
+                          void* stream) {
+    IM_CHECK_CTX(ctx);
+    (void)flavour;  // both flavours select the same candidate set (border test commutes with the threshold for thr >= 0)
+    if (!ctx->sp.ready) return ctx->fail(-40, "im_superpoint_forward: weights not finalized");
+    Workspace* ws = ctx->ws;
+    if (!ws || h > ctx->max_h || w > ctx->max_w || n_images > ctx->max_images)
+        return ctx->fail(-41, "im_superpoint_forward: %d x %d x %d exceeds the reserved workspace", n_images, h, w);
+    if (h < 8 || w < 8) return ctx->fail(-42, "im_superpoint_forward: image smaller than one cell");
+    if (threshold < 0.f) return ctx->fail(-43, "im_superpoint_forward: negative detection threshold unsupported");
+    hipStream_t s = (hipStream_t)stream;
+    const SuperPointW& W = ctx->sp;
+    const int B = n_images, K = ctx->max_kpts;
+    IM_HIP(ctx, launch_conv1a(d_gray, W.c1a_w, W.c1a_b, ws->act0, B, h, w, s));
+    float* src = ws->act0;
+    float* dst = ws->act1;
+    int ch = h, cw_ = w;
+    static const int pool_after[7] = {1, 0, 1, 0, 1, 0, 0};  // conv1b, 2a, 2b, 3a, 3b, 4a, 4b
+    for (int i = 0; i < 7; ++i) {
+        ConvArgs a;
+        a.in = src; a.w = W.cw[i]; a.bias = W.cb[i]; a.out = dst; a.B = B; a.H = ch; a.W = cw_;
+        a.Cin = SP_CIN[i]; a.Cout = SP_COUT[i]; a.pool = pool_after[i]; a.relu = 1;
+        IM_HIP(ctx, launch_conv3x3(a, s));
+        if (pool_after[i]) { ch /= 2; cw_ /= 2; }
+        std::swap(src, dst);
+    }
+    // src = feat [B][hc][wc][128] (in act1), dst = act0 free
+    const int hc = ch, wc = cw_;
+    const long cells = (long)B * hc * wc;
+    float* feat = src;
+    float* tmp = dst;
+    {
+        ConvArgs a;
+        a.in = feat; a.w = W.cw[7]; a.bias = W.cb[7]; a.out = tmp; a.B = B; a.H = hc; a.W = wc; a.Cin = 128; a.Cout = 256;
+        IM_HIP(ctx, launch_conv3x3(a, s));
+        GemmArgs g;
+        g.A = tmp; g.lda = 256; g.W = W.pb_w; g.ldw = 256; g.bias = W.pb_b; g.N = 65; g.K = 256; g.m_max = (int)cells;
+        g.C = ws->logits; g.ldc = 65; g.epi = EPI_BIAS;
+        IM_HIP(ctx, launch_gemm(g, s));
+        IM_HIP(ctx, launch_det_softmax(ws->logits, 65, ws->smap, B, hc, wc, s));
+    }
+    const int H8 = hc * 8, W8 = wc * 8;
+    IM_HIP(ctx, launch_nms(ws->smap, ws->nms, ws->mask, ws->supp, ws->rest, B, H8, W8, nms_radius, s));
+    IM_HIP(ctx, launch_select_topk(ws->nms, B, H8, W8, border, threshold, max_kpts, K, ws->counts, ws->n_cand, ws->keys,
+                                   d_kpts, d_scores, d_n, s));
+    {
+        ConvArgs a;
+        a.in = feat; a.w = W.cw[8]; a.bias = W.cb[8]; a.out = tmp; a.B = B; a.H = hc; a.W = wc; a.Cin = 128; a.Cout = 256;
+        IM_HIP(ctx, launch_conv3x3(a, s));
+        GemmArgs g;
+        g.A = tmp; g.lda = 256; g.W = W.db_w; g.ldw = 256; g.bias = W.db_b; g.N = 256; g.K = 256; g.m_max = (int)cells;
+        g.C = ws->dense; g.ldc = 256; g.epi = EPI_BIAS;
+        IM_HIP(ctx, launch_gemm(g, s));
+        IM_HIP(ctx, launch_sample_desc(ws->dense, B, hc, wc, d_kpts, d_n, K, d_desc, s));
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ LightGlue
+static int lg_block(im_ctx* ctx, hipStream_t s, int layer, bool cross, float* x, const float* cs, const float* sn) {
+    Workspace* ws = ctx->ws;
+    const LightGlueW& W = ctx->lg;
+    const int K = ctx->max_kpts;
+    const long xb = (long)K * 256;
+    const int* n_ptr = ws->st->n;
+    const int* active = &ws->st->active;
+    GemmArgs base;
+    base.m_max = K; base.m_ptr = n_ptr; base.active = active; base.batch = 2;
+    AttnArgs at;
+    at.q = ws->q; at.k = cross ? ws->q : ws->k; at.v = ws->v; at.hstride = (long)K * 64; at.bstride = (long)K * 256;
+    at.out = ws->att; at.out_bstride = xb; at.ldo = 256; at.n_ptr = n_ptr; at.n_max = K; at.batch = 2; at.heads = 4;
+    at.cross = cross ? 1 : 0; at.active = active;
+    if (!cross) {
+        GemmArgs g = base;
+        g.A = x; g.a_bstride = xb; g.lda = 256; g.W = W.qkv_w + (long)layer * 768 * 256; g.ldw = 256;
+        g.bias = W.qkv_b + (long)layer * 768; g.N = 768; g.K = 256; g.epi = EPI_QKV_ROPE;
+        g.q = ws->q; g.k = ws->k; g.v = ws->v; g.head_bstride = (long)K * 256; g.head_stride = (long)K * 64;
+        g.cs = cs; g.sn = sn; g.enc_bstride = (long)K * 32;
+        IM_HIP(ctx, launch_gemm(g, s));
+        at.scale = 0.125f;  // SDPA default 1/sqrt(64) (`lightglue.py:120-123`)
+    } else {
+        GemmArgs g = base;
+        g.A = x; g.a_bstride = xb; g.lda = 256; g.W = W.cqk_w + (long)layer * 65536; g.ldw = 256;
+        g.bias = W.cqk_b + (long)layer * 256; g.N = 256; g.K = 256; g.epi = EPI_HEADS;
+        g.q = ws->q; g.head_bstride = (long)K * 256; g.head_stride = (long)K * 64;
+        g.alpha = (float)0.35355339059327373;  // scale**0.5 = 64**-0.25 (`lightglue.py:201`)
+        IM_HIP(ctx, launch_gemm(g, s));
+        g.W = W.cv_w + (long)layer * 65536; g.bias = W.cv_b + (long)layer * 256; g.q = ws->v; g.alpha = 1.f;
+        IM_HIP(ctx, launch_gemm(g, s));
+        at.scale = 1.f;
+    }
+    IM_HIP(ctx, launch_flash_attn(at, s));
+    {   // out_proj / to_out
+        GemmArgs g = base;
+        g.A = ws->att; g.a_bstride = xb; g.lda = 256;
+        g.W = (cross ? W.co_w : W.out_w) + (long)layer * 65536; g.ldw = 256;
+        g.bias = (cross ? W.co_b : W.out_b) + (long)layer * 256; g.N = 256; g.K = 256;
+        g.C = ws->msg; g.c_bstride = xb; g.ldc = 256; g.epi = EPI_BIAS;
+        IM_HIP(ctx, launch_gemm(g, s));
+    }
+    {   // ffn.0 on cat([x, msg])
+        GemmArgs g = base;
+        g.A = x; g.a_bstride = xb; g.lda = 256; g.A1 = ws->msg; g.a1_bstride = xb; g.lda1 = 256; g.ksplit = 256;
+        g.W = (cross ? W.cf0_w : W.sf0_w) + (long)layer * 512 * 512; g.ldw = 512;
+        g.bias = (cross ? W.cf0_b : W.sf0_b) + (long)layer * 512; g.N = 512; g.K = 512;
+        g.C = ws->h; g.c_bstride = (long)K * 512; g.ldc = 512; g.epi = EPI_BIAS;
+        IM_HIP(ctx, launch_gemm(g, s));
+    }
+    IM_HIP(ctx, launch_layernorm_gelu(ws->h, (long)K * 512, n_ptr, K, (cross ? W.cln_g : W.sln_g) + (long)layer * 512,
+                                      (cross ? W.cln_b : W.sln_b) + (long)layer * 512, active, s));
+    {   // x += ffn.3(h)
+        GemmArgs g = base;
+        g.A = ws->h; g.a_bstride = (long)K * 512; g.lda = 512;
+        g.W = (cross ? W.cf3_w : W.sf3_w) + (long)layer * 256 * 512; g.ldw = 512;
+        g.bias = (cross ? W.cf3_b : W.sf3_b) + (long)layer * 256; g.N = 256; g.K = 512;
+        g.C = x; g.c_bstride = xb; g.ldc = 256; g.R = x; g.r_bstride = xb; g.ldr = 256; g.epi = EPI_BIAS_RESID;
+        IM_HIP(ctx, launch_gemm(g, s));
+    }
+    return 0;
+}
+
+int im_lightglue_forward(im_ctx* ctx, const float* d_kpts, const float* d_desc, const int32_t* d_n, const float* h_size,
+                         const im_lightglue_conf* conf, int32_t* d_matches, float* d_mscores, int32_t* d_prune,
+                         int32_t* d_info, void* stream) {
+    IM_CHECK_CTX(ctx);
+    if (!ctx->lg.ready) return ctx->fail(-50, "im_lightglue_forward: weights not finalized");
+    Workspace* ws = ctx->ws;
+    if (!ws) return ctx->fail(-51, "im_lightglue_forward: call im_ctx_reserve first");
+    hipStream_t s = (hipStream_t)stream;
+    const LightGlueW& W = ctx->lg;
+    const int K = ctx->max_kpts;
+    const int L = conf->n_layers;
+    if (L < 1 || L > 9) return ctx->fail(-52, "im_lightglue_forward: n_layers must be 1..9");
+    const bool do_stop = conf->depth_confidence > 0, do_prune = conf->width_confidence > 0;
+    const long xb = (long)K * 256, eb = (long)K * 32;
+    LGState* st = ws->st;
+
+    IM_HIP(ctx, launch_lg_init(st, d_n, ws->ind[0], ws->prune, K, K, d_matches, d_mscores, K, s));
+    IM_HIP(ctx, hipMemcpyAsync(ws->x[0], d_desc, sizeof(float) * 2 * xb, hipMemcpyDeviceToDevice, s));
+    IM_HIP(ctx, launch_posenc(d_kpts, (long)K * 2, st->n, K, W.wr, h_size, ws->cs[0], ws->sn[0], eb, s));
+    int cur = 0;
+    for (int i = 0; i < L; ++i) {
+        int rc = lg_block(ctx, s, i, false, ws->x[cur], ws->cs[cur], ws->sn[cur]);
+        if (rc) return rc;
+        rc = lg_block(ctx, s, i, true, ws->x[cur], ws->cs[cur], ws->sn[cur]);
+        if (rc) return rc;
+        if (i == L - 1) break;
+        if (!do_stop && !do_prune) continue;
+        IM_HIP(ctx, launch_rowdot(ws->x[cur], xb, st->n, K, do_stop ? W.tc_w + (long)i * 256 : nullptr, W.tc_b + i, 1,
+                                  do_prune ? W.ma_w + (long)i * 256 : nullptr, W.ma_b + i, nullptr, ws->conf, ws->msc, K,
+                                  W.thr[i], do_stop ? &st->cnt[i] : nullptr, &st->active, s));
+        // keep threshold: `scores > (1 - width_confidence)` evaluated in double, compared in fp32 (`lightglue.py:566`)
+        const float keep_thr = (float)(1.0 - (double)conf->width_confidence);
+        IM_HIP(ctx, launch_stop_prune(st, i, do_stop, do_prune, (float)conf->depth_confidence, keep_thr, W.thr[i], ws->conf,
+                                      ws->msc, K, ws->ind[cur], ws->ind[1 - cur], ws->keep_idx, ws->prune, K, s));
+        if (do_prune) {
+            IM_HIP(ctx, launch_gather_rows(st, K, ws->keep_idx, K, ws->x[cur], ws->x[1 - cur], xb, ws->cs[cur], ws->cs[1 - cur],
+                                           ws->sn[cur], ws->sn[1 - cur], eb, s));
+            cur = 1 - cur;
+        }
+    }
+    // ---- assignment with log_assignment[last executed layer]
+    IM_HIP(ctx, launch_lg_select_layer(st, L, ws->sel, d_info, s));
+    {
+        GemmArgs g;
+        g.m_max = K; g.m_ptr = st->n; g.batch = 2;
+        g.A = ws->x[cur]; g.a_bstride = xb; g.lda = 256; g.W = W.fp_w; g.ldw = 256; g.bias = W.fp_b;
+        g.sel = ws->sel; g.w_sel_stride = 65536; g.bias_sel_stride = 256; g.N = 256; g.K = 256;
+        g.C = ws->md; g.c_bstride = xb; g.ldc = 256; g.alpha = 0.25f;  // / 256**0.25 (`lightglue.py:279`)
+        g.epi = EPI_BIAS;
+        IM_HIP(ctx, launch_gemm(g, s));
+    }
+    IM_HIP(ctx, launch_rowdot(ws->x[cur], xb, st->n, K, W.ma_w, W.ma_b, 0, nullptr, nullptr, ws->sel, ws->z, nullptr, K, 0.f,
+                              nullptr, nullptr, s));
+    IM_HIP(ctx, launch_logsig(ws->z, K, st, K, ws->lz, s));
+    {
+        GemmArgs g;
+        g.m_max = K; g.m_ptr = &st->n[0]; g.n_ptr = &st->n[1]; g.batch = 1;
+        g.A = ws->md; g.lda = 256; g.W = ws->md + xb; g.ldw = 256; g.N = K; g.K = 256;
+        g.C = ws->sim; g.ldc = K; g.epi = EPI_BIAS; g.big_tile = 1;
+        IM_HIP(ctx, launch_gemm(g, s));
+    }
+    AssignArgs a;
+    a.sim = ws->sim; a.ld = K; a.m_ptr = &st->n[0]; a.n_ptr = &st->n[1]; a.m_max = K; a.n_max = K;
+    a.lz0 = ws->lz; a.lz1 = ws->lz + K;
+    a.rmax = ws->rmax; a.rlog = ws->rlog; a.cmax = ws->cmax; a.clog = ws->clog; a.part = ws->part;
+    a.ridx = ws->ridx; a.rval = ws->rval; a.cbest = ws->cbest; a.threshold = (float)conf->filter_threshold;
+    a.ind0 = ws->ind[cur]; a.ind1 = ws->ind[cur] + K;
+    a.out_m0 = d_matches; a.out_m1 = d_matches + K; a.out_s0 = d_mscores; a.out_s1 = d_mscores + K;
+    IM_HIP(ctx, launch_assign(a, s));
+    IM_HIP(ctx, hipMemcpyAsync(d_prune, ws->prune, sizeof(int) * 2 * K, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ stage entry points
+int im_nms(im_ctx* ctx, const float* d_scores, float* d_out, int n_images, int h, int w, int radius, void* stream) {
+    IM_CHECK_CTX(ctx);
+    Workspace* ws = ctx->ws;
+    if (!ws || (long)n_images * h * w > (long)ctx->max_images * ((ctx->max_h / 8) * 8) * ((ctx->max_w / 8) * 8))
+        return ctx->fail(-41, "im_nms: exceeds the reserved workspace");
+    IM_HIP(ctx, launch_nms(d_scores, d_out, ws->mask, ws->supp, ws->rest, n_images, h, w, radius, (hipStream_t)stream));
+    return 0;
+}
+
+int im_select_topk(im_ctx* ctx, const float* d_nms, int n_images, int h, int w, int border, float threshold, int max_kpts,
+                   float* d_kpts, float* d_scores, int32_t* d_n, void* stream) {
+    IM_CHECK_CTX(ctx);
+    Workspace* ws = ctx->ws;
+    if (!ws || (long)n_images * h * w > (long)ctx->max_images * ((ctx->max_h / 8) * 8) * ((ctx->max_w / 8) * 8))
+        return ctx->fail(-41, "im_select_topk: exceeds the reserved workspace");
+    IM_HIP(ctx, launch_select_topk(d_nms, n_images, h, w, border, threshold, max_kpts, ctx->max_kpts, ws->counts, ws->n_cand,
+                                   ws->keys, d_kpts, d_scores, d_n, (hipStream_t)stream));
+    return 0;
+}
+
+int im_sample_descriptors(im_ctx* ctx, const float* d_dense_raw, int n_images, int hc, int wc, const float* d_kpts,
+                          const int32_t* d_n, float* d_desc, void* stream) {
+    IM_CHECK_CTX(ctx);
+    if (!ctx->ws) return ctx->fail(-51, "im_sample_descriptors: call im_ctx_reserve first");
+    IM_HIP(ctx, launch_sample_desc(d_dense_raw, n_images, hc, wc, d_kpts, d_n, ctx->max_kpts, d_desc, (hipStream_t)stream));
+    return 0;
+}
+
+int im_assign_from_sim(im_ctx* ctx, const float* d_sim, int m, int n, int ld, const float* d_z0, const float* d_z1,
+                       float threshold, int32_t* d_m0, int32_t* d_m1, float* d_ms0, float* d_ms1, void* stream) {
+    IM_CHECK_CTX(ctx);
+    Workspace* ws = ctx->ws;
+    const int K = ctx->max_kpts;
+    if (!ws || m > K || n > K || m < 1 || n < 1) return ctx->fail(-41, "im_assign_from_sim: m, n must be 1..max_kpts");
+    hipStream_t s = (hipStream_t)stream;
+    // reuse the matcher state as the (m, n) holder
+    const int mn[2] = {m, n};
+    IM_HIP(ctx, hipMemcpyAsync(ws->st->n, mn, sizeof(mn), hipMemcpyHostToDevice, s));
+    IM_HIP(ctx, hipStreamSynchronize(s));
+    IM_HIP(ctx, hipMemcpyAsync(ws->z, d_z0, sizeof(float) * m, hipMemcpyDeviceToDevice, s));
+    IM_HIP(ctx, hipMemcpyAsync(ws->z + K, d_z1, sizeof(float) * n, hipMemcpyDeviceToDevice, s));
+    IM_HIP(ctx, launch_logsig(ws->z, K, ws->st, K, ws->lz, s));
+    AssignArgs a;
+    a.sim = d_sim; a.ld = ld; a.m_ptr = &ws->st->n[0]; a.n_ptr = &ws->st->n[1]; a.m_max = m; a.n_max = n;
+    a.lz0 = ws->lz; a.lz1 = ws->lz + K;
+    a.rmax = ws->rmax; a.rlog = ws->rlog; a.cmax = ws->cmax; a.clog = ws->clog; a.part = ws->part;
+    a.ridx = ws->ridx; a.rval = ws->rval; a.cbest = ws->cbest; a.threshold = threshold;
+    a.out_m0 = d_m0; a.out_m1 = d_m1; a.out_s0 = d_ms0; a.out_s1 = d_ms1;
+    IM_HIP(ctx, launch_assign(a, s));
+    return 0;
+}
+
+}  // extern "C"

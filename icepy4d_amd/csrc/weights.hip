@@ -1,6 +1,7 @@
 // Host-side weight handling: tensors arrive under their official state-dict key names (im_set_tensor),
 // im_finalize_weights re-packs them for the kernels and uploads.
 #include "ctx.h"
+#include "workspace.h"
 
 #include <cmath>
 #include <cstring>
@@ -21,4 +22,9 @@ std::vector<float> pack_conv3x3(const float* w, int cout, int cin) {
 void im_ctx::free_all() {
     for (void* p : allocs) hipFree(p);
     allocs.clear();
+    if (ws) {
+        for (void* p : ws->allocs) hipFree(p);
+        delete ws;
+        ws = nullptr;
+    }
 }

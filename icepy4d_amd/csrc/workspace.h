@@ -1,0 +1,32 @@
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+#include <utility>
+#include <vector>
+
+#include "lg_misc.h"
+
+// device workspace of one context, sized by im_ctx_reserve
+struct Workspace {
+    std::vector<void*> allocs;
+    // SuperPoint
+    float* act0 = nullptr; float* act1 = nullptr;       // NHWC ping-pong
+    float* logits = nullptr; float* dense = nullptr;    // [cells][65], [cells][256]
+    float* smap = nullptr; float* nms = nullptr; float* rest = nullptr;
+    uint8_t* mask = nullptr; uint8_t* supp = nullptr;
+    int* counts = nullptr; int* n_cand = nullptr; unsigned long long* keys = nullptr;
+    // LightGlue / SuperGlue
+    float* x[2] = {nullptr, nullptr}; float* cs[2] = {nullptr, nullptr}; float* sn[2] = {nullptr, nullptr};
+    int* ind[2] = {nullptr, nullptr};
+    float* q = nullptr; float* k = nullptr; float* v = nullptr;
+    float* att = nullptr; float* msg = nullptr; float* h = nullptr;
+    float* conf = nullptr; float* msc = nullptr; int* keep_idx = nullptr; int* prune = nullptr;
+    float* md = nullptr; float* z = nullptr; float* lz = nullptr;
+    float* sim = nullptr; float* sim2 = nullptr;
+    float* rmax = nullptr; float* rlog = nullptr; float* cmax = nullptr; float* clog = nullptr;
+    float2* part = nullptr; int* ridx = nullptr; float* rval = nullptr; unsigned long long* cbest = nullptr;
+    im::LGState* st = nullptr; int* sel = nullptr;
+    float* uv = nullptr;  // Sinkhorn potentials
+};

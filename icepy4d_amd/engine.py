@@ -1,0 +1,117 @@
+"""Thin host wrapper around one `im_ctx` of libicematch: weights in, device buffers, forward calls.
+
+torch is plumbing here (device memory, the current HIP stream); every computation happens in the library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import LightGlueConf, SuperGlueConf, ptr
+
+
+class Engine:
+    """One context on one device. Not re-entrant (results live in the engine's buffers until the next call)."""
+
+    def __init__(self, device: int = 0):
+        if not torch.cuda.is_available():
+            raise RuntimeError("icepy4d_amd needs a HIP device (MI355X); there is no CPU fallback")
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        self.ctx = _lib.Context(device)
+        self.max_h = self.max_w = self.max_images = self.max_kpts = 0
+        self._loaded = set()
+
+    # ------------------------------------------------------------------ weights
+    def load_state_dict(self, model: str, state_dict: Dict[str, torch.Tensor]) -> None:
+        """Pass a state dict with the official key names (`lightglue/superpoint.py:118-137`,
+        `lightglue/lightglue.py:350-373`, `SuperGlue/models/superglue.py:221-242`); the old LightGlue names
+        `self_attn.{i}` / `cross_attn.{i}` are remapped like the reference does (`lightglue.py:388-392`)."""
+        m = model.encode()
+        for key, t in state_dict.items():
+            if key.endswith("num_batches_tracked"):
+                continue
+            if model == "lightglue":
+                for i in range(9):
+                    if key.startswith(f"self_attn.{i}."):
+                        key = key.replace(f"self_attn.{i}", f"transformers.{i}.self_attn", 1)
+                    elif key.startswith(f"cross_attn.{i}."):
+                        key = key.replace(f"cross_attn.{i}", f"transformers.{i}.cross_attn", 1)
+            a = np.ascontiguousarray(t.detach().cpu().to(torch.float32).numpy())
+            self.ctx.call("im_set_tensor", m, key.encode(), a.ctypes.data, a.size)
+        self.ctx.call("im_finalize_weights", m)
+        self._loaded.add(model)
+
+    # ------------------------------------------------------------------ workspace
+    def reserve(self, max_h: int, max_w: int, max_images: int = 2, max_kpts: int = 4096) -> None:
+        if (max_h <= self.max_h and max_w <= self.max_w and max_images <= self.max_images and max_kpts == self.max_kpts):
+            return
+        max_h, max_w, max_images = max(max_h, self.max_h), max(max_w, self.max_w), max(max_images, self.max_images)
+        self.ctx.call("im_ctx_reserve", max_h, max_w, max_images, max_kpts)
+        self.max_h, self.max_w, self.max_images, self.max_kpts = max_h, max_w, max_images, max_kpts
+        K, B = max_kpts, max_images
+        d = self.device
+        self.kpts = torch.zeros(B, K, 2, device=d)
+        self.scores = torch.zeros(B, K, device=d)
+        self.desc = torch.zeros(B, K, 256, device=d)
+        self.n = torch.zeros(B, dtype=torch.int32, device=d)
+        self.matches = torch.zeros(2, K, dtype=torch.int32, device=d)
+        self.mscores = torch.zeros(2, K, device=d)
+        self.prune = torch.zeros(2, K, dtype=torch.int32, device=d)
+        self.info = torch.zeros(4, dtype=torch.int32, device=d)
+
+    # ------------------------------------------------------------------ forwards (enqueue only)
+    def superpoint(self, gray_u8: torch.Tensor, nms_radius: int = 4, threshold: float = 0.0005, border: int = 4,
+                   max_kpts: Optional[int] = None, flavour: int = 0) -> None:
+        """gray_u8: device uint8 [B, H, W]. Fills self.kpts / scores / desc / n."""
+        assert gray_u8.dtype == torch.uint8 and gray_u8.is_cuda and gray_u8.dim() == 3 and gray_u8.is_contiguous()
+        B, H, W = gray_u8.shape
+        k = -1 if max_kpts is None else int(max_kpts)
+        self.ctx.call("im_superpoint_forward", ptr(gray_u8), B, H, W, int(nms_radius), float(threshold), int(border), k,
+                      int(flavour), ptr(self.kpts), ptr(self.scores), ptr(self.desc), ptr(self.n), _lib.stream_ptr())
+
+    def lightglue(self, size0: Tuple[float, float], size1: Tuple[float, float], depth_confidence: float = 0.95,
+                  width_confidence: float = 0.99, filter_threshold: float = 0.1, n_layers: int = 9,
+                  kpts: Optional[torch.Tensor] = None, desc: Optional[torch.Tensor] = None,
+                  n: Optional[torch.Tensor] = None) -> None:
+        """Matches image 0 and 1 of (kpts, desc, n) (default: the SuperPoint outputs held by the engine).
+        size = (W, H). Fills self.matches / mscores / prune / info."""
+        kpts = self.kpts if kpts is None else kpts
+        desc = self.desc if desc is None else desc
+        n = self.n if n is None else n
+        conf = LightGlueConf(float(depth_confidence), float(width_confidence), float(filter_threshold), int(n_layers))
+        size = np.array([size0[0], size0[1], size1[0], size1[1]], dtype=np.float32)
+        self.ctx.call("im_lightglue_forward", ptr(kpts), ptr(desc), ptr(n), size.ctypes.data, C.byref(conf),
+                      ptr(self.matches), ptr(self.mscores), ptr(self.prune), ptr(self.info), _lib.stream_ptr())
+
+    def superglue(self, shape0: Tuple[int, int], shape1: Tuple[int, int], sinkhorn_iterations: int = 20,
+                  match_threshold: float = 0.3, n_layers: int = 18, kpts=None, scores=None, desc=None, n=None) -> None:
+        """shape = (H, W) of the image tensors. Fills self.matches / mscores / info."""
+        kpts = self.kpts if kpts is None else kpts
+        scores = self.scores if scores is None else scores
+        desc = self.desc if desc is None else desc
+        n = self.n if n is None else n
+        conf = SuperGlueConf(int(sinkhorn_iterations), float(match_threshold), int(n_layers))
+        shp = np.array([shape0[0], shape0[1], shape1[0], shape1[1]], dtype=np.float32)
+        self.ctx.call("im_superglue_forward", ptr(kpts), ptr(scores), ptr(desc), ptr(n), shp.ctypes.data, C.byref(conf),
+                      ptr(self.matches), ptr(self.mscores), ptr(self.info), _lib.stream_ptr())
+
+    # ------------------------------------------------------------------ results to host (synchronises)
+    def features_to_host(self, image: int):
+        n = int(self.n[image].item())
+        return (self.kpts[image, :n].cpu().numpy(), self.desc[image, :n].cpu().numpy(), self.scores[image, :n].cpu().numpy())
+
+    def matches_to_host(self, n0: int, n1: int):
+        m = self.matches.cpu().numpy().astype(np.int64)
+        s = self.mscores.cpu().numpy()
+        p = self.prune.cpu().numpy()
+        info = self.info.cpu().numpy()
+        return dict(matches0=m[0, :n0], matches1=m[1, :n1], matching_scores0=s[0, :n0], matching_scores1=s[1, :n1],
+                    prune0=p[0, :n0], prune1=p[1, :n1], stop=int(info[0]))
+
+    def close(self):
+        self.ctx.close()

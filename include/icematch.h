@@ -61,9 +61,9 @@ int im_superpoint_forward(im_ctx* ctx, const uint8_t* d_gray, int n_images, int 
  * Outputs: d_matches [2][max_kpts] int32 (-1 = none; row 0 = matches0, row 1 = matches1),
  * d_mscores [2][max_kpts], d_prune [2][max_kpts] int32, d_info int32[4] = {stop, n0_final, n1_final, 0}. */
 typedef struct {
-    float depth_confidence;  /* <= 0 disables early stop   (`lightglue.py:317`) */
-    float width_confidence;  /* <= 0 disables point pruning (`lightglue.py:318`) */
-    float filter_threshold;  /* `lightglue.py:319` */
+    double depth_confidence; /* <= 0 disables early stop   (`lightglue.py:317`); doubles: the reference holds */
+    double width_confidence; /* <= 0 disables point pruning (`lightglue.py:318`); Python floats and derives   */
+    double filter_threshold; /* `lightglue.py:319`                                 1 - width_confidence in double */
     int n_layers;            /* 9 */
 } im_lightglue_conf;
 int im_lightglue_forward(im_ctx* ctx, const float* d_kpts, const float* d_desc, const int32_t* d_n,
@@ -75,7 +75,7 @@ int im_lightglue_forward(im_ctx* ctx, const float* d_kpts, const float* d_desc, 
  * of the image tensors (`data['image0'].shape`). Outputs as for LightGlue (d_info = {0, n0, n1, 0}). */
 typedef struct {
     int sinkhorn_iterations; /* icepy4d default 20 (`matchers.py:857`) */
-    float match_threshold;   /* icepy4d default 0.3 (`matchers.py:864`) */
+    double match_threshold;  /* icepy4d default 0.3 (`matchers.py:864`) */
     int n_layers;            /* 18 */
 } im_superglue_conf;
 int im_superglue_forward(im_ctx* ctx, const float* d_kpts, const float* d_scores, const float* d_desc,
