@@ -37,6 +37,8 @@ SIGNATURES = {
     "im_ctx_destroy": [_P],
     "im_last_error": [_P],
     "im_ctx_reserve": [_P, _I, _I, _I, _I],
+    "im_profile_begin": [_P],
+    "im_profile_end": [_P, C.c_char_p, C.c_size_t],
     "im_set_tensor": [_P, C.c_char_p, C.c_char_p, _P, C.c_size_t],
     "im_finalize_weights": [_P, C.c_char_p],
     "im_superpoint_forward": [_P, _P, _I, _I, _I, _I, _F, _I, _I, _I, _P, _P, _P, _P, _P],
@@ -68,6 +70,9 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own libamdhip64: it must be the HIP runtime of the process (device pointers and streams
+    # are shared with torch), so torch is imported before the library's NEEDED libamdhip64.so.7 is resolved.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            f"(there is no CPU/torch fallback for the matching hot path)")

@@ -66,6 +66,18 @@ struct im_ctx {
     im::LightGlueW lg;
     im::SuperGlueW sg;
 
+    // optional per-launch timing (HIP events on the launch stream), see im_profile_begin / im_profile_end
+    struct ProfEntry { const char* name; hipEvent_t e0, e1; };
+    bool prof_on = false;
+    std::vector<ProfEntry> prof;
+    std::vector<hipEvent_t> prof_pool;
+    hipEvent_t prof_event() {
+        if (!prof_pool.empty()) { hipEvent_t e = prof_pool.back(); prof_pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        hipEventCreate(&e);
+        return e;
+    }
+
     // reserved workspace
     int max_h = 0, max_w = 0, max_images = 0, max_kpts = 0;
     struct Workspace* ws = nullptr;
@@ -98,6 +110,21 @@ struct im_ctx {
     do {                                                 \
         if (!(ctx)) return -1;                           \
         if (hipSetDevice((ctx)->device) != hipSuccess) return (ctx)->fail(-3, "hipSetDevice failed"); \
+    } while (0)
+
+// launch wrapper: when profiling is on, brackets the launch with two events on its stream
+#define IM_LAUNCH(ctx, name, stream, expr)                                   \
+    do {                                                                     \
+        if ((ctx)->prof_on) {                                                \
+            im_ctx::ProfEntry _pe{name, (ctx)->prof_event(), (ctx)->prof_event()}; \
+            hipEventRecord(_pe.e0, (stream));                                \
+            hipError_t _le = (expr);                                         \
+            hipEventRecord(_pe.e1, (stream));                                \
+            (ctx)->prof.push_back(_pe);                                      \
+            IM_HIP(ctx, _le);                                                \
+        } else {                                                             \
+            IM_HIP(ctx, expr);                                               \
+        }                                                                    \
     } while (0)
 
 #define IM_HIP(ctx, expr)                                                                                   \

@@ -142,6 +142,43 @@ int finalize_superglue(im_ctx* ctx);  // superglue.hip
 
 extern "C" {
 
+int im_profile_begin(im_ctx* ctx) {
+    IM_CHECK_CTX(ctx);
+    IM_HIP(ctx, hipDeviceSynchronize());
+    for (auto& e : ctx->prof) { ctx->prof_pool.push_back(e.e0); ctx->prof_pool.push_back(e.e1); }
+    ctx->prof.clear();
+    ctx->prof_on = true;
+    return 0;
+}
+
+// Writes {"name": {"count": n, "total_ms": t}, ...} (aggregated over the launches since im_profile_begin).
+int im_profile_end(im_ctx* ctx, char* buf, size_t cap) {
+    IM_CHECK_CTX(ctx);
+    ctx->prof_on = false;
+    IM_HIP(ctx, hipDeviceSynchronize());
+    std::map<std::string, std::pair<int, double>> agg;
+    for (auto& e : ctx->prof) {
+        float ms = 0.f;
+        IM_HIP(ctx, hipEventElapsedTime(&ms, e.e0, e.e1));
+        auto& a = agg[e.name];
+        a.first += 1;
+        a.second += ms;
+    }
+    std::string out = "{";
+    bool first = true;
+    for (auto& kv : agg) {
+        char line[256];
+        snprintf(line, sizeof(line), "%s\"%s\": {\"count\": %d, \"total_ms\": %.6f}", first ? "" : ", ", kv.first.c_str(),
+                 kv.second.first, kv.second.second);
+        out += line;
+        first = false;
+    }
+    out += "}";
+    if (!buf || out.size() + 1 > cap) return ctx->fail(-60, "im_profile_end: buffer too small (%zu needed)", out.size() + 1);
+    memcpy(buf, out.c_str(), out.size() + 1);
+    return 0;
+}
+
 int im_set_tensor(im_ctx* ctx, const char* model, const char* key, const float* h_data, size_t numel) {
     IM_CHECK_CTX(ctx);
     if (!model || !key || !h_data) return ctx->fail(-1, "im_set_tensor: null argument");
@@ -240,7 +277,7 @@ int im_superpoint_forward(im_ctx* ctx, const uint8_t* d_gray, int n_images, int 
     hipStream_t s = (hipStream_t)stream;
     const SuperPointW& W = ctx->sp;
     const int B = n_images, K = ctx->max_kpts;
-    IM_HIP(ctx, launch_conv1a(d_gray, W.c1a_w, W.c1a_b, ws->act0, B, h, w, s));
+    IM_LAUNCH(ctx, "conv1a", s, launch_conv1a(d_gray, W.c1a_w, W.c1a_b, ws->act0, B, h, w, s));
     float* src = ws->act0;
     float* dst = ws->act1;
     int ch = h, cw_ = w;
@@ -249,7 +286,7 @@ int im_superpoint_forward(im_ctx* ctx, const uint8_t* d_gray, int n_images, int 
         ConvArgs a;
         a.in = src; a.w = W.cw[i]; a.bias = W.cb[i]; a.out = dst; a.B = B; a.H = ch; a.W = cw_;
         a.Cin = SP_CIN[i]; a.Cout = SP_COUT[i]; a.pool = pool_after[i]; a.relu = 1;
-        IM_HIP(ctx, launch_conv3x3(a, s));
+        IM_LAUNCH(ctx, SP_CONV3[i], s, launch_conv3x3(a, s));
         if (pool_after[i]) { ch /= 2; cw_ /= 2; }
         std::swap(src, dst);
     }
@@ -261,26 +298,26 @@ int im_superpoint_forward(im_ctx* ctx, const uint8_t* d_gray, int n_images, int 
     {
         ConvArgs a;
         a.in = feat; a.w = W.cw[7]; a.bias = W.cb[7]; a.out = tmp; a.B = B; a.H = hc; a.W = wc; a.Cin = 128; a.Cout = 256;
-        IM_HIP(ctx, launch_conv3x3(a, s));
+        IM_LAUNCH(ctx, "convPa", s, launch_conv3x3(a, s));
         GemmArgs g;
         g.A = tmp; g.lda = 256; g.W = W.pb_w; g.ldw = 256; g.bias = W.pb_b; g.N = 65; g.K = 256; g.m_max = (int)cells;
         g.C = ws->logits; g.ldc = 65; g.epi = EPI_BIAS;
-        IM_HIP(ctx, launch_gemm(g, s));
-        IM_HIP(ctx, launch_det_softmax(ws->logits, 65, ws->smap, B, hc, wc, s));
+        IM_LAUNCH(ctx, "convPb_gemm", s, launch_gemm(g, s));
+        IM_LAUNCH(ctx, "det_softmax", s, launch_det_softmax(ws->logits, 65, ws->smap, B, hc, wc, s));
     }
     const int H8 = hc * 8, W8 = wc * 8;
-    IM_HIP(ctx, launch_nms(ws->smap, ws->nms, ws->mask, ws->supp, ws->rest, B, H8, W8, nms_radius, s));
-    IM_HIP(ctx, launch_select_topk(ws->nms, B, H8, W8, border, threshold, max_kpts, K, ws->counts, ws->n_cand, ws->keys,
-                                   d_kpts, d_scores, d_n, s));
+    IM_LAUNCH(ctx, "nms", s, launch_nms(ws->smap, ws->nms, ws->mask, ws->supp, ws->rest, B, H8, W8, nms_radius, s));
+    IM_LAUNCH(ctx, "select_topk", s, launch_select_topk(ws->nms, B, H8, W8, border, threshold, max_kpts, K, ws->counts, ws->n_cand,
+                                                      ws->keys, d_kpts, d_scores, d_n, s));
     {
         ConvArgs a;
         a.in = feat; a.w = W.cw[8]; a.bias = W.cb[8]; a.out = tmp; a.B = B; a.H = hc; a.W = wc; a.Cin = 128; a.Cout = 256;
-        IM_HIP(ctx, launch_conv3x3(a, s));
+        IM_LAUNCH(ctx, "convDa", s, launch_conv3x3(a, s));
         GemmArgs g;
         g.A = tmp; g.lda = 256; g.W = W.db_w; g.ldw = 256; g.bias = W.db_b; g.N = 256; g.K = 256; g.m_max = (int)cells;
         g.C = ws->dense; g.ldc = 256; g.epi = EPI_BIAS;
-        IM_HIP(ctx, launch_gemm(g, s));
-        IM_HIP(ctx, launch_sample_desc(ws->dense, B, hc, wc, d_kpts, d_n, K, d_desc, s));
+        IM_LAUNCH(ctx, "convDb_gemm", s, launch_gemm(g, s));
+        IM_LAUNCH(ctx, "sample_desc", s, launch_sample_desc(ws->dense, B, hc, wc, d_kpts, d_n, K, d_desc, s));
     }
     return 0;
 }
@@ -305,7 +342,7 @@ static int lg_block(im_ctx* ctx, hipStream_t s, int layer, bool cross, float* x,
         g.bias = W.qkv_b + (long)layer * 768; g.N = 768; g.K = 256; g.epi = EPI_QKV_ROPE;
         g.q = ws->q; g.k = ws->k; g.v = ws->v; g.head_bstride = (long)K * 256; g.head_stride = (long)K * 64;
         g.cs = cs; g.sn = sn; g.enc_bstride = (long)K * 32;
-        IM_HIP(ctx, launch_gemm(g, s));
+        IM_LAUNCH(ctx, "lg_qkv_rope_gemm", s, launch_gemm(g, s));
         at.scale = 0.125f;  // SDPA default 1/sqrt(64) (`lightglue.py:120-123`)
     } else {
         GemmArgs g = base;
@@ -313,19 +350,19 @@ static int lg_block(im_ctx* ctx, hipStream_t s, int layer, bool cross, float* x,
         g.bias = W.cqk_b + (long)layer * 256; g.N = 256; g.K = 256; g.epi = EPI_HEADS;
         g.q = ws->q; g.head_bstride = (long)K * 256; g.head_stride = (long)K * 64;
         g.alpha = (float)0.35355339059327373;  // scale**0.5 = 64**-0.25 (`lightglue.py:201`)
-        IM_HIP(ctx, launch_gemm(g, s));
+        IM_LAUNCH(ctx, "lg_proj_gemm", s, launch_gemm(g, s));
         g.W = W.cv_w + (long)layer * 65536; g.bias = W.cv_b + (long)layer * 256; g.q = ws->v; g.alpha = 1.f;
-        IM_HIP(ctx, launch_gemm(g, s));
+        IM_LAUNCH(ctx, "lg_proj_gemm", s, launch_gemm(g, s));
         at.scale = 1.f;
     }
-    IM_HIP(ctx, launch_flash_attn(at, s));
+    IM_LAUNCH(ctx, cross ? "flash_attn_cross" : "flash_attn_self", s, launch_flash_attn(at, s));
     {   // out_proj / to_out
         GemmArgs g = base;
         g.A = ws->att; g.a_bstride = xb; g.lda = 256;
         g.W = (cross ? W.co_w : W.out_w) + (long)layer * 65536; g.ldw = 256;
         g.bias = (cross ? W.co_b : W.out_b) + (long)layer * 256; g.N = 256; g.K = 256;
         g.C = ws->msg; g.c_bstride = xb; g.ldc = 256; g.epi = EPI_BIAS;
-        IM_HIP(ctx, launch_gemm(g, s));
+        IM_LAUNCH(ctx, "lg_proj_gemm", s, launch_gemm(g, s));
     }
     {   // ffn.0 on cat([x, msg])
         GemmArgs g = base;
@@ -333,17 +370,17 @@ static int lg_block(im_ctx* ctx, hipStream_t s, int layer, bool cross, float* x,
         g.W = (cross ? W.cf0_w : W.sf0_w) + (long)layer * 512 * 512; g.ldw = 512;
         g.bias = (cross ? W.cf0_b : W.sf0_b) + (long)layer * 512; g.N = 512; g.K = 512;
         g.C = ws->h; g.c_bstride = (long)K * 512; g.ldc = 512; g.epi = EPI_BIAS;
-        IM_HIP(ctx, launch_gemm(g, s));
+        IM_LAUNCH(ctx, "lg_ffn0_gemm", s, launch_gemm(g, s));
     }
-    IM_HIP(ctx, launch_layernorm_gelu(ws->h, (long)K * 512, n_ptr, K, (cross ? W.cln_g : W.sln_g) + (long)layer * 512,
-                                      (cross ? W.cln_b : W.sln_b) + (long)layer * 512, active, s));
+    IM_LAUNCH(ctx, "lg_layernorm_gelu", s, launch_layernorm_gelu(ws->h, (long)K * 512, n_ptr, K, (cross ? W.cln_g : W.sln_g) + (long)layer * 512,
+                                                               (cross ? W.cln_b : W.sln_b) + (long)layer * 512, active, s));
     {   // x += ffn.3(h)
         GemmArgs g = base;
         g.A = ws->h; g.a_bstride = (long)K * 512; g.lda = 512;
         g.W = (cross ? W.cf3_w : W.sf3_w) + (long)layer * 256 * 512; g.ldw = 512;
         g.bias = (cross ? W.cf3_b : W.sf3_b) + (long)layer * 256; g.N = 256; g.K = 512;
         g.C = x; g.c_bstride = xb; g.ldc = 256; g.R = x; g.r_bstride = xb; g.ldr = 256; g.epi = EPI_BIAS_RESID;
-        IM_HIP(ctx, launch_gemm(g, s));
+        IM_LAUNCH(ctx, "lg_ffn3_gemm", s, launch_gemm(g, s));
     }
     return 0;
 }
@@ -375,16 +412,16 @@ int im_lightglue_forward(im_ctx* ctx, const float* d_kpts, const float* d_desc, 
         if (rc) return rc;
         if (i == L - 1) break;
         if (!do_stop && !do_prune) continue;
-        IM_HIP(ctx, launch_rowdot(ws->x[cur], xb, st->n, K, do_stop ? W.tc_w + (long)i * 256 : nullptr, W.tc_b + i, 1,
+        IM_LAUNCH(ctx, "lg_adapt", s, launch_rowdot(ws->x[cur], xb, st->n, K, do_stop ? W.tc_w + (long)i * 256 : nullptr, W.tc_b + i, 1,
                                   do_prune ? W.ma_w + (long)i * 256 : nullptr, W.ma_b + i, nullptr, ws->conf, ws->msc, K,
                                   W.thr[i], do_stop ? &st->cnt[i] : nullptr, &st->active, s));
         // keep threshold: `scores > (1 - width_confidence)` evaluated in double, compared in fp32 (`lightglue.py:566`)
         const float keep_thr = (float)(1.0 - (double)conf->width_confidence);
-        IM_HIP(ctx, launch_stop_prune(st, i, do_stop, do_prune, (float)conf->depth_confidence, keep_thr, W.thr[i], ws->conf,
-                                      ws->msc, K, ws->ind[cur], ws->ind[1 - cur], ws->keep_idx, ws->prune, K, s));
+        IM_LAUNCH(ctx, "lg_adapt", s, launch_stop_prune(st, i, do_stop, do_prune, (float)conf->depth_confidence, keep_thr, W.thr[i], ws->conf,
+                                                      ws->msc, K, ws->ind[cur], ws->ind[1 - cur], ws->keep_idx, ws->prune, K, s));
         if (do_prune) {
-            IM_HIP(ctx, launch_gather_rows(st, K, ws->keep_idx, K, ws->x[cur], ws->x[1 - cur], xb, ws->cs[cur], ws->cs[1 - cur],
-                                           ws->sn[cur], ws->sn[1 - cur], eb, s));
+            IM_LAUNCH(ctx, "lg_adapt", s, launch_gather_rows(st, K, ws->keep_idx, K, ws->x[cur], ws->x[1 - cur], xb, ws->cs[cur], ws->cs[1 - cur],
+                                                           ws->sn[cur], ws->sn[1 - cur], eb, s));
             cur = 1 - cur;
         }
     }
@@ -397,7 +434,7 @@ int im_lightglue_forward(im_ctx* ctx, const float* d_kpts, const float* d_desc, 
         g.sel = ws->sel; g.w_sel_stride = 65536; g.bias_sel_stride = 256; g.N = 256; g.K = 256;
         g.C = ws->md; g.c_bstride = xb; g.ldc = 256; g.alpha = 0.25f;  // / 256**0.25 (`lightglue.py:279`)
         g.epi = EPI_BIAS;
-        IM_HIP(ctx, launch_gemm(g, s));
+        IM_LAUNCH(ctx, "lg_proj_gemm", s, launch_gemm(g, s));
     }
     IM_HIP(ctx, launch_rowdot(ws->x[cur], xb, st->n, K, W.ma_w, W.ma_b, 0, nullptr, nullptr, ws->sel, ws->z, nullptr, K, 0.f,
                               nullptr, nullptr, s));
@@ -407,7 +444,7 @@ int im_lightglue_forward(im_ctx* ctx, const float* d_kpts, const float* d_desc, 
         g.m_max = K; g.m_ptr = &st->n[0]; g.n_ptr = &st->n[1]; g.batch = 1;
         g.A = ws->md; g.lda = 256; g.W = ws->md + xb; g.ldw = 256; g.N = K; g.K = 256;
         g.C = ws->sim; g.ldc = K; g.epi = EPI_BIAS; g.big_tile = 1;
-        IM_HIP(ctx, launch_gemm(g, s));
+        IM_LAUNCH(ctx, "score_gemm", s, launch_gemm(g, s));
     }
     AssignArgs a;
     a.sim = ws->sim; a.ld = K; a.m_ptr = &st->n[0]; a.n_ptr = &st->n[1]; a.m_max = K; a.n_max = K;
@@ -416,7 +453,7 @@ int im_lightglue_forward(im_ctx* ctx, const float* d_kpts, const float* d_desc, 
     a.ridx = ws->ridx; a.rval = ws->rval; a.cbest = ws->cbest; a.threshold = (float)conf->filter_threshold;
     a.ind0 = ws->ind[cur]; a.ind1 = ws->ind[cur] + K;
     a.out_m0 = d_matches; a.out_m1 = d_matches + K; a.out_s0 = d_mscores; a.out_s1 = d_mscores + K;
-    IM_HIP(ctx, launch_assign(a, s));
+    IM_LAUNCH(ctx, "assign", s, launch_assign(a, s));
     IM_HIP(ctx, hipMemcpyAsync(d_prune, ws->prune, sizeof(int) * 2 * K, hipMemcpyDeviceToDevice, s));
     return 0;
 }

@@ -1,0 +1,107 @@
+"""Multitemporal sequence driver: the data-parallel replacement of the reference's sequential epoch loop
+(`main_dev.py:60`: `for ep in cfg.proc.epoch_to_process`, with a fresh matcher per epoch `main_dev.py:115-132`,
+i.e. no state is carried between epochs).
+
+Epochs (stereo pairs) are sharded over ranks, one process per GPU; every rank matches its own pairs with its own
+`Engine` and writes one fixed-size *match-table record* per pair into a device tensor. The only communication of
+the whole job is one all-gather of the per-rank tables at the end (RCCL over xGMI when the backend is "nccl";
+"gloo" on CPU for the tests), after which every rank holds the complete per-epoch match table.
+
+Record layout (int32 words):
+    [0] epoch  [1] n0  [2] n1  [3] n_matches (-1 = pair failed)  [4] stop layer  [5..7] reserved
+    [8 : 8+K]       matches0 (int32, -1 = unmatched)
+    [8+K : 8+2K]    matching_scores0 (float32 bit patterns)
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+HEADER = 8
+
+
+def record_words(max_kpts: int) -> int:
+    return HEADER + 2 * max_kpts
+
+
+def shard_epochs(n_epochs: int, rank: int, world: int) -> List[int]:
+    """Epochs owned by `rank`: e = rank (mod world). Round-robin keeps the ranks' work equal to within one
+    pair and every rank's share spread over the whole sequence."""
+    return list(range(rank, n_epochs, world))
+
+
+def new_table(n_rows: int, max_kpts: int, device) -> torch.Tensor:
+    t = torch.full((n_rows, record_words(max_kpts)), -1, dtype=torch.int32, device=device)
+    t[:, HEADER + max_kpts:] = 0
+    return t
+
+
+def write_record(table: torch.Tensor, row: int, epoch: int, n: torch.Tensor, matches0: torch.Tensor,
+                 mscores0: torch.Tensor, info: torch.Tensor) -> None:
+    """Device-side (no host sync): fill one row from the engine's output buffers."""
+    K = matches0.shape[0]
+    r = table[row]
+    r[0] = epoch
+    r[1:3] = n[:2]
+    r[3] = (matches0 > -1).sum().to(torch.int32)
+    r[4] = info[0]
+    r[HEADER:HEADER + K] = matches0
+    r[HEADER + K:HEADER + 2 * K] = mscores0.view(torch.int32)
+
+
+def all_gather_tables(local: torch.Tensor, group=None) -> torch.Tensor:
+    """One all-gather of the fixed-size per-rank tables; returns the global table sorted by epoch
+    (rows of ranks that own fewer epochs are padded with epoch = -1 and dropped)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        out = local
+    else:
+        world = dist.get_world_size(group)
+        rows = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
+        all_rows = [torch.zeros_like(rows) for _ in range(world)]
+        dist.all_gather(all_rows, rows, group=group)
+        max_rows = int(max(int(r.item()) for r in all_rows))
+        if local.shape[0] < max_rows:
+            pad = torch.full((max_rows - local.shape[0], local.shape[1]), -1, dtype=local.dtype, device=local.device)
+            local = torch.cat([local, pad], 0)
+        out = torch.empty((world * max_rows, local.shape[1]), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+    out = out[out[:, 0] >= 0]
+    return out[torch.argsort(out[:, 0])]
+
+
+def decode_record(rec: np.ndarray, max_kpts: int) -> dict:
+    rec = np.asarray(rec)
+    K = max_kpts
+    return dict(epoch=int(rec[0]), n0=int(rec[1]), n1=int(rec[2]), n_matches=int(rec[3]), stop=int(rec[4]),
+                matches0=rec[HEADER:HEADER + K][:max(int(rec[1]), 0)].astype(np.int64),
+                matching_scores0=rec[HEADER + K:HEADER + 2 * K].view(np.float32)[:max(int(rec[1]), 0)])
+
+
+class SequenceMatcher:
+    """SuperPoint + LightGlue over a list of stereo pairs on one GPU, results kept on the device."""
+
+    def __init__(self, engine, height: int, width: int, max_keypoints: int = 4096, nms_radius: int = 4,
+                 detection_threshold: float = 0.0005, remove_borders: int = 4, depth_confidence: float = 0.95,
+                 width_confidence: float = 0.99, filter_threshold: float = 0.1):
+        self.e = engine
+        self.h, self.w, self.k = height, width, max_keypoints
+        self.sp = (nms_radius, detection_threshold, remove_borders)
+        self.lg = dict(depth_confidence=depth_confidence, width_confidence=width_confidence, filter_threshold=filter_threshold)
+        engine.reserve(height, width, 2, max_keypoints)
+
+    def match_pair(self, pair_u8: torch.Tensor, epoch: int, table: torch.Tensor, row: int) -> None:
+        """pair_u8: device uint8 [2, H, W]. Enqueues the whole pair and its record; never synchronises."""
+        e = self.e
+        e.superpoint(pair_u8, self.sp[0], self.sp[1], self.sp[2], self.k)
+        e.lightglue((self.w, self.h), (self.w, self.h), **self.lg)
+        write_record(table, row, epoch, e.n, e.matches[0], e.mscores[0], e.info)
+
+    def run(self, pairs: Sequence[torch.Tensor], epochs: Sequence[int], table: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if table is None:
+            table = new_table(len(epochs), self.k, self.e.device)
+        for row, (p, ep) in enumerate(zip(pairs, epochs)):
+            self.match_pair(p, ep, table, row)
+        return table

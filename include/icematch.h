@@ -35,6 +35,11 @@ const char* im_last_error(im_ctx* ctx);
  * keypoints per image. Must be called before any forward; may be called again to grow. Synchronises. */
 int im_ctx_reserve(im_ctx* ctx, int max_h, int max_w, int max_images, int max_kpts);
 
+/* Per-launch timing with HIP events recorded on the launch stream (what bench.py's roofline leg reads).
+ * begin: synchronises and arms; end: synchronises and writes a JSON object {"kernel": {"count", "total_ms"}}. */
+int im_profile_begin(im_ctx* ctx);
+int im_profile_end(im_ctx* ctx, char* buf, size_t cap);
+
 /* ---- weights: tensors are passed under their OFFICIAL state-dict key names --------------------------
  * model: "superpoint" (`lightglue/superpoint.py:118-137` == `SuperGlue/models/superpoint.py:122-140`),
  *        "lightglue"  (`lightglue/lightglue.py:350-373`), "superglue" (`SuperGlue/models/superglue.py:221-242`).
