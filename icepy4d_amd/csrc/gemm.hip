@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
                     if (row < M && col_ok) {
                         const int which = col >> 8, hd = col & 255, head = hd >> 6, d = hd & 63;
                         float outv = val;
-                        if (which < 2) {
+                        if (which < 2 && a.cs) {
                             const long e = (long)z * a.enc_bstride + (long)row * 32 + (d >> 1);
                             const float cs = a.cs[e], sn = a.sn[e];
                             outv = (d & 1) ? (val * cs) + (partner * sn) : (val * cs) + ((-partner) * sn);

@@ -20,6 +20,7 @@ struct AssignArgs {
     float2* part = nullptr;                                   // [ceil(m_max/128)][n_max]
     int* ridx = nullptr; float* rval = nullptr; unsigned long long* cbest = nullptr;
     float threshold = 0.1f;
+    int mode = 0;   // 0: LightGlue double log-softmax; 1: SuperGlue OT (rmax = u, cmax = v, rlog[0] = norm)
     const int* ind0 = nullptr; const int* ind1 = nullptr;     // compact -> original index (null = identity)
     int* out_m0 = nullptr; int* out_m1 = nullptr; float* out_s0 = nullptr; float* out_s1 = nullptr;
 };

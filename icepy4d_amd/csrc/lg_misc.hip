@@ -334,11 +334,16 @@ __global__ __launch_bounds__(256) void logsig_kernel(const float* __restrict__ z
     if (i < st->n[b]) lz[(long)b * bstride + i] = log_sigmoid(z[(long)b * bstride + i]);
 }
 
+// MODE 0 (LightGlue): score = log_softmax_row + log_softmax_col + certainties
+// MODE 1 (SuperGlue, `superglue.py:160, 185`): score = ((x + u_i) + v_j) - norm, with u in rmax, v in cmax, norm in *rlog
+template <int MODE>
 __device__ __forceinline__ float assign_score(float x, float rm, float rl, float cm, float cl, float l0, float l1) {
-    return (((x - rm) - rl) + ((x - cm) - cl)) + (l0 + l1);
+    if constexpr (MODE == 0) return (((x - rm) - rl) + ((x - cm) - cl)) + (l0 + l1);
+    else return ((x + rm) + cm) - rl;
 }
 
 // wave per row: argmax over columns, first index among ties (torch.max semantics)
+template <int MODE>
 __global__ __launch_bounds__(256) void row_argmax_kernel(const float* __restrict__ sim, int ld, const int* __restrict__ m_ptr,
                                                           const int* __restrict__ n_ptr, const float* __restrict__ rmax,
                                                           const float* __restrict__ rlog, const float* __restrict__ cmax,
@@ -350,11 +355,12 @@ __global__ __launch_bounds__(256) void row_argmax_kernel(const float* __restrict
     const int m = *m_ptr, n = *n_ptr;
     if (i >= m) return;
     const float* p = sim + (long)i * ld;
-    const float rm = rmax[i], rl = rlog[i], l0 = lz0[i];
+    const float rm = rmax[i], rl = MODE == 0 ? rlog[i] : rlog[0], l0 = MODE == 0 ? lz0[i] : 0.f;
     float best = -INFINITY;
     int bj = 0x7fffffff;
     for (int j = lane; j < n; j += 64) {
-        const float v = assign_score(p[j], rm, rl, cmax[j], clog[j], l0, lz1[j]);
+        const float v = MODE == 0 ? assign_score<0>(p[j], rm, rl, cmax[j], clog[j], l0, lz1[j])
+                                  : assign_score<1>(p[j], rm, rl, cmax[j], 0.f, 0.f, 0.f);
         if (v > best || (bj == 0x7fffffff)) { best = v; bj = j; }
     }
 #pragma unroll
@@ -368,6 +374,7 @@ __global__ __launch_bounds__(256) void row_argmax_kernel(const float* __restrict
 
 // thread per column, strip of rows: running best (strict > keeps the first row), merged with a 64-bit atomicMax
 // on (ordered score bits, ~row): max is order independent => deterministic
+template <int MODE>
 __global__ __launch_bounds__(256) void col_argmax_kernel(const float* __restrict__ sim, int ld, const int* __restrict__ m_ptr,
                                                           const int* __restrict__ n_ptr, const float* __restrict__ rmax,
                                                           const float* __restrict__ rlog, const float* __restrict__ cmax,
@@ -378,11 +385,13 @@ __global__ __launch_bounds__(256) void col_argmax_kernel(const float* __restrict
     const int i0 = blockIdx.y * COL_STRIP;
     if (j >= n || i0 >= m) return;
     const int i1 = min(i0 + COL_STRIP, m);
-    const float cm = cmax[j], cl = clog[j], l1 = lz1[j];
+    const float cm = cmax[j], cl = MODE == 0 ? clog[j] : 0.f, l1 = MODE == 0 ? lz1[j] : 0.f;
+    const float nrm = MODE == 0 ? 0.f : rlog[0];
     float best = -INFINITY;
     int bi = -1;
     for (int i = i0; i < i1; ++i) {
-        const float v = assign_score(sim[(long)i * ld + j], rmax[i], rlog[i], cm, cl, lz0[i], l1);
+        const float v = MODE == 0 ? assign_score<0>(sim[(long)i * ld + j], rmax[i], rlog[i], cm, cl, lz0[i], l1)
+                                  : assign_score<1>(sim[(long)i * ld + j], rmax[i], nrm, cm, 0.f, 0.f, 0.f);
         if (v > best || bi < 0) { best = v; bi = i; }
     }
     const unsigned long long key = ((unsigned long long)f2ord(best) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)bi);
@@ -398,6 +407,7 @@ __global__ __launch_bounds__(256) void filter_scatter_kernel(const int* __restri
                                                               float* __restrict__ out_s0, float* __restrict__ out_s1) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int m = *m_ptr, n = *n_ptr;
+    if (m <= 0 || n <= 0) return;  // outputs keep their -1 / 0 initialisation (`superglue.py:255-262`)
     auto col_of = [&](int j) { return (int)(0xFFFFFFFFu - (unsigned)(cbest[j] & 0xFFFFFFFFull)); };
     if (blockIdx.y == 0) {
         if (t >= m) return;
@@ -427,13 +437,20 @@ hipError_t launch_assign(const AssignArgs& a, hipStream_t s) {
     hipError_t e = hipMemsetAsync(a.cbest, 0, sizeof(unsigned long long) * kc, s);
     if (e != hipSuccess) return e;
     const int nstrips = (kr + COL_STRIP - 1) / COL_STRIP;
-    hipLaunchKernelGGL(row_lse_kernel, dim3((kr + 3) / 4), dim3(256), 0, s, a.sim, a.ld, a.m_ptr, a.n_ptr, a.rmax, a.rlog);
-    hipLaunchKernelGGL(col_lse_partial_kernel, dim3((kc + 255) / 256, nstrips), dim3(256), 0, s, a.sim, a.ld, a.m_ptr, a.n_ptr, a.part, kc);
-    hipLaunchKernelGGL(col_lse_combine_kernel, dim3((kc + 255) / 256), dim3(256), 0, s, a.part, kc, a.m_ptr, a.n_ptr, a.cmax, a.clog);
-    hipLaunchKernelGGL(row_argmax_kernel, dim3((kr + 3) / 4), dim3(256), 0, s, a.sim, a.ld, a.m_ptr, a.n_ptr, a.rmax, a.rlog, a.cmax,
-                       a.clog, a.lz0, a.lz1, a.ridx, a.rval);
-    hipLaunchKernelGGL(col_argmax_kernel, dim3((kc + 255) / 256, nstrips), dim3(256), 0, s, a.sim, a.ld, a.m_ptr, a.n_ptr, a.rmax, a.rlog,
-                       a.cmax, a.clog, a.lz0, a.lz1, a.cbest);
+    if (a.mode == 0) {
+        hipLaunchKernelGGL(row_lse_kernel, dim3((kr + 3) / 4), dim3(256), 0, s, a.sim, a.ld, a.m_ptr, a.n_ptr, a.rmax, a.rlog);
+        hipLaunchKernelGGL(col_lse_partial_kernel, dim3((kc + 255) / 256, nstrips), dim3(256), 0, s, a.sim, a.ld, a.m_ptr, a.n_ptr, a.part, kc);
+        hipLaunchKernelGGL(col_lse_combine_kernel, dim3((kc + 255) / 256), dim3(256), 0, s, a.part, kc, a.m_ptr, a.n_ptr, a.cmax, a.clog);
+        hipLaunchKernelGGL(row_argmax_kernel<0>, dim3((kr + 3) / 4), dim3(256), 0, s, a.sim, a.ld, a.m_ptr, a.n_ptr, a.rmax, a.rlog, a.cmax,
+                           a.clog, a.lz0, a.lz1, a.ridx, a.rval);
+        hipLaunchKernelGGL(col_argmax_kernel<0>, dim3((kc + 255) / 256, nstrips), dim3(256), 0, s, a.sim, a.ld, a.m_ptr, a.n_ptr, a.rmax, a.rlog,
+                           a.cmax, a.clog, a.lz0, a.lz1, a.cbest);
+    } else {  // optimal transport: rmax = u, cmax = v, rlog[0] = norm were produced by the Sinkhorn sweeps
+        hipLaunchKernelGGL(row_argmax_kernel<1>, dim3((kr + 3) / 4), dim3(256), 0, s, a.sim, a.ld, a.m_ptr, a.n_ptr, a.rmax, a.rlog, a.cmax,
+                           a.clog, a.lz0, a.lz1, a.ridx, a.rval);
+        hipLaunchKernelGGL(col_argmax_kernel<1>, dim3((kc + 255) / 256, nstrips), dim3(256), 0, s, a.sim, a.ld, a.m_ptr, a.n_ptr, a.rmax, a.rlog,
+                           a.cmax, a.clog, a.lz0, a.lz1, a.cbest);
+    }
     const int kk = kr > kc ? kr : kc;
     hipLaunchKernelGGL(filter_scatter_kernel, dim3((kk + 255) / 256, 2), dim3(256), 0, s, a.m_ptr, a.n_ptr, a.ridx, a.rval, a.cbest,
                        a.threshold, a.ind0, a.ind1, a.out_m0, a.out_m1, a.out_s0, a.out_s1);

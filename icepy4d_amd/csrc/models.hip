@@ -202,13 +202,17 @@ int im_finalize_weights(im_ctx* ctx, const char* model) {
 int im_ctx_reserve(im_ctx* ctx, int max_h, int max_w, int max_images, int max_kpts) {
     IM_CHECK_CTX(ctx);
     if (max_h < 8 || max_w < 8 || max_images < 1 || max_kpts < 1) return ctx->fail(-30, "im_ctx_reserve: bad sizes");
-    if (ctx->ws && max_h <= ctx->max_h && max_w <= ctx->max_w && max_images <= ctx->max_images && max_kpts == ctx->max_kpts) return 0;
+    if (ctx->ws && max_h <= ctx->max_h && max_w <= ctx->max_w && max_images <= ctx->max_images && max_kpts <= ctx->max_kpts) return 0;
     IM_HIP(ctx, hipDeviceSynchronize());
     if (ctx->ws) {
         for (void* p : ctx->ws->allocs) hipFree(p);
         delete ctx->ws;
         ctx->ws = nullptr;
     }
+    if (ctx->max_h > max_h) max_h = ctx->max_h;
+    if (ctx->max_w > max_w) max_w = ctx->max_w;
+    if (ctx->max_images > max_images) max_images = ctx->max_images;
+    if (ctx->max_kpts > max_kpts) max_kpts = ctx->max_kpts;
     Workspace* ws = new Workspace();
     const long B = max_images;
     const long H8 = (max_h / 8) * 8, W8 = (max_w / 8) * 8, cells = (H8 / 8) * (W8 / 8), K = max_kpts;

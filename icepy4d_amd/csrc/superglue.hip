@@ -1,0 +1,365 @@
+// SuperGlue (`SuperGlue/models/superglue.py:250-305`): keypoint encoder, 18-layer attentional GNN, score GEMM,
+// log-domain Sinkhorn, mutual filter. The GNN reuses the fp32-MFMA GEMM and flash-attention kernels: SuperGlue's
+// head layout (channel c = d * 4 + head, `view(b, 64, 4, N)` `:111-114`) is absorbed into the packed weights
+// (projection rows and merge columns are permuted to head-major once at load), BatchNorm (eval) is folded into
+// the preceding 1x1 convolution. The Sinkhorn sweeps never materialise the (M+1) x (N+1) coupling matrix:
+// the similarity matrix stays read-only in HBM and the dustbin row / column are the scalar `bin_score`.
+#include <cmath>
+#include <cstring>
+
+#include "common.h"
+#include "ctx.h"
+#include "lg_misc.h"
+#include "workspace.h"
+
+using namespace im;
+
+namespace im {
+
+// keypoint encoder input (`superglue.py:64-71, 82-84`): [(x - W/2) / (0.7 max(W, H)), (y - H/2) / .., score, 0 x 29]
+__global__ __launch_bounds__(256) void sg_kenc_input_kernel(const float* __restrict__ kpts, const float* __restrict__ scores,
+                                                             int kmax, const LGState* __restrict__ st, float4 shapes,
+                                                             float* __restrict__ inp) {
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int i = t >> 5, f = t & 31;
+    if (i >= st->n[b]) return;
+    const float hgt = b == 0 ? shapes.x : shapes.z, wid = b == 0 ? shapes.y : shapes.w;
+    const float scaling = fmaxf(wid, hgt) * 0.7f;
+    float v = 0.f;
+    if (f == 0) v = (kpts[((long)b * kmax + i) * 2] - wid / 2.f) / scaling;
+    else if (f == 1) v = (kpts[((long)b * kmax + i) * 2 + 1] - hgt / 2.f) / scaling;
+    else if (f == 2) v = scores[(long)b * kmax + i];
+    inp[((long)b * kmax + i) * 32 + f] = v;
+}
+
+// ---- log-domain Sinkhorn (`log_sinkhorn_iterations`, `superglue.py:152-160`), couplings Z = [[sim, a], [a, a]]
+__device__ __forceinline__ float sg_norm(int m, int n) { return -logf((float)m + (float)n); }
+
+// u[i] = log_mu[i] - logsumexp_j(Z[i][j] + v[j]), i in [0, m]; wave per row
+__global__ __launch_bounds__(256) void sinkhorn_row_kernel(const float* __restrict__ sim, int ld, const int* __restrict__ m_ptr,
+                                                            const int* __restrict__ n_ptr, float alpha,
+                                                            const float* __restrict__ v, float* __restrict__ u) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int m = *m_ptr, n = *n_ptr;
+    if (i > m || m <= 0 || n <= 0) return;
+    const float* p = sim + (long)i * ld;
+    const bool bin_row = i == m;
+    float mx = alpha + v[n];
+    for (int j = lane; j < n; j += 64) mx = fmaxf(mx, (bin_row ? alpha : p[j]) + v[j]);
+    mx = wave_max(mx);
+    float s = 0.f;
+    for (int j = lane; j < n; j += 64) s += expf(((bin_row ? alpha : p[j]) + v[j]) - mx);
+    s = wave_sum(s) + expf((alpha + v[n]) - mx);
+    if (lane == 0) {
+        const float norm = sg_norm(m, n);
+        const float log_mu = bin_row ? logf((float)n) + norm : norm;
+        u[i] = log_mu - (logf(s) + mx);
+    }
+}
+
+static constexpr int SK_STRIP = 128;
+
+// per column j in [0, n] and row strip: online (max, sum) of Z[i][j] + u[i] over the strip's rows i < m
+__global__ __launch_bounds__(256) void sinkhorn_col_partial_kernel(const float* __restrict__ sim, int ld, const int* __restrict__ m_ptr,
+                                                                    const int* __restrict__ n_ptr, float alpha,
+                                                                    const float* __restrict__ u, float2* __restrict__ part, int pstride) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int m = *m_ptr, n = *n_ptr;
+    const int i0 = blockIdx.y * SK_STRIP;
+    if (j > n || i0 >= m || n <= 0) return;
+    const int i1 = min(i0 + SK_STRIP, m);
+    const bool bin_col = j == n;
+    float mx = -INFINITY;
+    for (int i = i0; i < i1; ++i) mx = fmaxf(mx, (bin_col ? alpha : sim[(long)i * ld + j]) + u[i]);
+    float s = 0.f;
+    for (int i = i0; i < i1; ++i) s += expf(((bin_col ? alpha : sim[(long)i * ld + j]) + u[i]) - mx);
+    part[(long)blockIdx.y * pstride + j] = make_float2(mx, s);
+}
+
+__global__ __launch_bounds__(256) void sinkhorn_col_combine_kernel(const float2* __restrict__ part, int pstride,
+                                                                    const int* __restrict__ m_ptr, const int* __restrict__ n_ptr,
+                                                                    float alpha, const float* __restrict__ u, float* __restrict__ v,
+                                                                    float* __restrict__ norm_out) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int m = *m_ptr, n = *n_ptr;
+    if (j > n || m <= 0 || n <= 0) return;
+    const int ns = (m + SK_STRIP - 1) / SK_STRIP;
+    const float last = alpha + u[m];  // dustbin row
+    float mx = last;
+    for (int s = 0; s < ns; ++s) mx = fmaxf(mx, part[(long)s * pstride + j].x);
+    float sum = expf(last - mx);
+    for (int s = 0; s < ns; ++s) {
+        const float2 p = part[(long)s * pstride + j];
+        sum += p.y * expf(p.x - mx);
+    }
+    const float norm = sg_norm(m, n);
+    const float log_nu = (j == n) ? logf((float)m) + norm : norm;
+    v[j] = log_nu - (logf(sum) + mx);
+    if (j == 0) *norm_out = norm;
+}
+
+// full (m+1) x (n+1) transport matrix, only for the stage entry point / tests
+__global__ __launch_bounds__(256) void ot_materialize_kernel(const float* __restrict__ sim, int ld, int m, int n, float alpha,
+                                                              const float* __restrict__ u, const float* __restrict__ v,
+                                                              float* __restrict__ out) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)(m + 1) * (n + 1);
+    if (t >= total) return;
+    const int i = (int)(t / (n + 1)), j = (int)(t - (long)i * (n + 1));
+    const float z = (i < m && j < n) ? sim[(long)i * ld + j] : alpha;
+    out[t] = ((z + u[i]) + v[j]) - sg_norm(m, n);
+}
+
+}  // namespace im
+
+static int sinkhorn(im_ctx* ctx, hipStream_t s, const float* sim, int ld, const int* m_ptr, const int* n_ptr, int m_max, int n_max,
+                    float alpha, int iters, float* u, float* v, float* norm_out) {
+    Workspace* ws = ctx->ws;
+    IM_HIP(ctx, hipMemsetAsync(u, 0, sizeof(float) * (m_max + 1), s));
+    IM_HIP(ctx, hipMemsetAsync(v, 0, sizeof(float) * (n_max + 1), s));
+    const int nstrips = (m_max + SK_STRIP - 1) / SK_STRIP;
+    const int pstride = n_max + 1;
+    for (int it = 0; it < iters; ++it) {
+        hipLaunchKernelGGL(sinkhorn_row_kernel, dim3((m_max + 1 + 3) / 4), dim3(256), 0, s, sim, ld, m_ptr, n_ptr, alpha, v, u);
+        hipLaunchKernelGGL(sinkhorn_col_partial_kernel, dim3((n_max + 1 + 255) / 256, nstrips), dim3(256), 0, s, sim, ld, m_ptr, n_ptr,
+                           alpha, u, ws->part, pstride);
+        hipLaunchKernelGGL(sinkhorn_col_combine_kernel, dim3((n_max + 1 + 255) / 256), dim3(256), 0, s, ws->part, pstride, m_ptr, n_ptr,
+                           alpha, u, v, norm_out);
+    }
+    if (iters == 0)  // norm is still needed by the assignment
+        hipLaunchKernelGGL(sinkhorn_col_combine_kernel, dim3((n_max + 1 + 255) / 256), dim3(256), 0, s, ws->part, pstride, m_ptr, n_ptr,
+                           alpha, u, v, norm_out);
+    IM_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ weights
+static const std::vector<float>* sg_find(im_ctx* ctx, const std::string& key, size_t numel) {
+    auto it = ctx->host_w.find("superglue/" + key);
+    if (it == ctx->host_w.end()) { ctx->fail(-20, "weights: missing tensor %s of model superglue", key.c_str()); return nullptr; }
+    if (it->second.size() != numel) {
+        ctx->fail(-21, "weights: tensor %s has %zu elements, expected %zu", key.c_str(), it->second.size(), numel);
+        return nullptr;
+    }
+    return &it->second;
+}
+
+// fold eval-mode BatchNorm1d (eps 1e-5) into the preceding 1x1 conv: y = g (Wx + b - mean) / sqrt(var + eps) + beta
+static int fold_bn(im_ctx* ctx, const std::string& bn, int c, int in, std::vector<float>& w, std::vector<float>& b) {
+    const auto* g = sg_find(ctx, bn + ".weight", c);
+    const auto* be = sg_find(ctx, bn + ".bias", c);
+    const auto* mu = sg_find(ctx, bn + ".running_mean", c);
+    const auto* var = sg_find(ctx, bn + ".running_var", c);
+    if (!g || !be || !mu || !var) return -20;
+    for (int o = 0; o < c; ++o) {
+        const float sc = (*g)[o] / std::sqrt((*var)[o] + 1e-5f);
+        for (int i = 0; i < in; ++i) w[(size_t)o * in + i] *= sc;
+        b[o] = (b[o] - (*mu)[o]) * sc + (*be)[o];
+    }
+    return 0;
+}
+
+int finalize_superglue(im_ctx* ctx) {
+    SuperGlueW& W = ctx->sg;
+    static const int dims[6] = {3, 32, 64, 128, 256, 256};
+    for (int l = 0; l < 5; ++l) {
+        const int in = dims[l], out = dims[l + 1], inp = l == 0 ? 32 : in;
+        const std::string key = "kenc.encoder." + std::to_string(3 * l);
+        const auto* w = sg_find(ctx, key + ".weight", (size_t)out * in);
+        const auto* b = sg_find(ctx, key + ".bias", out);
+        if (!w || !b) return -20;
+        std::vector<float> ww(*w), bb(*b);
+        if (l < 4 && fold_bn(ctx, "kenc.encoder." + std::to_string(3 * l + 1), out, in, ww, bb)) return -20;
+        std::vector<float> wp((size_t)out * inp, 0.f);
+        for (int o = 0; o < out; ++o)
+            for (int i = 0; i < in; ++i) wp[(size_t)o * inp + i] = ww[(size_t)o * in + i];
+        W.kenc_w[l] = ctx->upload(wp);
+        W.kenc_b[l] = ctx->upload(bb);
+    }
+    const int L = 18;
+    std::vector<float> qkv_w((size_t)L * 768 * 256), qkv_b((size_t)L * 768), mg_w((size_t)L * 65536), mg_b((size_t)L * 256),
+        m0_w((size_t)L * 512 * 512), m0_b((size_t)L * 512), m3_w((size_t)L * 256 * 512), m3_b((size_t)L * 256);
+    for (int l = 0; l < L; ++l) {
+        const std::string p = "gnn.layers." + std::to_string(l);
+        for (int which = 0; which < 3; ++which) {
+            const auto* w = sg_find(ctx, p + ".attn.proj." + std::to_string(which) + ".weight", 65536);
+            const auto* b = sg_find(ctx, p + ".attn.proj." + std::to_string(which) + ".bias", 256);
+            if (!w || !b) return -20;
+            for (int h = 0; h < 4; ++h)
+                for (int d = 0; d < 64; ++d) {
+                    const int src = d * 4 + h, dst = which * 256 + h * 64 + d;
+                    memcpy(&qkv_w[((size_t)l * 768 + dst) * 256], &(*w)[(size_t)src * 256], 256 * sizeof(float));
+                    qkv_b[(size_t)l * 768 + dst] = (*b)[src];
+                }
+        }
+        const auto* mw = sg_find(ctx, p + ".attn.merge.weight", 65536);
+        const auto* mb = sg_find(ctx, p + ".attn.merge.bias", 256);
+        if (!mw || !mb) return -20;
+        for (int o = 0; o < 256; ++o)
+            for (int h = 0; h < 4; ++h)
+                for (int d = 0; d < 64; ++d) mg_w[((size_t)l * 256 + o) * 256 + h * 64 + d] = (*mw)[(size_t)o * 256 + d * 4 + h];
+        memcpy(&mg_b[(size_t)l * 256], mb->data(), 256 * sizeof(float));
+        const auto* w0 = sg_find(ctx, p + ".mlp.0.weight", 512 * 512);
+        const auto* b0 = sg_find(ctx, p + ".mlp.0.bias", 512);
+        const auto* w3 = sg_find(ctx, p + ".mlp.3.weight", 256 * 512);
+        const auto* b3 = sg_find(ctx, p + ".mlp.3.bias", 256);
+        if (!w0 || !b0 || !w3 || !b3) return -20;
+        std::vector<float> ww(*w0), bb(*b0);
+        if (fold_bn(ctx, p + ".mlp.1", 512, 512, ww, bb)) return -20;
+        memcpy(&m0_w[(size_t)l * 512 * 512], ww.data(), ww.size() * sizeof(float));
+        memcpy(&m0_b[(size_t)l * 512], bb.data(), 512 * sizeof(float));
+        memcpy(&m3_w[(size_t)l * 256 * 512], w3->data(), w3->size() * sizeof(float));
+        memcpy(&m3_b[(size_t)l * 256], b3->data(), 256 * sizeof(float));
+    }
+    W.proj_w = ctx->upload(qkv_w); W.proj_b = ctx->upload(qkv_b);
+    W.merge_w = ctx->upload(mg_w); W.merge_b = ctx->upload(mg_b);
+    W.mlp0_w = ctx->upload(m0_w); W.mlp0_b = ctx->upload(m0_b);
+    W.mlp3_w = ctx->upload(m3_w); W.mlp3_b = ctx->upload(m3_b);
+    const auto* fw = sg_find(ctx, "final_proj.weight", 65536);
+    const auto* fb = sg_find(ctx, "final_proj.bias", 256);
+    const auto* bs = sg_find(ctx, "bin_score", 1);
+    if (!fw || !fb || !bs) return -20;
+    W.fp_w = ctx->upload(*fw); W.fp_b = ctx->upload(*fb);
+    W.bin_score = (*bs)[0];
+    if (!W.proj_w || !W.merge_w || !W.mlp0_w || !W.mlp3_w || !W.fp_w) return ctx->fail(-22, "weights: upload failed");
+    W.ready = true;
+    return 0;
+}
+
+extern "C" {
+
+int im_superglue_forward(im_ctx* ctx, const float* d_kpts, const float* d_scores, const float* d_desc, const int32_t* d_n,
+                         const float* h_shape, const im_superglue_conf* conf, int32_t* d_matches, float* d_mscores,
+                         int32_t* d_info, void* stream) {
+    IM_CHECK_CTX(ctx);
+    if (!ctx->sg.ready) return ctx->fail(-50, "im_superglue_forward: weights not finalized");
+    Workspace* ws = ctx->ws;
+    if (!ws) return ctx->fail(-51, "im_superglue_forward: call im_ctx_reserve first");
+    hipStream_t s = (hipStream_t)stream;
+    const SuperGlueW& W = ctx->sg;
+    const int K = ctx->max_kpts, L = conf->n_layers;
+    if (L < 0 || L > 18) return ctx->fail(-52, "im_superglue_forward: n_layers must be 0..18");
+    const long xb = (long)K * 256;
+    LGState* st = ws->st;
+    IM_HIP(ctx, launch_lg_init(st, d_n, ws->ind[0], ws->prune, K, K, d_matches, d_mscores, K, s));
+    float* x = ws->x[0];
+    GemmArgs base;
+    base.m_max = K; base.m_ptr = st->n; base.batch = 2;
+    {   // keypoint encoder; the last layer adds the visual descriptors: x = desc + kenc(kpts, scores) (`superglue.py:269-270`)
+        float* inp = ws->h;  // [2][K][32]
+        const float4 shapes = make_float4(h_shape[0], h_shape[1], h_shape[2], h_shape[3]);
+        hipLaunchKernelGGL(sg_kenc_input_kernel, dim3((K * 32 + 255) / 256, 2), dim3(256), 0, s, d_kpts, d_scores, K, st, shapes, inp);
+        static const int dims[6] = {32, 32, 64, 128, 256, 256};
+        const float* src = inp;
+        float* bufs[2] = {ws->msg, ws->att};
+        for (int l = 0; l < 5; ++l) {
+            GemmArgs g = base;
+            g.A = src; g.a_bstride = (long)K * dims[l]; g.lda = dims[l];
+            g.W = W.kenc_w[l]; g.ldw = dims[l]; g.bias = W.kenc_b[l]; g.N = dims[l + 1]; g.K = dims[l];
+            if (l < 4) {
+                g.C = bufs[l & 1]; g.c_bstride = (long)K * dims[l + 1]; g.ldc = dims[l + 1]; g.epi = EPI_BIAS_RELU;
+            } else {
+                g.C = x; g.c_bstride = xb; g.ldc = 256; g.R = d_desc; g.r_bstride = xb; g.ldr = 256; g.epi = EPI_BIAS_RESID;
+            }
+            IM_LAUNCH(ctx, "sg_kenc_gemm", s, launch_gemm(g, s));
+            src = bufs[l & 1];
+        }
+    }
+    for (int l = 0; l < L; ++l) {
+        const bool cross = (l & 1) != 0;  // ['self', 'cross'] * 9 (`superglue.py:215`)
+        {
+            GemmArgs g = base;
+            g.A = x; g.a_bstride = xb; g.lda = 256; g.W = W.proj_w + (long)l * 768 * 256; g.ldw = 256;
+            g.bias = W.proj_b + (long)l * 768; g.N = 768; g.K = 256; g.epi = EPI_QKV_ROPE;  // no rotary tables => plain q/k/v
+            g.q = ws->q; g.k = ws->k; g.v = ws->v; g.head_bstride = (long)K * 256; g.head_stride = (long)K * 64;
+            IM_LAUNCH(ctx, "sg_qkv_gemm", s, launch_gemm(g, s));
+        }
+        {
+            AttnArgs at;
+            at.q = ws->q; at.k = ws->k; at.v = ws->v; at.hstride = (long)K * 64; at.bstride = (long)K * 256;
+            at.out = ws->att; at.out_bstride = xb; at.ldo = 256; at.n_ptr = st->n; at.n_max = K; at.batch = 2; at.heads = 4;
+            at.cross = cross ? 1 : 0; at.scale = 0.125f;  // / dim ** .5, dim = 64 (`superglue.py:91`)
+            IM_LAUNCH(ctx, cross ? "flash_attn_cross" : "flash_attn_self", s, launch_flash_attn(at, s));
+        }
+        {
+            GemmArgs g = base;
+            g.A = ws->att; g.a_bstride = xb; g.lda = 256; g.W = W.merge_w + (long)l * 65536; g.ldw = 256;
+            g.bias = W.merge_b + (long)l * 256; g.N = 256; g.K = 256; g.C = ws->msg; g.c_bstride = xb; g.ldc = 256; g.epi = EPI_BIAS;
+            IM_LAUNCH(ctx, "sg_merge_gemm", s, launch_gemm(g, s));
+        }
+        {
+            GemmArgs g = base;
+            g.A = x; g.a_bstride = xb; g.lda = 256; g.A1 = ws->msg; g.a1_bstride = xb; g.lda1 = 256; g.ksplit = 256;
+            g.W = W.mlp0_w + (long)l * 512 * 512; g.ldw = 512; g.bias = W.mlp0_b + (long)l * 512; g.N = 512; g.K = 512;
+            g.C = ws->h; g.c_bstride = (long)K * 512; g.ldc = 512; g.epi = EPI_BIAS_RELU;
+            IM_LAUNCH(ctx, "sg_mlp0_gemm", s, launch_gemm(g, s));
+        }
+        {
+            GemmArgs g = base;
+            g.A = ws->h; g.a_bstride = (long)K * 512; g.lda = 512; g.W = W.mlp3_w + (long)l * 256 * 512; g.ldw = 512;
+            g.bias = W.mlp3_b + (long)l * 256; g.N = 256; g.K = 512;
+            g.C = x; g.c_bstride = xb; g.ldc = 256; g.R = x; g.r_bstride = xb; g.ldr = 256; g.epi = EPI_BIAS_RESID;
+            IM_LAUNCH(ctx, "sg_mlp3_gemm", s, launch_gemm(g, s));
+        }
+    }
+    {
+        GemmArgs g = base;
+        g.A = x; g.a_bstride = xb; g.lda = 256; g.W = W.fp_w; g.ldw = 256; g.bias = W.fp_b; g.N = 256; g.K = 256;
+        g.C = ws->md; g.c_bstride = xb; g.ldc = 256; g.epi = EPI_BIAS;
+        IM_LAUNCH(ctx, "sg_proj_gemm", s, launch_gemm(g, s));
+        GemmArgs sgm;
+        sgm.m_max = K; sgm.m_ptr = &st->n[0]; sgm.n_ptr = &st->n[1]; sgm.batch = 1;
+        sgm.A = ws->md; sgm.lda = 256; sgm.W = ws->md + xb; sgm.ldw = 256; sgm.N = K; sgm.K = 256;
+        sgm.C = ws->sim; sgm.ldc = K; sgm.alpha = 0.0625f;  // / 256 ** .5 (`superglue.py:280`)
+        sgm.epi = EPI_BIAS; sgm.big_tile = 1;
+        IM_LAUNCH(ctx, "score_gemm", s, launch_gemm(sgm, s));
+    }
+    float* u = ws->uv;
+    float* v = ws->uv + (K + 1);
+    float* norm = ws->uv + 2 * (K + 1);
+    if (ctx->prof_on) {
+        im_ctx::ProfEntry pe{"sinkhorn", ctx->prof_event(), ctx->prof_event()};
+        hipEventRecord(pe.e0, s);
+        int rc = sinkhorn(ctx, s, ws->sim, K, &st->n[0], &st->n[1], K, K, W.bin_score, conf->sinkhorn_iterations, u, v, norm);
+        hipEventRecord(pe.e1, s);
+        ctx->prof.push_back(pe);
+        if (rc) return rc;
+    } else {
+        int rc = sinkhorn(ctx, s, ws->sim, K, &st->n[0], &st->n[1], K, K, W.bin_score, conf->sinkhorn_iterations, u, v, norm);
+        if (rc) return rc;
+    }
+    AssignArgs a;
+    a.mode = 1;
+    a.sim = ws->sim; a.ld = K; a.m_ptr = &st->n[0]; a.n_ptr = &st->n[1]; a.m_max = K; a.n_max = K;
+    a.rmax = u; a.cmax = v; a.rlog = norm; a.clog = ws->clog; a.part = ws->part;
+    a.ridx = ws->ridx; a.rval = ws->rval; a.cbest = ws->cbest; a.threshold = (float)conf->match_threshold;
+    a.out_m0 = d_matches; a.out_m1 = d_matches + K; a.out_s0 = d_mscores; a.out_s1 = d_mscores + K;
+    IM_LAUNCH(ctx, "assign", s, launch_assign(a, s));
+    IM_HIP(ctx, launch_lg_select_layer(st, 0, ws->sel, d_info, s));
+    return 0;
+}
+
+int im_log_optimal_transport(im_ctx* ctx, const float* d_scores, int m, int n, int ld, float bin_score, int iters, float* d_out,
+                             void* stream) {
+    IM_CHECK_CTX(ctx);
+    Workspace* ws = ctx->ws;
+    const int K = ctx->max_kpts;
+    if (!ws || m > K || n > K || m < 1 || n < 1) return ctx->fail(-41, "im_log_optimal_transport: m, n must be 1..max_kpts");
+    hipStream_t s = (hipStream_t)stream;
+    const int mn[2] = {m, n};
+    IM_HIP(ctx, hipMemcpyAsync(ws->st->n, mn, sizeof(mn), hipMemcpyHostToDevice, s));
+    IM_HIP(ctx, hipStreamSynchronize(s));
+    float* u = ws->uv;
+    float* v = ws->uv + (K + 1);
+    float* norm = ws->uv + 2 * (K + 1);
+    int rc = sinkhorn(ctx, s, d_scores, ld, &ws->st->n[0], &ws->st->n[1], m, n, bin_score, iters, u, v, norm);
+    if (rc) return rc;
+    const long total = (long)(m + 1) * (n + 1);
+    hipLaunchKernelGGL(ot_materialize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d_scores, ld, m, n, bin_score, u, v, d_out);
+    IM_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

@@ -48,9 +48,11 @@ class Engine:
 
     # ------------------------------------------------------------------ workspace
     def reserve(self, max_h: int, max_w: int, max_images: int = 2, max_kpts: int = 4096) -> None:
-        if (max_h <= self.max_h and max_w <= self.max_w and max_images <= self.max_images and max_kpts == self.max_kpts):
+        """Grow-only: buffers keep the largest sizes seen (row strides are the reserved max_kpts)."""
+        if (max_h <= self.max_h and max_w <= self.max_w and max_images <= self.max_images and max_kpts <= self.max_kpts):
             return
         max_h, max_w, max_images = max(max_h, self.max_h), max(max_w, self.max_w), max(max_images, self.max_images)
+        max_kpts = max(max_kpts, self.max_kpts)
         self.ctx.call("im_ctx_reserve", max_h, max_w, max_images, max_kpts)
         self.max_h, self.max_w, self.max_images, self.max_kpts = max_h, max_w, max_images, max_kpts
         K, B = max_kpts, max_images

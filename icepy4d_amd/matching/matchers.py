@@ -1,0 +1,437 @@
+"""Matcher plugin API of the reference (`src/icepy4d/matching/matchers.py`), host side, bound to libicematch.
+
+Same class / method names, arguments and result properties as the reference:
+`FeaturesBase` (`:44-48`), `ImageMatcherBase.match` (`:139-261`), the plugin hook
+`_match_images(image0, image1, **config) -> (FeaturesBase, FeaturesBase, matches0, mconf)` (`:276-302`),
+`_match_by_tile` (`:304-469`), `_tile_selection` (`:471-581`), `LightGlueMatcher` (`:1202-1342`),
+`SuperGlueMatcher` (`:826-940`). What differs is only where the arithmetic runs: `_match_images` enqueues the
+SuperPoint + LightGlue / SuperGlue kernels of libicematch on the MI355X (no torch modules, no CPU fallback) and
+copies the results back once.
+
+Observable quirks of the reference are kept where downstream code can depend on them (q1: LightGlueMatcher with
+TileSelection.NONE stores the *unfiltered* keypoints; q4: tiles lose their last row/column; q5: `mconf` of
+SuperGlue / tile modes is the keypoint score; q6: tile matches are re-ordered by `np.unique`), and fixed where
+they are plain bugs that cannot be relied on (q2: `min_matches_per_tile` is honoured; q7: no bare `except`;
+q9: no Tk import). Weights: the reference downloads / reads `.pth` files at construction; here a state dict (official
+key names) is passed through `opt["state_dicts"]` or `opt["weights_dir"]`.
+"""
+from __future__ import annotations
+
+import logging
+import os
+from copy import deepcopy
+from dataclasses import dataclass
+from itertools import product
+from pathlib import Path
+from typing import Dict, List, Optional, Tuple, Union
+
+import numpy as np
+import torch
+
+from ..utils import AverageTimer, timeit
+from .enums import GeometricVerification, Quality, TileSelection
+from .geometric_verification import geometric_verification
+from .pyramid import pyr_down, pyr_up
+from .tiling import Tiler
+
+logger = logging.getLogger(__name__)
+
+MIN_MATCHES_PER_TILE = 5
+
+_ENGINES: Dict[int, "object"] = {}
+
+
+def get_engine(device: int = 0):
+    """One engine (context + workspace) per device and process, shared by all matcher objects."""
+    from ..engine import Engine
+    if device not in _ENGINES:
+        _ENGINES[device] = Engine(device)
+    return _ENGINES[device]
+
+
+def check_dict_keys(dict: dict, keys: List[str]):
+    missing_keys = [key for key in keys if key not in dict]
+    if missing_keys:
+        raise KeyError(f"Missing required keys: {', '.join(missing_keys)} Matcher option dictionary")
+
+
+@dataclass
+class FeaturesBase:
+    keypoints: np.ndarray
+    descriptors: np.ndarray = None
+    scores: np.ndarray = None
+
+
+def _to_gray_u8(image: np.ndarray, flavour: str) -> np.ndarray:
+    """The kernels take gray uint8. 3-channel input: LightGlue flavour = kornia weights on the scaled float image
+    (`lightglue/utils.py:35-36`), SuperGlue flavour = cv2.cvtColor(RGB2GRAY) on uint8 (`matchers.py:911-914`).
+    Both are un-vendored: the result is rounded to uint8 here, so colour input is parity-unpinned;
+    gray input is the pinned path."""
+    if image.ndim == 2:
+        return np.ascontiguousarray(image)
+    if image.ndim != 3 or image.shape[2] != 3:
+        raise ValueError(f"Not an image: {image.shape}")
+    f = image.astype(np.float32)
+    g = (0.299 * f[..., 0] + 0.587 * f[..., 1]) + 0.114 * f[..., 2]
+    return np.clip(np.rint(g), 0, 255).astype(np.uint8)
+
+
+def _load_state_dict(opt: dict, model: str, filenames: List[str]) -> Dict[str, torch.Tensor]:
+    sds = opt.get("state_dicts") or {}
+    if model in sds:
+        return sds[model]
+    wdir = opt.get("weights_dir") or os.environ.get("ICEPY4D_AMD_WEIGHTS")
+    if wdir:
+        for fn in filenames:
+            p = Path(wdir) / fn
+            if p.exists():
+                return torch.load(str(p), map_location="cpu")
+    raise FileNotFoundError(
+        f"No weights for '{model}': pass opt['state_dicts']['{model}'] (official key names) or opt['weights_dir'] "
+        f"containing one of {filenames}. (The reference downloads them; this build has no network access.)")
+
+
+class ImageMatcherBase:
+    def __init__(self, opt: dict = {}) -> None:
+        """Base class for matchers: `match()` and everything shared; subclasses implement `_match_images`.
+
+        Raises:
+            TypeError: If `opt` is not a dictionary.
+        """
+        if not isinstance(opt, dict):
+            raise TypeError("opt must be a dictionary")
+        self._opt = dict(opt)
+        if opt.get("force_cpu"):
+            logger.warning("force_cpu is ignored: the MI355X build has no CPU path")
+        self._device_index = int(opt.get("device", 0))
+        self._device = f"cuda:{self._device_index}"
+        self._engine = None
+        self.reset()
+
+    @property
+    def engine(self):
+        if self._engine is None:
+            self._engine = get_engine(self._device_index)
+        return self._engine
+
+    def reset(self):
+        """Reset the matcher by clearing the features and matches"""
+        self._mkpts0 = None
+        self._mkpts1 = None
+        self._descriptors0 = None
+        self._descriptors1 = None
+        self._scores0 = None
+        self._scores1 = None
+        self._mconf = None
+
+    device = property(lambda self: self._device)
+    mkpts0 = property(lambda self: self._mkpts0)
+    mkpts1 = property(lambda self: self._mkpts1)
+    descriptors0 = property(lambda self: self._descriptors0)
+    descriptors1 = property(lambda self: self._descriptors1)
+    scores0 = property(lambda self: self._scores0)
+    scores1 = property(lambda self: self._scores1)
+    mconf = property(lambda self: self._mconf)
+
+    @timeit
+    def match(self, image0: np.ndarray, image1: np.ndarray, quality: Quality = Quality.HIGH,
+              tile_selection: TileSelection = TileSelection.NONE, **config) -> bool:
+        """Matches images and performs geometric verification (`matchers.py:139-261`)."""
+        self.timer = AverageTimer()
+        gv_method = config.get("geometric_verification", GeometricVerification.PYDEGENSAC)
+        threshold = config.get("threshold", 1)
+        confidence = config.get("confidence", 0.9999)
+        save_dir = config.get("save_dir", None)
+        self._save_dir = Path(save_dir) if save_dir is not None else None
+        if self._save_dir is not None:
+            self._save_dir.mkdir(parents=True, exist_ok=True)
+
+        image0_, image1_ = self._resize_images(quality, image0, image1)
+        if tile_selection == TileSelection.NONE:
+            logger.info("Matching full images...")
+            features0, features1, matches0, mconf = self._match_images(image0_, image1_, **config)
+        else:
+            logger.info("Matching by tiles...")
+            features0, features1, matches0, mconf = self._match_by_tile(image0_, image1_, tile_selection, **config)
+        features0, features1 = self._resize_features(quality, features0, features1)
+        try:
+            self._store_features(features0, features1, matches0)
+            self._mconf = mconf
+        except Exception as e:  # same behaviour as the reference: log and go on (`matchers.py:199-207`)
+            logger.error(f"Error storing matches: {e}. Implement your own _store_features() method if the "
+                         f"output of your matcher is different from FeaturesBase.")
+        self.timer.update("matching")
+        logger.info("Matching done!")
+
+        if gv_method is not GeometricVerification.NONE and len(self._mkpts0) != len(self._mkpts1):
+            # q1: LightGlueMatcher + TileSelection.NONE stores unpaired keypoint sets; the reference's verification
+            # then fails inside pydegensac / cv2 and keeps everything (`geometric_verification.py:79-100`)
+            logger.error("Geometric verification skipped: keypoint sets are not paired (use a tile mode)")
+        elif gv_method is not GeometricVerification.NONE:
+            F, inl = geometric_verification(self._mkpts0, self._mkpts1, method=gv_method, confidence=confidence,
+                                            threshold=threshold)
+            self._F = F
+            self._filter_matches_by_mask(inl)
+            self.timer.update("geometric_verification")
+        if self._save_dir is not None:
+            self.save_mkpts_as_txt(self._save_dir)
+        self.timer.print("Matching")
+        return True
+
+    def _match_images(self, image0: np.ndarray, image1: np.ndarray, **config
+                      ) -> Tuple[FeaturesBase, FeaturesBase, np.ndarray, np.ndarray]:
+        raise NotImplementedError("Subclasses must implement _match_full_images() method.")
+
+    def _match_by_tile(self, image0: np.ndarray, image1: np.ndarray,
+                       tile_selection: TileSelection = TileSelection.PRESELECTION, **config
+                       ) -> Tuple[FeaturesBase, FeaturesBase, np.ndarray, np.ndarray]:
+        """Tile loop (`matchers.py:304-469`): match every selected tile pair, keep the valid matches, shift them by
+        the tile origin, concatenate, `np.unique` on the image-0 points, return 1-to-1 matches."""
+        assert isinstance(image0, np.ndarray), "image0 must be a NumPy array"
+        assert isinstance(image1, np.ndarray), "image1 must be a NumPy array"
+        grid = config.get("grid", [1, 1])
+        overlap = config.get("overlap", 0)
+        origin = config.get("origin", [0, 0])
+        self._tiler = Tiler(grid=grid, overlap=overlap, origin=origin)
+        t0_lims, t0_origin = self._tiler.compute_limits_by_grid(image0)
+        t1_lims, t1_origin = self._tiler.compute_limits_by_grid(image1)
+        tile_pairs = self._tile_selection(image0, image1, t0_lims, t1_lims, tile_selection, **config)
+
+        mk0, mk1 = [np.zeros((0, 2), np.float32)], [np.zeros((0, 2), np.float32)]
+        d0, d1 = [np.zeros((256, 0), np.float32)], [np.zeros((256, 0), np.float32)]
+        s0, s1 = [np.zeros(0, np.float32)], [np.zeros(0, np.float32)]
+        for tidx0, tidx1 in tile_pairs:
+            logger.info(f" - Matching tile pair ({tidx0}, {tidx1})")
+            lim0, lim1 = t0_lims[tidx0], t1_lims[tidx1]
+            tile0 = self._tiler.extract_patch(image0, lim0)
+            tile1 = self._tiler.extract_patch(image1, lim1)
+            f0, f1, matches0, _ = self._match_images(tile0, tile1, **config)
+            valid = matches0 > -1
+            idx1 = matches0[valid]
+            mk0.append(f0.keypoints[valid] + np.array(lim0[0:2]).astype("float32"))
+            mk1.append(f1.keypoints[idx1] + np.array(lim1[0:2]).astype("float32"))
+            d0.append(f0.descriptors[:, valid])
+            d1.append(f1.descriptors[:, idx1])
+            s0.append(f0.scores[valid])
+            s1.append(f1.scores[idx1])
+        mk0 = np.vstack(mk0) + np.array(t0_origin).astype("float32")
+        mk1 = np.vstack(mk1) + np.array(t1_origin).astype("float32")
+        d0, d1, s0, s1 = np.hstack(d0), np.hstack(d1), np.concatenate(s0), np.concatenate(s1)
+        mk0, uniq = np.unique(mk0, axis=0, return_index=True)  # q6: lexicographic re-ordering
+        features0 = FeaturesBase(keypoints=mk0, descriptors=d0[:, uniq], scores=s0[uniq])
+        features1 = FeaturesBase(keypoints=mk1[uniq], descriptors=d1[:, uniq], scores=s1[uniq])
+        matches0 = np.arange(mk0.shape[0])
+        mconf = features0.scores[matches0 > -1]  # q5: keypoint scores, not match confidences
+        logger.info("Matching by tile completed.")
+        return features0, features1, matches0, mconf
+
+    def _tile_selection(self, image0: np.ndarray, image1: np.ndarray, t0_lims: Dict[int, tuple],
+                        t1_lims: Dict[int, tuple], method: TileSelection = TileSelection.PRESELECTION, **config
+                        ) -> List[Tuple[int, int]]:
+        """Tile pairs to match (`matchers.py:471-581`)."""
+        def points_in_rect(points: np.ndarray, rect) -> np.ndarray:
+            rect = np.asarray(rect)
+            return np.all(points > rect[:2], axis=1) & np.all(points < rect[2:], axis=1)
+
+        min_matches_per_tile = config.get("min_matches_per_tile", MIN_MATCHES_PER_TILE)
+        if method == TileSelection.EXHAUSTIVE:
+            return sorted(product(t0_lims.keys(), t1_lims.keys()))
+        if method == TileSelection.GRID:
+            return sorted(zip(t0_lims.keys(), t1_lims.keys()))
+        if method == TileSelection.PRESELECTION:
+            # pyramid depth by image height (`matchers.py:516-523`; the >8000 branch is dead in the reference: q3)
+            if image0.shape[0] > 4000:
+                n_down = 3
+            elif image0.shape[0] > 2000:
+                n_down = 2
+            else:
+                n_down = 1
+            i0, i1 = deepcopy(image0), deepcopy(image1)
+            for _ in range(n_down):
+                i0, i1 = pyr_down(i0), pyr_down(i1)
+            f0, f1, mtc, _ = self._match_images(i0, i1, max_keypoints=4096)
+            vld = mtc > -1
+            kp0 = f0.keypoints[vld] * (2 ** n_down)
+            kp1 = f1.keypoints[mtc[vld]] * (2 ** n_down)
+            pairs = []
+            for tidx0, tidx1 in sorted(product(t0_lims.keys(), t1_lims.keys())):
+                ret = points_in_rect(kp0, t0_lims[tidx0]) & points_in_rect(kp1, t1_lims[tidx1])
+                if int(ret.sum()) > min_matches_per_tile:
+                    pairs.append((tidx0, tidx1))
+            self.timer.update("preselection")
+            return pairs
+        raise ValueError(f"unknown tile selection {method}")
+
+    def _resize_images(self, quality: Quality, image0: np.ndarray, image1: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+        """`matchers.py:583-610`: HIGHEST = pyrUp, HIGH = identity, MEDIUM = pyrDown, LOW = pyrDown twice."""
+        if quality == Quality.HIGHEST:
+            return pyr_up(image0), pyr_up(image1)
+        if quality == Quality.HIGH:
+            return image0, image1
+        if quality == Quality.MEDIUM:
+            return pyr_down(image0), pyr_down(image1)
+        if quality == Quality.LOW:
+            return pyr_down(pyr_down(image0)), pyr_down(pyr_down(image1))
+        raise ValueError(f"unknown quality {quality}")
+
+    def _resize_features(self, quality: Quality, features0: FeaturesBase, features1: FeaturesBase):
+        """`matchers.py:612-639`."""
+        f = {Quality.HIGHEST: 0.5, Quality.HIGH: 1.0, Quality.MEDIUM: 2.0, Quality.LOW: 4.0}[quality]
+        if f != 1.0:
+            features0.keypoints = features0.keypoints * np.float32(f)
+            features1.keypoints = features1.keypoints * np.float32(f)
+        return features0, features1
+
+    def _store_features(self, features0: FeaturesBase, features1: FeaturesBase, matches0: np.ndarray,
+                        force_overwrite: bool = True) -> bool:
+        """Stores keypoints, descriptors and scores of the matches (`matchers.py:641-680`)."""
+        assert isinstance(features0, FeaturesBase), "features0 must be a FeaturesBase object"
+        assert isinstance(features1, FeaturesBase), "features1 must be a FeaturesBase object"
+        if self._mkpts0 is not None and self._mkpts1 is not None and force_overwrite is False:
+            logger.warning("Matches already stored. Not overwriting them. Use force_overwrite=True to force overwrite them.")
+            return False
+        valid = matches0 > -1
+        self._valid = valid
+        idx1 = matches0[valid]
+        self._mkpts0 = features0.keypoints[valid]
+        self._mkpts1 = features1.keypoints[idx1]
+        if features0.descriptors is not None:
+            self._descriptors0 = features0.descriptors[:, valid]
+            self._descriptors1 = features1.descriptors[:, idx1]
+        if features0.scores is not None:
+            self._scores0 = features0.scores[valid]
+            self._scores1 = features1.scores[idx1]
+        return True
+
+    def _filter_matches_by_mask(self, inlMask: np.ndarray) -> None:
+        """`matchers.py:682-700`."""
+        self._mkpts0 = self._mkpts0[inlMask, :]
+        self._mkpts1 = self._mkpts1[inlMask, :]
+        if self._descriptors0 is not None:
+            self._descriptors0 = self._descriptors0[:, inlMask]
+        if self._descriptors1 is not None:
+            self._descriptors1 = self._descriptors1[:, inlMask]
+        if self._scores0 is not None:
+            self._scores0 = self._scores0[inlMask]
+        if self._scores1 is not None:
+            self._scores1 = self._scores1[inlMask]
+        if self._mconf is not None and len(self._mconf) == len(inlMask):
+            self._mconf = self._mconf[inlMask]
+
+    def save_mkpts_as_txt(self, savedir: Union[str, Path], delimiter: str = ",", header: str = "x,y") -> None:
+        """Save keypoints in a .txt file (`matchers.py:802-824`)."""
+        path = Path(savedir)
+        path.mkdir(parents=True, exist_ok=True)
+        np.savetxt(path / "keypoints_0.txt", self.mkpts0, delimiter=delimiter, newline="\n", header=header)
+        np.savetxt(path / "keypoints_1.txt", self.mkpts1, delimiter=delimiter, newline="\n", header=header)
+
+    # ------------------------------------------------------------------ shared device plumbing
+    def _upload_pair(self, g0: np.ndarray, g1: np.ndarray) -> List[torch.Tensor]:
+        dev = self.engine.device
+        if g0.shape == g1.shape:
+            return [torch.from_numpy(np.stack([g0, g1])).to(dev)]
+        return [torch.from_numpy(g0[None].copy()).to(dev), torch.from_numpy(g1[None].copy()).to(dev)]
+
+
+class SuperGlueMatcher(ImageMatcherBase):
+    def __init__(self, opt: dict) -> None:
+        """Options as in the reference (`matchers.py:829-890`): 'weights', 'keypoint_threshold', 'max_keypoints',
+        'match_threshold', 'force_cpu' (+ 'nms_radius', 'sinkhorn_iterations')."""
+        if not isinstance(opt, dict):
+            raise TypeError("opt must be a dictionary")
+        cfg = self._build_superglue_config(opt)
+        super().__init__({**opt, **cfg})
+        self._cfg = cfg
+        eng = self.engine
+        eng.load_state_dict("superpoint", _load_state_dict(opt, "superpoint", ["superpoint_v1.pth"]))
+        eng.load_state_dict("superglue", _load_state_dict(opt, "superglue", [f"superglue_{cfg['superglue']['weights']}.pth"]))
+
+    def _build_superglue_config(self, opt: dict) -> dict:
+        def_opt = {"weights": "outdoor", "keypoint_threshold": 0.001, "max_keypoints": -1, "match_threshold": 0.3,
+                   "force_cpu": False, "nms_radius": 3, "sinkhorn_iterations": 20}
+        opt = {**def_opt, **opt}
+        check_dict_keys(opt, ["weights", "keypoint_threshold", "max_keypoints", "match_threshold", "force_cpu"])
+        return {"superpoint": {"nms_radius": opt["nms_radius"], "keypoint_threshold": opt["keypoint_threshold"],
+                               "max_keypoints": opt["max_keypoints"]},
+                "superglue": {"weights": opt["weights"], "sinkhorn_iterations": opt["sinkhorn_iterations"],
+                              "match_threshold": opt["match_threshold"]},
+                "force_cpu": opt["force_cpu"]}
+
+    def _match_images(self, image0: np.ndarray, image1: np.ndarray, **config):
+        """`SuperGlueMatcher._match_images` (`matchers.py:892-940`) on the GPU."""
+        g0, g1 = _to_gray_u8(image0, "superglue"), _to_gray_u8(image1, "superglue")
+        sp, sg = self._cfg["superpoint"], self._cfg["superglue"]
+        eng = self.engine
+        unlimited = sp["max_keypoints"] < 0
+        cap = int(self._opt.get("max_keypoints_cap", 16384)) if unlimited else int(sp["max_keypoints"])
+        eng.reserve(max(g0.shape[0], g1.shape[0]), max(g0.shape[1], g1.shape[1]), 2, max(cap, 1))
+        ups = self._upload_pair(g0, g1)
+        if len(ups) == 1:
+            eng.superpoint(ups[0], sp["nms_radius"], sp["keypoint_threshold"], 4, cap, flavour=1)
+        else:
+            raise NotImplementedError("image0 and image1 of different size are matched tile by tile in icepy4d; "
+                                      "both images of a pair must have the same shape")
+        eng.superglue(g0.shape, g1.shape, sg["sinkhorn_iterations"], sg["match_threshold"])
+        torch.cuda.synchronize()
+        k0, d0, s0 = eng.features_to_host(0)
+        k1, d1, s1 = eng.features_to_host(1)
+        out = eng.matches_to_host(len(k0), len(k1))
+        features0 = FeaturesBase(keypoints=k0, descriptors=np.ascontiguousarray(d0.T), scores=s0)
+        features1 = FeaturesBase(keypoints=k1, descriptors=np.ascontiguousarray(d1.T), scores=s1)
+        matches0 = out["matches0"]
+        mconf = features0.scores[matches0 > -1]  # q5 (`matchers.py:936-938`)
+        return features0, features1, matches0, mconf
+
+
+class LightGlueMatcher(ImageMatcherBase):
+    def __init__(self, opt: dict = {}) -> None:
+        """SuperPoint + LightGlue (`matchers.py:1205-1209`). The reference rebuilds both models and reloads their
+        weights inside every `_match_images` call (`:1256-1258`); here they are uploaded once."""
+        self._localfeatures = opt.get("features", "superpoint")
+        if self._localfeatures != "superpoint":
+            raise ValueError("only features='superpoint' is supported (DISK is outside the hot-path scope)")
+        super().__init__(opt)
+        eng = self.engine
+        eng.load_state_dict("superpoint", _load_state_dict(opt, "superpoint", ["superpoint_v1.pth"]))
+        eng.load_state_dict("lightglue", _load_state_dict(opt, "lightglue", ["superpoint_lightglue.pth",
+                                                                              "superpoint_lightglue_v0-1_arxiv-pth"]))
+        self._lg_conf = {k: opt[k] for k in ("depth_confidence", "width_confidence", "filter_threshold") if k in opt}
+
+    def _match_images(self, image0: np.ndarray, image1: np.ndarray, **config):
+        """`LightGlueMatcher._match_images` (`matchers.py:1226-1304`) on the GPU: returns
+        (FeaturesBase, FeaturesBase, matches0 [K] int64, mconf [S] = scores of the valid matches)."""
+        max_keypoints = config.get("max_keypoints", 10240)
+        if config.get("resize", None) is not None:
+            raise NotImplementedError("resize is not supported: icepy4d always calls extract(resize=None)")
+        g0, g1 = _to_gray_u8(image0, "lightglue"), _to_gray_u8(image1, "lightglue")
+        if g0.shape != g1.shape:
+            raise NotImplementedError("both images of a pair must have the same shape")
+        eng = self.engine
+        eng.reserve(g0.shape[0], g0.shape[1], 2, int(max_keypoints))
+        pair = self._upload_pair(g0, g1)[0]
+        eng.superpoint(pair, 4, 0.0005, 4, int(max_keypoints), flavour=0)
+        eng.lightglue((g0.shape[1], g0.shape[0]), (g1.shape[1], g1.shape[0]), **self._lg_conf)
+        torch.cuda.synchronize()
+        k0, d0, s0 = eng.features_to_host(0)
+        k1, d1, s1 = eng.features_to_host(1)
+        out = eng.matches_to_host(len(k0), len(k1))
+        features0 = FeaturesBase(keypoints=k0, descriptors=np.ascontiguousarray(d0.T), scores=s0)
+        features1 = FeaturesBase(keypoints=k1, descriptors=np.ascontiguousarray(d1.T), scores=s1)
+        matches0 = out["matches0"]
+        mconf = out["matching_scores0"][matches0 > -1]
+        self._last = out
+        return features0, features1, matches0, mconf
+
+    def _store_features(self, features0: FeaturesBase, features1: FeaturesBase, matches0: np.ndarray,
+                        force_overwrite: bool = True) -> bool:
+        """q1 (`matchers.py:1306-1342`): the LightGlue override ignores `matches0` and stores ALL keypoints."""
+        assert isinstance(features0, FeaturesBase), "features0 must be a FeaturesBase object"
+        assert isinstance(features1, FeaturesBase), "features1 must be a FeaturesBase object"
+        if self._mkpts0 is not None and self._mkpts1 is not None and force_overwrite is False:
+            return False
+        self._mkpts0, self._mkpts1 = features0.keypoints, features1.keypoints
+        if features0.descriptors is not None:
+            self._descriptors0, self._descriptors1 = features0.descriptors, features1.descriptors
+        if features0.scores is not None:
+            self._scores0, self._scores1 = features0.scores, features1.scores
+        return True

@@ -203,3 +203,107 @@ def test_assign_from_sim_exact(lg_eng):
     assert (ds0.cpu() - s0[0]).abs().max().item() < 1e-5
     assert (ds1.cpu() - s1[0]).abs().max().item() < 1e-5
     assert int((r0[0] > -1).sum()) > 20
+
+
+# ------------------------------------------------------------------------------------------- SuperGlue
+@pytest.mark.parametrize("ci", range(3))
+def test_superglue_golden(lg_eng, ci):
+    g = load_golden(f"g3_superglue_{ci}")
+    e = lg_eng
+    e.load_state_dict("superglue", synthetic.superglue_state_dict(0, str(g["variant"])))
+    f = synthetic.synthetic_features(int(g["seed"]), int(g["m"]), int(g["n"]))
+    m, n = int(g["m"]), int(g["n"])
+    e.kpts.zero_(); e.desc.zero_(); e.scores.zero_()
+    e.kpts[0, :m] = torch.from_numpy(f["kpts0"]).cuda(); e.kpts[1, :n] = torch.from_numpy(f["kpts1"]).cuda()
+    e.desc[0, :m] = torch.from_numpy(f["desc0"]).cuda(); e.desc[1, :n] = torch.from_numpy(f["desc1"]).cuda()
+    e.scores[0, :m] = torch.from_numpy(f["scores0"]).cuda(); e.scores[1, :n] = torch.from_numpy(f["scores1"]).cuda()
+    e.n[:] = torch.tensor([m, n], dtype=torch.int32)
+    e.superglue((480, 640), (480, 640), sinkhorn_iterations=int(g["iters"]), match_threshold=0.3)
+    torch.cuda.synchronize()
+    out = e.matches_to_host(m, n)
+    assert np.array_equal(out["matches0"], g["matches0"])
+    assert np.array_equal(out["matches1"], g["matches1"])
+    assert np.abs(out["matching_scores0"] - g["matching_scores0"]).max() < 1e-4
+    assert np.abs(out["matching_scores1"] - g["matching_scores1"]).max() < 1e-4
+
+
+@pytest.mark.parametrize("ci", range(3))
+def test_log_optimal_transport(lg_eng, ci):
+    from icepy4d_amd._lib import stream_ptr
+    g = load_golden(f"g3_superglue_{ci}")
+    zin = torch.from_numpy(g["ot_in"]).cuda().contiguous()
+    m, n = zin.shape
+    out = torch.full((m + 1, n + 1), float("nan"), device="cuda")
+    lg_eng.ctx.call("im_log_optimal_transport", *ptrs(zin), m, n, n, 1.0, int(g["iters"]), *ptrs(out), stream_ptr())
+    torch.cuda.synchronize()
+    err = np.abs(out.cpu().numpy() - g["ot_out"]).max()
+    assert err < 1e-4, err
+
+
+def test_superglue_empty_input(lg_eng):
+    """`superglue.py:255-262`: no keypoints in one image -> all matches -1, scores 0."""
+    e = lg_eng
+    e.load_state_dict("superglue", synthetic.superglue_state_dict(0, "default"))
+    e.n[:] = torch.tensor([0, 17], dtype=torch.int32)
+    e.superglue((480, 640), (480, 640))
+    torch.cuda.synchronize()
+    out = e.matches_to_host(0, 17)
+    assert (out["matches1"] == -1).all() and (out["matching_scores1"] == 0).all()
+
+
+# ------------------------------------------------------------------------------------------- matcher API (wrappers)
+def overlap(a, b):
+    sa, sb = {tuple(np.round(p, 3)) for p in a}, {tuple(np.round(p, 3)) for p in b}
+    return len(sa & sb) / max(len(sb), 1)
+
+
+def test_lightglue_matcher_api():
+    """G4: the wrapper classes against the reference's own outputs (quirks q1, q4, q5, q6)."""
+    from icepy4d_amd.matching import GeometricVerification, LightGlueMatcher, Quality, TileSelection
+    g = load_golden("g4_wrappers")
+    sds = {"superpoint": SP_SD, "lightglue": synthetic.lightglue_state_dict(0, "passthrough")}
+    m = LightGlueMatcher({"state_dicts": sds})
+    cfg = dict(geometric_verification=GeometricVerification.NONE, max_keypoints=256)
+    assert m.match(g["image0"], g["image1"], quality=Quality.HIGH, tile_selection=TileSelection.NONE, **cfg) is True
+    # q1: with TileSelection.NONE the stored keypoints are the unfiltered detections, mconf the valid match scores
+    assert m.mkpts0.shape == g["lg_none_mkpts0"].shape and m.descriptors0.shape == g["lg_none_desc0"].shape
+    assert overlap(m.mkpts0, g["lg_none_mkpts0"]) >= 0.97
+    assert abs(len(m.mconf) - len(g["lg_none_mconf"])) <= 0.05 * len(g["lg_none_mconf"]) + 2
+    m = LightGlueMatcher({"state_dicts": sds})
+    m.match(g["image0"], g["image1"], quality=Quality.HIGH, tile_selection=TileSelection.GRID, grid=[2, 2], overlap=20, **cfg)
+    ref0, ref1 = g["lg_grid_mkpts0"], g["lg_grid_mkpts1"]
+    assert m.mkpts0.shape[1] == 2 and m.descriptors0.shape[0] == 256 and len(m.mconf) == len(m.mkpts0)
+    pairs = {(tuple(a), tuple(b)) for a, b in zip(m.mkpts0, m.mkpts1)}
+    refp = {(tuple(a), tuple(b)) for a, b in zip(ref0, ref1)}
+    assert len(pairs & refp) >= 0.95 * len(refp), (len(pairs & refp), len(refp))
+    assert np.array_equal(m.mkpts0, np.unique(m.mkpts0, axis=0))  # q6 ordering
+    # medium quality goes through the pyramid and rescales keypoints
+    m.match(g["image0"], g["image1"], quality=Quality.MEDIUM, tile_selection=TileSelection.NONE, **cfg)
+    assert m.mkpts0[:, 0].max() > g["image0"].shape[1] / 2
+
+
+def test_superglue_matcher_api():
+    from icepy4d_amd.matching import GeometricVerification, Quality, SuperGlueMatcher, TileSelection
+    g = load_golden("g4_wrappers")
+    sds = {"superpoint": SP_SD, "superglue": synthetic.superglue_state_dict(0, "passthrough")}
+    with pytest.raises(TypeError):
+        SuperGlueMatcher("not a dict")
+    m = SuperGlueMatcher({"weights": "outdoor", "keypoint_threshold": 0.001, "max_keypoints": 256, "match_threshold": 0.3,
+                          "force_cpu": False, "state_dicts": sds})
+    m.match(g["image0"], g["image1"], quality=Quality.HIGH, tile_selection=TileSelection.NONE,
+            geometric_verification=GeometricVerification.NONE)
+    pairs = {(tuple(a), tuple(b)) for a, b in zip(m.mkpts0, m.mkpts1)}
+    refp = {(tuple(a), tuple(b)) for a, b in zip(g["sg_none_mkpts0"], g["sg_none_mkpts1"])}
+    assert len(pairs & refp) >= 0.9 * len(refp), (len(pairs & refp), len(refp))
+    assert np.array_equal(m.mconf, m.scores0)  # q5: mconf is the keypoint score of the valid matches
+    m.reset()
+    m.match(g["image0"], g["image1"], quality=Quality.HIGH, tile_selection=TileSelection.EXHAUSTIVE, grid=[1, 2], overlap=10,
+            geometric_verification=GeometricVerification.NONE)
+    pairs = {(tuple(a), tuple(b)) for a, b in zip(m.mkpts0, m.mkpts1)}
+    refp = {(tuple(a), tuple(b)) for a, b in zip(g["sg_exh_mkpts0"], g["sg_exh_mkpts1"])}
+    assert len(pairs & refp) >= 0.9 * len(refp), (len(pairs & refp), len(refp))
+    # geometric verification on the paired matches keeps the dominant translation
+    m.match(g["image0"], g["image1"], quality=Quality.HIGH, tile_selection=TileSelection.NONE,
+            geometric_verification=GeometricVerification.PYDEGENSAC, threshold=2)
+    d = m.mkpts1 - m.mkpts0
+    assert len(d) > 10 and np.mean(np.all(np.abs(d - np.median(d, 0)) < 3, 1)) > 0.8
