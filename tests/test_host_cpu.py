@@ -1,0 +1,206 @@
+"""CPU-side tests (no GPU): the C-ABI library loads and exports every declared symbol, host logic of the matcher
+API (tiler, pyramid, geometric verification, timers), the sequence sharding + match-table all-gather on gloo
+(world_size 2), and the synthetic data generators."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden
+from icepy4d_amd import synthetic
+
+
+def test_library_exports_every_declared_symbol():
+    from icepy4d_amd import _lib
+    assert os.path.exists(_lib.LIB_PATH), "run __graft_entry__.build() first"
+    lib = _lib.load()  # binds every name of _lib.SIGNATURES; no compute, no GPU needed
+    header = open(os.path.join(ROOT, "include", "icematch.h")).read()
+    declared = set(re.findall(r"\b(im_[a-z0-9_]+)\s*\(", header))
+    declared -= {"im_ctx"}
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.im_version() >= 100
+
+
+def test_no_cpu_fallback_without_gpu():
+    """The product path fails loudly when there is no HIP device."""
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from icepy4d_amd.engine import Engine
+    with pytest.raises(RuntimeError):
+        Engine(0)
+    from icepy4d_amd.matching import LightGlueMatcher
+    with pytest.raises(RuntimeError):
+        LightGlueMatcher({"state_dicts": {"superpoint": {}, "lightglue": {}}})
+
+
+def test_product_never_imports_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "icepy4d_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("the oracle", "").replace("CPU oracle", "") or f == "synthetic.py", (dirpath, f)
+
+
+def test_tiler_matches_reference():
+    from icepy4d_amd.matching import Tiler
+    g = load_golden("g4_wrappers")
+    t = Tiler(grid=[2, 3], overlap=15, origin=[0, 0])
+    lims, origin = t.compute_limits_by_grid(g["image0"])
+    assert np.array_equal(np.array([lims[i] for i in sorted(lims)]), g["tiler_limits"])
+    assert np.array_equal(t.extract_patch(g["image0"], lims[4]), g["tiler_patch"])
+    # q4: a 1x1 grid drops the last row and column
+    lims, _ = Tiler(grid=[1, 1]).compute_limits_by_grid(np.zeros((800, 1200), np.uint8))
+    assert Tiler.extract_patch(np.zeros((800, 1200), np.uint8), lims[0]).shape == (799, 1199)
+
+
+def test_enums_match_reference_values():
+    from icepy4d_amd.matching import GeometricVerification, Quality, TileSelection
+    assert [e.value for e in TileSelection] == [0, 1, 2, 3] and TileSelection.PRESELECTION.value == 3
+    assert GeometricVerification.NONE.value == 1 and GeometricVerification.MAGSAC.value == 3
+    assert Quality.LOW.value == 1 and Quality.HIGHEST.value == 4
+
+
+def test_pyramid():
+    from icepy4d_amd.matching.pyramid import pyr_down, pyr_up
+    a = np.full((37, 50), 100, np.uint8)
+    assert pyr_down(a).shape == (19, 25) and (pyr_down(a) == 100).all()
+    assert pyr_up(a).shape == (74, 100) and (pyr_up(a) == 100).all()
+    rng = np.random.default_rng(0)
+    b = synthetic.band_limited_noise(rng, 64, 96)
+    d = pyr_down(b)
+    # hand-computed interior sample of the 5x5 binomial filter
+    k = np.array([1, 4, 6, 4, 1], np.int64)
+    y, x = 10, 20
+    ref = (np.outer(k, k) * b[2 * y - 2:2 * y + 3, 2 * x - 2:2 * x + 3].astype(np.int64)).sum()
+    assert d[y, x] == (ref + 128) >> 8
+    assert abs(float(pyr_up(d).mean()) - float(b.mean())) < 2.0
+
+
+def test_geometric_verification():
+    from icepy4d_amd.matching import GeometricVerification, geometric_verification
+    rng = np.random.default_rng(1)
+    # points on two depth planes seen by two translated cameras -> a valid epipolar geometry
+    X = np.c_[rng.uniform(-1, 1, 200), rng.uniform(-1, 1, 200), rng.uniform(4, 8, 200)]
+    K = np.array([[800, 0, 320], [0, 800, 240], [0, 0, 1.0]])
+    p0 = (K @ X.T).T
+    p0 = p0[:, :2] / p0[:, 2:]
+    X1 = X + np.array([0.5, 0.05, 0.1])
+    p1 = (K @ X1.T).T
+    p1 = p1[:, :2] / p1[:, 2:]
+    p1[:40] += rng.uniform(20, 60, size=(40, 2))  # outliers
+    F, mask = geometric_verification(p0.astype(np.float32), p1.astype(np.float32), GeometricVerification.PYDEGENSAC, threshold=1.0)
+    assert F is not None and mask[40:].mean() > 0.95 and mask[:40].mean() < 0.2
+    F, mask = geometric_verification(p0[:3], p1[:3], GeometricVerification.MAGSAC)
+    assert F is None and mask.all()
+    F, mask = geometric_verification(p0, p1, GeometricVerification.NONE)
+    assert F is None and mask.all()
+
+
+def test_average_timer_and_timeit(capsys):
+    from icepy4d_amd.utils import AverageTimer, timeit
+    t = AverageTimer()
+    t.update("matching")
+    t.update("matching")
+    assert "matching" in t.times and t.will_print["matching"]
+    t.print("Matching")
+    assert not t.will_print["matching"]
+
+    @timeit
+    def f(x):
+        return x + 1
+
+    assert f(1) == 2
+    assert "Function f took" in capsys.readouterr().out
+
+
+def test_matcher_option_errors():
+    from icepy4d_amd.matching import ImageMatcherBase, check_dict_keys
+    with pytest.raises(TypeError):
+        ImageMatcherBase("nope")
+    with pytest.raises(KeyError):
+        check_dict_keys({"a": 1}, ["a", "b"])
+    m = ImageMatcherBase({})
+    with pytest.raises(NotImplementedError):
+        m._match_images(np.zeros((8, 8), np.uint8), np.zeros((8, 8), np.uint8))
+    assert m.mkpts0 is None and m.mconf is None
+
+
+def test_store_and_filter_features():
+    from icepy4d_amd.matching import FeaturesBase, ImageMatcherBase
+    m = ImageMatcherBase({})
+    f0 = FeaturesBase(np.arange(10, dtype=np.float32).reshape(5, 2), np.arange(256 * 5, dtype=np.float32).reshape(256, 5), np.arange(5, dtype=np.float32))
+    f1 = FeaturesBase(f0.keypoints + 100, f0.descriptors + 1, f0.scores + 10)
+    matches0 = np.array([2, -1, 0, -1, 4])
+    m._store_features(f0, f1, matches0)
+    m._mconf = f0.scores[matches0 > -1]
+    assert np.array_equal(m.mkpts0, f0.keypoints[[0, 2, 4]]) and np.array_equal(m.mkpts1, f1.keypoints[[2, 0, 4]])
+    assert m.descriptors1.shape == (256, 3) and np.array_equal(m.scores1, f1.scores[[2, 0, 4]])
+    m._filter_matches_by_mask(np.array([True, False, True]))
+    assert len(m.mkpts0) == 2 and m.descriptors0.shape == (256, 2) and len(m.mconf) == 2
+
+
+def test_synthetic_generators_are_deterministic():
+    a0, a1 = synthetic.stereo_pair(3, 64, 96)
+    b0, b1 = synthetic.stereo_pair(3, 64, 96)
+    assert np.array_equal(a0, b0) and np.array_equal(a1, b1) and a0.dtype == np.uint8
+    sd1, sd2 = synthetic.superpoint_state_dict(0), synthetic.superpoint_state_dict(0)
+    assert all(torch.equal(sd1[k], sd2[k]) for k in sd1)
+    assert set(synthetic.lightglue_state_dict(0)) == set(synthetic.lightglue_state_dict(0, "prune"))
+    i0, i1 = synthetic.translated_pair(0, 64, 96, 16, 8)
+    assert i0.shape == i1.shape == (64, 96)
+
+
+def test_shard_and_records():
+    from icepy4d_amd import sequence as sq
+    assert sq.shard_epochs(10, 1, 4) == [1, 5, 9]
+    assert sorted(sum((sq.shard_epochs(2048, r, 8) for r in range(8)), [])) == list(range(2048))
+    K = 16
+    t = sq.new_table(2, K, "cpu")
+    m0 = torch.full((K,), -1, dtype=torch.int32)
+    m0[3] = 7
+    ms = torch.zeros(K)
+    ms[3] = 0.5
+    sq.write_record(t, 1, 42, torch.tensor([10, 12], dtype=torch.int32), m0, ms, torch.tensor([9, 0, 0, 0], dtype=torch.int32))
+    r = sq.decode_record(t[1].numpy(), K)
+    assert r["epoch"] == 42 and r["n0"] == 10 and r["n1"] == 12 and r["n_matches"] == 1 and r["stop"] == 9
+    assert r["matches0"][3] == 7 and r["matching_scores0"][3] == 0.5 and len(r["matches0"]) == 10
+
+
+WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["REPO"])
+from icepy4d_amd import sequence as sq
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+K, n_epochs = 8, 7
+mine = sq.shard_epochs(n_epochs, rank, world)
+t = sq.new_table(len(mine), K, "cpu")
+for row, ep in enumerate(mine):
+    m0 = torch.full((K,), -1, dtype=torch.int32); m0[ep % K] = ep
+    sq.write_record(t, row, ep, torch.tensor([K, K], dtype=torch.int32), m0, torch.full((K,), float(ep)), torch.tensor([9, 0, 0, 0], dtype=torch.int32))
+full = sq.all_gather_tables(t)
+assert full.shape[0] == n_epochs, full.shape
+assert full[:, 0].tolist() == list(range(n_epochs))
+for ep in range(n_epochs):
+    r = sq.decode_record(full[ep].numpy(), K)
+    assert r["matches0"][ep % K] == ep and r["matching_scores0"][0] == float(ep) and r["n_matches"] == 1
+dist.barrier(); dist.destroy_process_group()
+print("ok", rank)
+'''
+
+
+def test_all_gather_match_tables_gloo_world2(tmp_path):
+    """The N > 1 path: round-robin epoch shards with unequal counts, one all-gather, every rank gets the full table."""
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, REPO=ROOT, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29531", str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert r.stdout.count("ok") == 2
