@@ -10,23 +10,107 @@
 // Work split: one wave owns 32 query rows, a block is 4 waves = 128 queries of one (image, head); all four
 // waves stream the same 64-key K/V tiles through LDS. Both products keep the QUERY on the MFMA lane:
 //     S^T (keys x queries)  = K . Q^T     A = K tile from LDS (16-byte reads, permuted d order), B = Q in registers
-//     O^T (d x queries)    += V^T . P^T   A = V tile from LDS, B = P = exp(S^T - m) straight from the accumulator layout
+//     O^T (d x queries)    += V^T . P^T   A = V tile from LDS, B = P = exp2(S^T - m) straight from the accumulator layout
 // so the online-softmax statistics (running max m, running sum l) are one scalar per lane and rescaling the
-// output accumulator is a per-lane multiply. fp32 throughout; exp via v_exp_f32.
+// output accumulator is a per-lane multiply.
+//
+// Pipeline (one barrier per 64-key tile): K and V tiles live in two LDS rings of depth 2, K running one tile
+// ahead of V. Iteration t issues the QK^T MFMAs of tile t+1 and, in their shadow, the softmax VALU work of tile t,
+// then the PV MFMAs of tile t; global loads for K(t+3) / V(t+2) are in flight meanwhile (register staging).
+// Loads beyond the live key count are clamped to the last valid row (their scores are masked to -inf in the
+// last tile), so the main loop has no divergent branch.
 #include "common.h"
 #include "kernels.h"
 
 namespace im {
 
-static constexpr int KT = 64;       // keys per LDS tile
+static constexpr int KT = 64;       // keys per tile
 static constexpr int KS = 68;       // K tile row stride (floats): conflict-free ds_read_b128
 static constexpr int VS = 64;       // V tile row stride
+static constexpr int ATTN_LDS_FLOATS = 2 * KT * KS + 2 * KT * VS;
 
-__global__ __launch_bounds__(256) void flash_attn_f32_kernel(AttnArgs a) {
+// register staging of one 64 x 64 tile: 1024 float4, 4 per thread (thread -> row idx >> 4, 16-byte column idx & 15)
+__device__ __forceinline__ float4 load_row4(const float* __restrict__ base, int row0, int nk, int idx) {
+    const int row = min(row0 + (idx >> 4), nk - 1);
+    return *reinterpret_cast<const float4*>(base + (long)row * 64 + (idx & 15) * 4);
+}
+#define IM_LOAD_TILE(r, base, row0)                       \
+    r##0 = load_row4(base, row0, nk, tid);                \
+    r##1 = load_row4(base, row0, nk, tid + 256);          \
+    r##2 = load_row4(base, row0, nk, tid + 512);          \
+    r##3 = load_row4(base, row0, nk, tid + 768);
+#define IM_STORE_TILE(r, dst, stride)                                                                          \
+    *reinterpret_cast<float4*>((dst) + (tid >> 4) * (stride) + (tid & 15) * 4) = r##0;                        \
+    *reinterpret_cast<float4*>((dst) + ((tid >> 4) + 16) * (stride) + (tid & 15) * 4) = r##1;                 \
+    *reinterpret_cast<float4*>((dst) + ((tid >> 4) + 32) * (stride) + (tid & 15) * 4) = r##2;                 \
+    *reinterpret_cast<float4*>((dst) + ((tid >> 4) + 48) * (stride) + (tid & 15) * 4) = r##3;
+
+// S^T for one 64-key tile: two 32-key halves, 32 MFMAs each; contraction order d = s (hh = 0) / 32 + s (hh = 1)
+__device__ __forceinline__ void qk_tile(const float* __restrict__ sK, int c, int hh, const float (&qf)[32], f32x16& sa, f32x16& sb) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sa[r] = 0.f; sb[r] = 0.f; }
+    const float* ka = sK + c * KS + hh * 32;
+    const float* kb = ka + 32 * KS;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const float4 fa = *reinterpret_cast<const float4*>(ka + t * 4);
+        const float4 fb = *reinterpret_cast<const float4*>(kb + t * 4);
+        sa = mfma32(fa.x, qf[4 * t + 0], sa); sb = mfma32(fb.x, qf[4 * t + 0], sb);
+        sa = mfma32(fa.y, qf[4 * t + 1], sa); sb = mfma32(fb.y, qf[4 * t + 1], sb);
+        sa = mfma32(fa.z, qf[4 * t + 2], sa); sb = mfma32(fb.z, qf[4 * t + 2], sb);
+        sa = mfma32(fa.w, qf[4 * t + 3], sa); sb = mfma32(fb.w, qf[4 * t + 3], sb);
+    }
+}
+
+// online softmax of one 64-key tile in the log2 domain; on return sa / sb hold P = exp2(s * c - m)
+template <bool TAIL>
+__device__ __forceinline__ void softmax_tile(f32x16& sa, f32x16& sb, int kb, int nk, int hh, float& m_run, float& l_run,
+                                             f32x16& o0, f32x16& o1) {
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        if (TAIL) {
+            if (kb + acc_row(r, hh) >= nk) sa[r] = -INFINITY;
+            if (kb + 32 + acc_row(r, hh) >= nk) sb[r] = -INFINITY;
+        }
+        mx = fmaxf(mx, fmaxf(sa[r], sb[r]));
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    float rs = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float pa = __builtin_amdgcn_exp2f(sa[r] - m_new), pb = __builtin_amdgcn_exp2f(sb[r] - m_new);
+        sa[r] = pa; sb[r] = pb;
+        rs += pa + pb;
+    }
+    rs += __shfl_xor(rs, 32);
+    l_run = l_run * alpha + rs;
+    m_run = m_new;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+}
+
+// O^T += V^T . P^T for one 64-key tile: register r of P is key acc_row(r, hh) of its half
+__device__ __forceinline__ void pv_tile(const float* __restrict__ sV, int c, int hh, const f32x16& pa, const f32x16& pb, f32x16& o0, f32x16& o1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float* vp = sV + acc_row(r, hh) * VS + c;
+        o0 = mfma32(vp[0], pa[r], o0);
+        o1 = mfma32(vp[32], pa[r], o1);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float* vp = sV + (32 + acc_row(r, hh)) * VS + c;
+        o0 = mfma32(vp[0], pb[r], o0);
+        o1 = mfma32(vp[32], pb[r], o1);
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void flash_attn_f32_kernel(AttnArgs a) {
     if (a.active && *a.active == 0) return;
-    __shared__ __attribute__((aligned(16))) float smem[KT * KS + KT * VS];
-    float* sK = smem;
-    float* sV = smem + KT * KS;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int z = blockIdx.z, head = blockIdx.y;
     const int y = a.cross ? (z ^ 1) : z;
@@ -38,7 +122,6 @@ __global__ __launch_bounds__(256) void flash_attn_f32_kernel(AttnArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 31, hh = lane >> 5;
     const int qrow = qb + wave * 32 + c;
-    const int qrow_ld = min(qrow, nq - 1);
 
     const float* Q = a.q + (long)z * a.bstride + (long)head * a.hstride;
     const float* K = a.k + (long)y * a.bstride + (long)head * a.hstride;
@@ -46,101 +129,73 @@ __global__ __launch_bounds__(256) void flash_attn_f32_kernel(AttnArgs a) {
 
     // Q fragment: lane (c, hh) keeps Q[qrow][32*hh + s], s = 0..31
     float qf[32];
+    {
+        const float* qp = Q + (long)min(qrow, nq - 1) * 64 + hh * 32;
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        float4 v4 = *reinterpret_cast<const float4*>(Q + (long)qrow_ld * 64 + hh * 32 + t * 4);
-        qf[4 * t + 0] = v4.x; qf[4 * t + 1] = v4.y; qf[4 * t + 2] = v4.z; qf[4 * t + 3] = v4.w;
+        for (int t = 0; t < 8; ++t) {
+            const float4 v4 = *reinterpret_cast<const float4*>(qp + t * 4);
+            qf[4 * t + 0] = v4.x; qf[4 * t + 1] = v4.y; qf[4 * t + 2] = v4.z; qf[4 * t + 3] = v4.w;
+        }
+        // softmax in the log2 domain: exp(s x) = exp2(x * s * log2 e); the factor is folded into Q once
+        const float c2 = a.scale * 1.4426950408889634f;
+#pragma unroll
+        for (int t = 0; t < 32; ++t) qf[t] *= c2;
     }
 
-    f32x16 o0, o1;
+    f32x16 o0, o1, sa, sb, na, nb;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
     float m_run = -INFINITY, l_run = 0.f;
+    const int nt = (nk + KT - 1) / KT;
 
-    // register staging of the next K/V tile: 64 rows x 16 float4 = 1024 float4 per tensor, 4 per thread
-    float4 rk[4], rv[4];
-    auto load_tile = [&](int kt) {
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            int idx = tid + it * 256;
-            int row = kt + (idx >> 4), c4 = idx & 15;
-            if (row < nk) {
-                rk[it] = *reinterpret_cast<const float4*>(K + (long)row * 64 + c4 * 4);
-                rv[it] = *reinterpret_cast<const float4*>(V + (long)row * 64 + c4 * 4);
-            } else {
-                rk[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-                rv[it] = rk[it];
-            }
-        }
-    };
-    auto store_tile = [&]() {
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            int idx = tid + it * 256;
-            int row = idx >> 4, c4 = idx & 15;
-            *reinterpret_cast<float4*>(sK + row * KS + c4 * 4) = rk[it];
-            *reinterpret_cast<float4*>(sV + row * VS + c4 * 4) = rv[it];
-        }
-    };
+    // ---- prologue: K0 -> LDS, S(0); K1, V0 -> LDS; K2, V1 in registers
+    float4 rk0, rk1, rk2, rk3, rv0, rv1, rv2, rv3;
+    float* const sK0 = smem;
+    float* const sV0 = smem + 2 * KT * KS;
+    IM_LOAD_TILE(rk, K, 0)
+    IM_STORE_TILE(rk, sK0, KS)
+    IM_LOAD_TILE(rk, K, KT)
+    IM_LOAD_TILE(rv, V, 0)
+    __syncthreads();
+    qk_tile(sK0, c, hh, qf, sa, sb);
+    IM_STORE_TILE(rk, sK0 + KT * KS, KS)
+    IM_STORE_TILE(rv, sV0, VS)
+    IM_LOAD_TILE(rk, K, 2 * KT)
+    IM_LOAD_TILE(rv, V, KT)
+    __syncthreads();
 
-    load_tile(0);
-    for (int kt = 0; kt < nk; kt += KT) {
-        __syncthreads();  // previous tile fully consumed
-        store_tile();
-        __syncthreads();
-        if (kt + KT < nk) load_tile(kt + KT);
-
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-            const int kb = kt + sub * 32;
-            if (kb >= nk) break;  // wave-uniform
-            // ---- S^T = K . Q^T : 32 MFMAs, contraction order d = s (hh=0) / 32+s (hh=1)
-            f32x16 st;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) st[r] = 0.f;
-            const float* kp = sK + (sub * 32 + c) * KS + hh * 32;
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                float4 kf = *reinterpret_cast<const float4*>(kp + t * 4);
-                st = mfma32(kf.x, qf[4 * t + 0], st);
-                st = mfma32(kf.y, qf[4 * t + 1], st);
-                st = mfma32(kf.z, qf[4 * t + 2], st);
-                st = mfma32(kf.w, qf[4 * t + 3], st);
-            }
-            // ---- online softmax over the 32 keys of this sub-tile (16 here, 16 in lane ^ 32)
-            const bool tail = kb + 32 > nk;
-            float mx = -INFINITY;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float sv = st[r] * a.scale;
-                if (tail && (kb + acc_row(r, hh) >= nk)) sv = -INFINITY;
-                st[r] = sv;
-                mx = fmaxf(mx, sv);
-            }
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float m_new = fmaxf(m_run, mx);
-            const float alpha = __expf(m_run - m_new);
-            float rs = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float p = __expf(st[r] - m_new);
-                st[r] = p;
-                rs += p;
-            }
-            rs += __shfl_xor(rs, 32);
-            l_run = l_run * alpha + rs;
-            m_run = m_new;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
-            // ---- O^T += V^T . P^T : register r of P is key acc_row(r, hh) of the sub-tile
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float* vp = sV + (sub * 32 + acc_row(r, hh)) * VS + c;
-                o0 = mfma32(vp[0], st[r], o0);
-                o1 = mfma32(vp[32], st[r], o1);
-            }
-        }
+    // iteration t: stage K(t+2), V(t+1); prefetch K(t+3), V(t+2); QK^T of tile t+1 with the softmax of tile t in
+    // its shadow (one basic block, so the scheduler can interleave MFMA and VALU); PV of tile t; one barrier
+#ifndef IM_ATTN_NO_SCHED
+#define IM_SCHED_QK_SOFTMAX                                                    \
+    _Pragma("unroll") for (int _i = 0; _i < 64; ++_i) {                        \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); /* 1 MFMA */        \
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0); /* 4 VALU */        \
     }
+#else
+#define IM_SCHED_QK_SOFTMAX
+#endif
+#define IM_STEP(TAIL)                                                                   \
+    {                                                                                   \
+        float* const kw = sK0 + (t & 1) * (KT * KS);                                    \
+        float* const kr = sK0 + ((t + 1) & 1) * (KT * KS);                              \
+        float* const vw = sV0 + ((t + 1) & 1) * (KT * VS);                              \
+        float* const vr = sV0 + (t & 1) * (KT * VS);                                    \
+        IM_STORE_TILE(rk, kw, KS)                                                       \
+        IM_STORE_TILE(rv, vw, VS)                                                       \
+        IM_LOAD_TILE(rk, K, (t + 3) * KT)                                               \
+        IM_LOAD_TILE(rv, V, (t + 2) * KT)                                               \
+        qk_tile(kr, c, hh, qf, na, nb);                                                 \
+        softmax_tile<TAIL>(sa, sb, t * KT, nk, hh, m_run, l_run, o0, o1);           \
+        pv_tile(vr, c, hh, sa, sb, o0, o1);                                             \
+        IM_SCHED_QK_SOFTMAX                                                             \
+        sa = na; sb = nb;                                                               \
+        __syncthreads();                                                                \
+    }
+    int t = 0;
+    for (; t < nt - 1; ++t) IM_STEP(false)
+    IM_STEP(true)
+#undef IM_STEP
 
     // ---- epilogue: lane (c, hh) holds query qrow, d = db*32 + 8*g + 4*hh + (0..3) in registers 4g..4g+3
     if (qrow < nq) {
@@ -148,8 +203,8 @@ __global__ __launch_bounds__(256) void flash_attn_f32_kernel(AttnArgs a) {
         float* op = a.out + (long)z * a.out_bstride + (long)qrow * a.ldo + head * 64;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            float4 w0 = make_float4(o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
-            float4 w1 = make_float4(o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+            const float4 w0 = make_float4(o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+            const float4 w1 = make_float4(o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
             *reinterpret_cast<float4*>(op + 8 * g + 4 * hh) = w0;
             *reinterpret_cast<float4*>(op + 32 + 8 * g + 4 * hh) = w1;
         }
@@ -158,8 +213,16 @@ __global__ __launch_bounds__(256) void flash_attn_f32_kernel(AttnArgs a) {
 
 hipError_t launch_flash_attn(const AttnArgs& a, hipStream_t s) {
     if (a.n_max <= 0) return hipSuccess;
+    const size_t lds = ATTN_LDS_FLOATS * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_f32_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
     dim3 grid((a.n_max + 127) / 128, a.heads, a.batch), block(256);
-    hipLaunchKernelGGL(flash_attn_f32_kernel, grid, block, 0, s, a);
+    hipLaunchKernelGGL(flash_attn_f32_kernel, grid, block, lds, s, a);
     return hipGetLastError();
 }
 
