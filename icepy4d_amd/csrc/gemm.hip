@@ -8,9 +8,9 @@
 // (`lightglue/lightglue.py:280`, `superglue.py:279`).
 //
 // Tiling: 256 threads = 4 waves in a 2x2 grid; each wave owns (BM/2)x(BN/2) of the block tile as
-// 32x32 MFMA tiles. K is consumed in slabs of 32 staged through LDS (row stride 36 floats: the
-// ds_read_b128 fragment reads are bank-conflict free). The contraction index inside a slab is
-// permuted (lane-half h reads k = 16h .. 16h+15 contiguously) so that one 16-byte LDS read feeds four
+// 32x32 MFMA tiles. K is consumed in slabs of BK (32 or 64) staged through LDS (row stride BK + 4 floats:
+// the ds_read_b128 fragment reads are bank-conflict free). The contraction index inside a slab is
+// permuted (lane-half h reads k = h BK/2 .. contiguously) so that one 16-byte LDS read feeds four
 // MFMAs; A and B use the same permutation, so the product is unchanged up to summation order.
 // Global loads of slab t+1 are issued before the MFMAs of slab t (register staging).
 #include "common.h"
@@ -18,15 +18,14 @@
 
 namespace im {
 
-static constexpr int BK = 32;
-static constexpr int LDS_LD = BK + 4;
-
-template <int BM, int BN, int EPI>
+template <int BM, int BN, int BK, int EPI>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
     if (a.active && *a.active == 0) return;
+    constexpr int LDS_LD = BK + 4;
     constexpr int WM = BM / 2, WN = BN / 2;
     constexpr int MB = WM / 32, NB = WN / 32;
-    constexpr int A_IT = BM / 32, B_IT = BN / 32;  // float4 loads per thread per slab
+    constexpr int F4 = BK / 4;                                 // float4 per row of a slab
+    constexpr int A_IT = BM * F4 / 256, B_IT = BN * F4 / 256;  // float4 loads per thread per slab
     __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDS_LD];
     float* sA = smem;
     float* sB = smem + BM * LDS_LD;
@@ -56,53 +55,46 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float4 ra[A_IT], rb[B_IT];
-    auto load_slab = [&](int k0) {
-        const float* src = A0;
-        int ld = a.lda, kk = k0;
-        if (A1 && k0 >= a.ksplit) { src = A1; ld = a.lda1; kk = k0 - a.ksplit; }
-#pragma unroll
-        for (int it = 0; it < A_IT; ++it) {
-            int idx = tid + it * 256;
-            int row = m0 + (idx >> 3), c4 = idx & 7;
-            ra[it] = (row < M) ? *reinterpret_cast<const float4*>(src + (long)row * ld + kk + c4 * 4)
-                               : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int it = 0; it < B_IT; ++it) {
-            int idx = tid + it * 256;
-            int row = n0 + (idx >> 3), c4 = idx & 7;
-            rb[it] = (row < Nlive) ? *reinterpret_cast<const float4*>(Wp + (long)row * a.ldw + k0 + c4 * 4)
-                                   : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-    auto store_slab = [&]() {
-#pragma unroll
-        for (int it = 0; it < A_IT; ++it) {
-            int idx = tid + it * 256;
-            *reinterpret_cast<float4*>(sA + (idx >> 3) * LDS_LD + (idx & 7) * 4) = ra[it];
-        }
-#pragma unroll
-        for (int it = 0; it < B_IT; ++it) {
-            int idx = tid + it * 256;
-            *reinterpret_cast<float4*>(sB + (idx >> 3) * LDS_LD + (idx & 7) * 4) = rb[it];
-        }
-    };
+    // Register staging of the next slab in named registers (arrays indexed inside helper lambdas / loops ended up
+    // in scratch). Rows beyond the live counts are clamped to the last valid row; their products are never stored.
+    static_assert((A_IT == 1 || A_IT == 2 || A_IT == 4) && (B_IT == 1 || B_IT == 2 || B_IT == 4), "staging registers");
+    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+    ra1 = ra2 = ra3 = rb1 = rb2 = rb3 = make_float4(0.f, 0.f, 0.f, 0.f);
+#define IM_LD_A(i) *reinterpret_cast<const float4*>(src + (long)min(m0 + (tid + (i) * 256) / F4, M - 1) * ld + kk + ((tid + (i) * 256) % F4) * 4)
+#define IM_LD_B(i, k0_) *reinterpret_cast<const float4*>(Wp + (long)min(n0 + (tid + (i) * 256) / F4, Nlive - 1) * a.ldw + (k0_) + ((tid + (i) * 256) % F4) * 4)
+#define IM_LOAD_SLAB(k0_)                                                                  \
+    {                                                                                      \
+        const float* src = A0;                                                             \
+        int ld = a.lda, kk = (k0_);                                                        \
+        if (A1 && (k0_) >= a.ksplit) { src = A1; ld = a.lda1; kk = (k0_) - a.ksplit; }     \
+        ra0 = IM_LD_A(0);                                                                  \
+        if constexpr (A_IT > 1) ra1 = IM_LD_A(1);                                          \
+        if constexpr (A_IT > 2) { ra2 = IM_LD_A(2); ra3 = IM_LD_A(3); }                    \
+        rb0 = IM_LD_B(0, k0_);                                                             \
+        if constexpr (B_IT > 1) rb1 = IM_LD_B(1, k0_);                                     \
+        if constexpr (B_IT > 2) { rb2 = IM_LD_B(2, k0_); rb3 = IM_LD_B(3, k0_); }          \
+    }
+#define IM_ST(buf, i, r) *reinterpret_cast<float4*>(buf + ((tid + (i) * 256) / F4) * LDS_LD + ((tid + (i) * 256) % F4) * 4) = r
 
-    load_slab(0);
+    IM_LOAD_SLAB(0)
     for (int k0 = 0; k0 < a.K; k0 += BK) {
-        store_slab();
+        IM_ST(sA, 0, ra0);
+        if constexpr (A_IT > 1) IM_ST(sA, 1, ra1);
+        if constexpr (A_IT > 2) { IM_ST(sA, 2, ra2); IM_ST(sA, 3, ra3); }
+        IM_ST(sB, 0, rb0);
+        if constexpr (B_IT > 1) IM_ST(sB, 1, rb1);
+        if constexpr (B_IT > 2) { IM_ST(sB, 2, rb2); IM_ST(sB, 3, rb3); }
         __syncthreads();
-        if (k0 + BK < a.K) load_slab(k0 + BK);
+        if (k0 + BK < a.K) IM_LOAD_SLAB(k0 + BK)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < BK / 8; ++t) {
             float4 fa[MB], fb[NB];
 #pragma unroll
             for (int i = 0; i < MB; ++i)
-                fa[i] = *reinterpret_cast<const float4*>(sA + (wm0 + i * 32 + c) * LDS_LD + hh * 16 + t * 4);
+                fa[i] = *reinterpret_cast<const float4*>(sA + (wm0 + i * 32 + c) * LDS_LD + hh * (BK / 2) + t * 4);
 #pragma unroll
             for (int j = 0; j < NB; ++j)
-                fb[j] = *reinterpret_cast<const float4*>(sB + (wn0 + j * 32 + c) * LDS_LD + hh * 16 + t * 4);
+                fb[j] = *reinterpret_cast<const float4*>(sB + (wn0 + j * 32 + c) * LDS_LD + hh * (BK / 2) + t * 4);
 #pragma unroll
             for (int i = 0; i < MB; ++i)
 #pragma unroll
@@ -115,6 +107,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
         }
         __syncthreads();
     }
+#undef IM_LOAD_SLAB
+#undef IM_LD_A
+#undef IM_LD_B
+#undef IM_ST
 
     // ---- epilogue: lane holds column n = .. + c, rows acc_row(r, hh)
 #pragma unroll
@@ -160,14 +156,16 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
 }
 
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
-    if (a.K % BK != 0 || (a.A1 && a.ksplit % BK != 0)) return hipErrorInvalidValue;
+    if (a.K % 32 != 0 || (a.A1 && a.ksplit % 64 != 0)) return hipErrorInvalidValue;
+    const bool k64 = false;  // 64-deep slabs measured neutral-to-slower on MI355X at the LightGlue shapes; kept for tuning
     const int bm = a.big_tile ? 128 : 64, bn = bm;
     dim3 grid((a.N + bn - 1) / bn, (a.m_max + bm - 1) / bm, a.batch), block(256);
     if (grid.y == 0 || grid.x == 0) return hipSuccess;
 #define IM_GEMM_CASE(E)                                                                  \
     case E:                                                                              \
-        if (a.big_tile) hipLaunchKernelGGL((gemm_nt_kernel<128, 128, E>), grid, block, 0, s, a); \
-        else hipLaunchKernelGGL((gemm_nt_kernel<64, 64, E>), grid, block, 0, s, a);      \
+        if (a.big_tile) hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 32, E>), grid, block, 0, s, a);   \
+        else if (k64) hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 64, E>), grid, block, 0, s, a);      \
+        else hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 32, E>), grid, block, 0, s, a);               \
         break;
     switch (a.epi) {
         IM_GEMM_CASE(EPI_BIAS)

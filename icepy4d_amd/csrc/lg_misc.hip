@@ -75,6 +75,8 @@ hipError_t launch_layernorm_gelu(float* h, long bstride, const int* n_ptr, int n
 //   out0 = act0(x . w0 + b0)   token confidence (`lightglue/lightglue.py:77-89`) or matchability logit (`:281-282`)
 //   out1 = sigmoid(x . w1 + b1) matchability (`:284-285`)
 // and an integer count of rows with out0 < thr (the early-stop statistic, `:571-579`).
+static constexpr int RD_ROWS = 8;  // rows per wave: one counter atomic per block of 32 rows instead of one per row
+
 __global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ x, long bstride, const int* __restrict__ n_ptr,
                                                       const float* __restrict__ w0, const float* __restrict__ b0, int act0,
                                                       const float* __restrict__ w1, const float* __restrict__ b1,
@@ -82,32 +84,49 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ x
                                                       float* __restrict__ out1, long out_bstride, float thr,
                                                       int* __restrict__ counter, const int* __restrict__ active) {
     if (active && *active == 0) return;
-    const int b = blockIdx.y, lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= n_ptr[b]) return;
+    __shared__ int blk_cnt;
+    const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = n_ptr[b];
+    const int row0 = (blockIdx.x * 4 + wave) * RD_ROWS;
+    if (blockIdx.x * 4 * RD_ROWS >= n) return;  // block-uniform
+    if (threadIdx.x == 0) blk_cnt = 0;
+    __syncthreads();
     const int l = sel ? *sel : 0;
-    const float4 v = *reinterpret_cast<const float4*>(x + (long)b * bstride + (long)row * 256 + lane * 4);
-    if (w0) {
-        const float4 w = *reinterpret_cast<const float4*>(w0 + (long)l * 256 + lane * 4);
-        float d = wave_sum(v.x * w.x + v.y * w.y + v.z * w.z + v.w * w.w) + b0[l];
-        if (act0) d = sigmoidf(d);
-        if (lane == 0) {
-            out0[(long)b * out_bstride + row] = d;
-            if (counter && d < thr) atomicAdd(counter, 1);
+    float4 wa = make_float4(0.f, 0.f, 0.f, 0.f), wb = wa;
+    float ba = 0.f, bb = 0.f;
+    if (w0) { wa = *reinterpret_cast<const float4*>(w0 + (long)l * 256 + lane * 4); ba = b0[l]; }
+    if (w1) { wb = *reinterpret_cast<const float4*>(w1 + (long)l * 256 + lane * 4); bb = b1[l]; }
+    int cnt = 0;
+#pragma unroll
+    for (int i = 0; i < RD_ROWS; ++i) {
+        const int row = row0 + i;
+        if (row >= n) break;  // wave-uniform
+        const float4 v = *reinterpret_cast<const float4*>(x + (long)b * bstride + (long)row * 256 + lane * 4);
+        if (w0) {
+            float d = wave_sum(v.x * wa.x + v.y * wa.y + v.z * wa.z + v.w * wa.w) + ba;
+            if (act0) d = sigmoidf(d);
+            if (lane == 0) {
+                out0[(long)b * out_bstride + row] = d;
+                if (d < thr) ++cnt;
+            }
+        }
+        if (w1) {
+            const float d = sigmoidf(wave_sum(v.x * wb.x + v.y * wb.y + v.z * wb.z + v.w * wb.w) + bb);
+            if (lane == 0) out1[(long)b * out_bstride + row] = d;
         }
     }
-    if (w1) {
-        const float4 w = *reinterpret_cast<const float4*>(w1 + (long)l * 256 + lane * 4);
-        const float d = sigmoidf(wave_sum(v.x * w.x + v.y * w.y + v.z * w.z + v.w * w.w) + b1[l]);
-        if (lane == 0) out1[(long)b * out_bstride + row] = d;
+    if (counter) {
+        if (lane == 0 && cnt) atomicAdd(&blk_cnt, cnt);
+        __syncthreads();
+        if (threadIdx.x == 0 && blk_cnt) atomicAdd(counter, blk_cnt);
     }
 }
 
 hipError_t launch_rowdot(const float* x, long bstride, const int* n_ptr, int n_max, const float* w0, const float* b0, int act0,
                          const float* w1, const float* b1, const int* sel, float* out0, float* out1, long out_bstride,
                          float thr, int* counter, const int* active, hipStream_t s) {
-    hipLaunchKernelGGL(rowdot_kernel, dim3((n_max + 3) / 4, 2), dim3(256), 0, s, x, bstride, n_ptr, w0, b0, act0, w1, b1, sel,
-                       out0, out1, out_bstride, thr, counter, active);
+    hipLaunchKernelGGL(rowdot_kernel, dim3((n_max + 4 * RD_ROWS - 1) / (4 * RD_ROWS), 2), dim3(256), 0, s, x, bstride, n_ptr, w0, b0, act0, w1,
+                       b1, sel, out0, out1, out_bstride, thr, counter, active);
     return hipGetLastError();
 }
 

@@ -43,7 +43,7 @@ def write_record(table: torch.Tensor, row: int, epoch: int, n: torch.Tensor, mat
     """Device-side (no host sync): fill one row from the engine's output buffers."""
     K = matches0.shape[0]
     r = table[row]
-    r[0] = epoch
+    r[0:1].fill_(epoch)   # a fill kernel (a scalar assignment would be a host->device copy: not capturable)
     r[1:3] = n[:2]
     r[3] = (matches0 > -1).sum().to(torch.int32)
     r[4] = info[0]
@@ -81,27 +81,100 @@ def decode_record(rec: np.ndarray, max_kpts: int) -> dict:
 
 
 class SequenceMatcher:
-    """SuperPoint + LightGlue over a list of stereo pairs on one GPU, results kept on the device."""
+    """SuperPoint + LightGlue over a list of stereo pairs on one GPU, results kept on the device.
+
+    A pair is ~200 kernel launches, none of which needs the host (counts, early stop and pruning are device state),
+    so the whole pair is captured once into a HIP graph and replayed per epoch: the input pair is copied into a
+    static device buffer, the graph runs, the record row is copied out. `use_graph=False` enqueues the launches
+    directly (same results bit for bit)."""
 
     def __init__(self, engine, height: int, width: int, max_keypoints: int = 4096, nms_radius: int = 4,
                  detection_threshold: float = 0.0005, remove_borders: int = 4, depth_confidence: float = 0.95,
-                 width_confidence: float = 0.99, filter_threshold: float = 0.1):
+                 width_confidence: float = 0.99, filter_threshold: float = 0.1, use_graph: bool = True):
         self.e = engine
         self.h, self.w, self.k = height, width, max_keypoints
         self.sp = (nms_radius, detection_threshold, remove_borders)
         self.lg = dict(depth_confidence=depth_confidence, width_confidence=width_confidence, filter_threshold=filter_threshold)
         engine.reserve(height, width, 2, max_keypoints)
+        self.use_graph = use_graph
+        self._graph = None
+        self._inp = torch.zeros(2, height, width, dtype=torch.uint8, device=engine.device)
+        self._rec = new_table(1, engine.max_kpts, engine.device)
 
-    def match_pair(self, pair_u8: torch.Tensor, epoch: int, table: torch.Tensor, row: int) -> None:
-        """pair_u8: device uint8 [2, H, W]. Enqueues the whole pair and its record; never synchronises."""
+    def _enqueue(self, pair_u8: torch.Tensor) -> None:
         e = self.e
         e.superpoint(pair_u8, self.sp[0], self.sp[1], self.sp[2], self.k)
         e.lightglue((self.w, self.h), (self.w, self.h), **self.lg)
-        write_record(table, row, epoch, e.n, e.matches[0], e.mscores[0], e.info)
+
+    def _capture(self) -> None:
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream(device=self.e.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):  # warm-up outside capture: lazy kernel attributes, allocator pools
+            for _ in range(2):
+                self._enqueue(self._inp)
+                write_record(self._rec, 0, 0, self.e.n, self.e.matches[0], self.e.mscores[0], self.e.info)
+        cur.wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._enqueue(self._inp)
+            write_record(self._rec, 0, 0, self.e.n, self.e.matches[0], self.e.mscores[0], self.e.info)
+        self._graph = g
+
+    def match_pair(self, pair_u8: torch.Tensor, epoch: int, table: torch.Tensor, row: int) -> None:
+        """pair_u8: device uint8 [2, H, W]. Enqueues the whole pair and its record; never synchronises."""
+        if not self.use_graph:
+            self._enqueue(pair_u8)
+            write_record(table, row, epoch, self.e.n, self.e.matches[0], self.e.mscores[0], self.e.info)
+            return
+        if self._graph is None:
+            self._capture()
+        self._inp.copy_(pair_u8, non_blocking=True)
+        self._graph.replay()
+        table[row].copy_(self._rec[0], non_blocking=True)
+        table[row, 0:1].fill_(epoch)
 
     def run(self, pairs: Sequence[torch.Tensor], epochs: Sequence[int], table: Optional[torch.Tensor] = None) -> torch.Tensor:
         if table is None:
-            table = new_table(len(epochs), self.k, self.e.device)
+            table = new_table(len(epochs), self.e.max_kpts, self.e.device)
         for row, (p, ep) in enumerate(zip(pairs, epochs)):
             self.match_pair(p, ep, table, row)
         return table
+
+
+class PairPipeline:
+    """`n_streams` independent (engine, HIP stream, captured graph) slots on one GPU; pairs are dealt round-robin.
+
+    One 1080p / 4096-keypoint pair does not fill the chip at every stage (the attention launches are exactly one
+    4-wave block per CU, the small GEMMs and the selection kernels much less), so two pairs in flight on separate
+    streams overlap one pair's latency-bound stages with the other's MFMA-bound ones. Each slot owns its context and
+    workspace; results are written to disjoint rows of the caller's table. Launches are made on side streams, never
+    on the legacy null stream (graph launches there serialise against every other stream)."""
+
+    def __init__(self, make_engine, height: int, width: int, max_keypoints: int = 4096, n_streams: int = 2,
+                 use_graph: bool = True, **matcher_conf):
+        self.slots = []
+        for _ in range(max(1, n_streams)):
+            eng = make_engine()
+            stream = torch.cuda.Stream(device=eng.device)
+            with torch.cuda.stream(stream):
+                sm = SequenceMatcher(eng, height, width, max_keypoints, use_graph=use_graph, **matcher_conf)
+            self.slots.append((eng, stream, sm))
+        self._next = 0
+        self.device = self.slots[0][0].device
+        self.max_kpts = self.slots[0][0].max_kpts
+
+    def match_pair(self, pair_u8: torch.Tensor, epoch: int, table: torch.Tensor, row: int) -> None:
+        eng, stream, sm = self.slots[self._next]
+        self._next = (self._next + 1) % len(self.slots)
+        with torch.cuda.stream(stream):
+            sm.match_pair(pair_u8, epoch, table, row)
+
+    def synchronize(self) -> None:
+        for _, stream, _ in self.slots:
+            stream.synchronize()
+
+    def close(self) -> None:
+        for eng, _, _ in self.slots:
+            eng.close()

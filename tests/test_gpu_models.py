@@ -307,3 +307,34 @@ def test_superglue_matcher_api():
             geometric_verification=GeometricVerification.PYDEGENSAC, threshold=2)
     d = m.mkpts1 - m.mkpts0
     assert len(d) > 10 and np.mean(np.all(np.abs(d - np.median(d, 0)) < 3, 1)) > 0.8
+
+
+# ------------------------------------------------------------------------------------------- sequence driver
+def test_sequence_graph_equals_direct_and_oracle():
+    """The HIP-graph replay path gives bit-identical records to direct launches, and the records decode to the
+    oracle's matches on a translated pair (end-to-end match-index parity)."""
+    from icepy4d_amd.engine import Engine
+    from icepy4d_amd import sequence as sq
+    o = oracle()
+    lg_sd = synthetic.lightglue_state_dict(0, "passthrough")
+    e = Engine(0)
+    e.load_state_dict("superpoint", SP_SD)
+    e.load_state_dict("lightglue", lg_sd)
+    pairs_np = [synthetic.translated_pair(s, 240, 320) for s in (1, 2, 3)]
+    pairs = [torch.from_numpy(np.stack(p)).cuda() for p in pairs_np]
+    K = 512
+    tabs = []
+    for use_graph in (False, True):
+        sm = sq.SequenceMatcher(e, 240, 320, K, use_graph=use_graph)
+        tabs.append(sm.run(pairs, [10, 11, 12]).cpu())
+    torch.cuda.synchronize()
+    assert torch.equal(tabs[0], tabs[1])
+    for row, (a, b) in enumerate(pairs_np):
+        rec = sq.decode_record(tabs[1][row].numpy(), e.max_kpts)
+        assert rec["epoch"] == 10 + row and rec["stop"] == 9
+        F0, F1, m0, mconf, ref = o.match_images_lightglue(a, b, SP_SD, lg_sd, max_keypoints=K)
+        assert rec["n0"] == len(F0[0]) and rec["n1"] == len(F1[0])
+        agree = np.mean(rec["matches0"] == m0)
+        assert agree > 0.97, agree
+        assert rec["n_matches"] > 50
+    e.close()
