@@ -49,12 +49,12 @@ def kernel_flops(name, n_images=2, n0=KPTS, n1=KPTS):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pool", type=int, default=4, help="distinct synthetic pairs per rank (cycled)")
     ap.add_argument("--no-graph", action="store_true", help="enqueue launches directly instead of replaying a HIP graph")
-    ap.add_argument("--streams", type=int, default=2, help="pairs in flight per GPU (independent contexts on separate HIP streams)")
+    ap.add_argument("--streams", type=int, default=3, help="pairs in flight per GPU (independent contexts on separate HIP streams)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))

@@ -63,6 +63,10 @@ struct ConvArgs {
     int B = 1, H = 0, W = 0, Cin = 0, Cout = 0;
     int pool = 0;                // fused 2x2 max-pool (floor) after bias + ReLU
     int relu = 1;
+    // fused first layer: when img != nullptr the input is conv1a(img / 255) computed on the fly (Cin must be 64)
+    const uint8_t* img = nullptr; // uint8 gray [B][H][W]
+    const float* w1 = nullptr;    // conv1a weights [9][64]
+    const float* b1 = nullptr;    // conv1a bias [64]
 };
 hipError_t launch_conv3x3(const ConvArgs& a, hipStream_t s);
 // conv1a: u8 gray [B][H][W] -> (x / 255) * w + b, ReLU -> NHWC [B][H][W][64]; w packed [9][64]

@@ -281,8 +281,8 @@ int im_superpoint_forward(im_ctx* ctx, const uint8_t* d_gray, int n_images, int 
     hipStream_t s = (hipStream_t)stream;
     const SuperPointW& W = ctx->sp;
     const int B = n_images, K = ctx->max_kpts;
-    IM_LAUNCH(ctx, "conv1a", s, launch_conv1a(d_gray, W.c1a_w, W.c1a_b, ws->act0, B, h, w, s));
-    float* src = ws->act0;
+    // conv1a is fused into conv1b's patch producer: the full-resolution 64-channel activation never touches HBM
+    float* src = nullptr;
     float* dst = ws->act1;
     int ch = h, cw_ = w;
     static const int pool_after[7] = {1, 0, 1, 0, 1, 0, 0};  // conv1b, 2a, 2b, 3a, 3b, 4a, 4b
@@ -290,10 +290,13 @@ int im_superpoint_forward(im_ctx* ctx, const uint8_t* d_gray, int n_images, int 
         ConvArgs a;
         a.in = src; a.w = W.cw[i]; a.bias = W.cb[i]; a.out = dst; a.B = B; a.H = ch; a.W = cw_;
         a.Cin = SP_CIN[i]; a.Cout = SP_COUT[i]; a.pool = pool_after[i]; a.relu = 1;
+        if (i == 0) { a.img = d_gray; a.w1 = W.c1a_w; a.b1 = W.c1a_b; }
         IM_LAUNCH(ctx, SP_CONV3[i], s, launch_conv3x3(a, s));
         if (pool_after[i]) { ch /= 2; cw_ /= 2; }
-        std::swap(src, dst);
+        src = dst;
+        dst = (dst == ws->act1) ? ws->act0 : ws->act1;
     }
+    dst = (src == ws->act1) ? ws->act0 : ws->act1;
     // src = feat [B][hc][wc][128] (in act1), dst = act0 free
     const int hc = ch, wc = cw_;
     const long cells = (long)B * hc * wc;
