@@ -1,0 +1,105 @@
+"""Full-size runs of the BASELINE.json configurations: parity against the oracle where it finishes in seconds
+(config 2: 1080p, 4096 keypoints) and size-independent properties where it does not (config 5: 12 MP, 16384
+keypoints, SuperGlue + Sinkhorn): determinism, mutual consistency of the match tables, Sinkhorn marginals."""
+import numpy as np
+import pytest
+import torch
+
+from icepy4d_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+SP_SD = synthetic.superpoint_state_dict(0)
+
+
+def mutual_consistency(m0, m1):
+    i = np.where(m0 > -1)[0]
+    assert (m0[i] < len(m1)).all() and np.array_equal(m1[m0[i]], i)
+    j = np.where(m1 > -1)[0]
+    assert np.array_equal(m0[m1[j]], j)
+
+
+def test_config2_full_size_vs_oracle():
+    """1080 x 1920, 4096 keypoints, SuperPoint + LightGlue: keypoints, descriptors, match indices vs the CPU oracle."""
+    from icepy4d_amd.engine import Engine
+    from oracle import ref_cpu as o
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    lg_sd = synthetic.lightglue_state_dict(0, "passthrough")
+    img0, img1 = synthetic.translated_pair(0, 1080, 1920, 40, 8)
+    e = Engine(0)
+    e.load_state_dict("superpoint", SP_SD)
+    e.load_state_dict("lightglue", lg_sd)
+    e.reserve(1080, 1920, 2, 4096)
+    pair = torch.from_numpy(np.stack([img0, img1])).cuda()
+    outs = []
+    for _ in range(2):
+        e.superpoint(pair, 4, 0.0005, 4, 4096)
+        e.lightglue((1920, 1080), (1920, 1080))
+        torch.cuda.synchronize()
+        k0, d0, s0 = e.features_to_host(0)
+        k1, d1, s1 = e.features_to_host(1)
+        outs.append((k0, d0, s0, k1, d1, s1, e.matches_to_host(len(k0), len(k1))))
+    a, b = outs
+    for x, y in zip(a[:6], b[:6]):
+        assert np.array_equal(x, y)                      # bit-identical across runs
+    assert np.array_equal(a[6]["matches0"], b[6]["matches0"]) and np.array_equal(a[6]["matching_scores0"], b[6]["matching_scores0"])
+    k0, d0, s0, k1, d1, s1, out = a
+    mutual_consistency(out["matches0"], out["matches1"])
+    F0, F1, m0, mconf, ref = o.match_images_lightglue(img0, img1, SP_SD, lg_sd, max_keypoints=4096)
+    assert k0.shape == F0[0].shape == (4096, 2) and out["stop"] == ref["stop"]
+    idx = {tuple(p): i for i, p in enumerate(k0)}
+    common = [(idx[tuple(p)], j) for j, p in enumerate(F0[0]) if tuple(p) in idx]
+    assert len(common) >= 0.97 * 4096, len(common)
+    ii, jj = np.array(common).T
+    assert np.abs(d0[ii] - F0[1].T[jj]).max() < 1e-4
+    assert np.abs(s0[ii] - F0[2][jj]).max() < 1e-5
+    ours = {(tuple(k0[i]), tuple(k1[j])) for i, j in enumerate(out["matches0"]) if j > -1}
+    theirs = {(tuple(F0[0][i]), tuple(F1[0][j])) for i, j in enumerate(m0) if j > -1}
+    assert len(theirs) > 500
+    assert len(ours & theirs) >= 0.95 * len(theirs), (len(ours & theirs), len(theirs), len(ours))
+    d = np.array([np.array(q) - np.array(p) for p, q in ours])
+    assert np.mean(np.all(np.abs(d - np.array([40, 8])) < 1.5, 1)) > 0.7   # matches follow the true translation
+    e.close()
+
+
+def test_config5_12mp_superglue_properties():
+    """12 MP pair, up to 16384 keypoints, SuperGlue with 20 Sinkhorn iterations (1 GB score matrix)."""
+    from icepy4d_amd.engine import Engine
+    from icepy4d_amd._lib import ptr, stream_ptr
+    H, W, K = 3000, 4000, 16384
+    img0, img1 = synthetic.translated_pair(5, H, W, 48, 16)
+    e = Engine(0)
+    e.load_state_dict("superpoint", SP_SD)
+    e.load_state_dict("superglue", synthetic.superglue_state_dict(0, "passthrough"))
+    e.reserve(H, W, 2, K)
+    pair = torch.from_numpy(np.stack([img0, img1])).cuda()
+    res = []
+    for _ in range(2):
+        e.superpoint(pair, 3, 0.001, 4, K, flavour=1)
+        e.superglue((H, W), (H, W), sinkhorn_iterations=20, match_threshold=0.3)
+        torch.cuda.synchronize()
+        n0, n1 = int(e.n[0]), int(e.n[1])
+        res.append((n0, n1, e.kpts[0, :n0].cpu().numpy(), e.scores[0, :n0].cpu().numpy(), e.matches_to_host(n0, n1)))
+    (n0, n1, kp, sc, out), (_, _, kp2, sc2, out2) = res
+    assert n0 == K and n1 == K
+    assert np.array_equal(kp, kp2) and np.array_equal(out["matches0"], out2["matches0"])        # deterministic
+    assert (np.diff(sc) <= 0).all()                                                              # top-k sorted descending
+    assert kp[:, 0].min() >= 4 and kp[:, 0].max() < W - 4 and kp[:, 1].min() >= 4 and kp[:, 1].max() < H - 4
+    assert len({tuple(p) for p in kp}) == K                                                     # no duplicate keypoints
+    mutual_consistency(out["matches0"], out["matches1"])
+    v = out["matches0"] > -1
+    assert v.sum() > 1000 and (out["matching_scores0"][v] > 0.3).all() and (out["matching_scores0"] <= 1.0 + 1e-5).all()
+    k1 = e.kpts[1, :n1].cpu().numpy()
+    d = k1[out["matches0"][v]] - kp[v]
+    assert np.mean(np.all(np.abs(d - np.array([48, 16])) < 1.5, 1)) > 0.7
+    # Sinkhorn marginals on a 4096 x 3000 random score block: after the last v-update every column of
+    # exp(Z) sums to exp(log_nu - norm), i.e. logsumexp_i Z[i][j] = log_nu[j] - norm = 0 (and log m for the dustbin)
+    m, n = 4096, 3000
+    g = torch.Generator(device="cuda").manual_seed(1)
+    zin = torch.randn(m, n, device="cuda", generator=g) * 2
+    zout = torch.empty(m + 1, n + 1, device="cuda")
+    e.ctx.call("im_log_optimal_transport", ptr(zin), m, n, n, 1.0, 20, ptr(zout), stream_ptr())
+    torch.cuda.synchronize()
+    col = torch.logsumexp(zout.double(), 0).cpu().numpy()
+    assert np.abs(col[:n]).max() < 1e-4 and abs(col[n] - np.log(m)) < 1e-4
+    e.close()
