@@ -64,10 +64,17 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
     import torch.distributed as dist
+    # debugging aid only: IM_BENCH_ONE_DEVICE=1 runs every rank on cuda:0 with a gloo group (1-GPU box rehearsal of N > 1)
+    one_dev = os.environ.get("IM_BENCH_ONE_DEVICE") == "1"
+    if one_dev:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if one_dev:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from icepy4d_amd import synthetic
     from icepy4d_amd.engine import Engine
@@ -104,17 +111,17 @@ def main():
         sm.match_pair(pool[i % len(pool)], epochs[i % len(epochs)], scratch, i % scratch.shape[0])
     sm.synchronize()
     if world > 1:
-        all_gather_tables(scratch)
+        all_gather_tables(scratch.cpu() if one_dev else scratch)
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         sm.match_pair(pool[(args.warmup + i) % len(pool)], epochs[args.warmup + i], table, i)
     sm.synchronize()
-    full = all_gather_tables(table)
+    full = all_gather_tables(table.cpu() if one_dev else table)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if one_dev else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     n_pairs = args.steps * world
@@ -163,8 +170,14 @@ def main():
         dom = max(gstat, key=lambda k: gstat[k][0])
         ms, cnt, fl = gstat[dom]
         ach = fl / (ms * 1e-3) / 1e12
+        traffic = None  # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_traffic.json), if any
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as fh:
+                traffic = json.load(fh).get(dom, {}).get("traffic_bytes")
+        except OSError:
+            pass
         result["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                              "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None, "avg_launch_ms": ms / cnt,
+                              "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "avg_launch_ms": ms / cnt,
                               "launches_per_pair": cnt / prof_steps, "algorithmic_gflop_per_launch": fl / cnt / 1e9,
                               "share_of_pair_time": ms / tot}
         result["kernel_ms_per_pair"] = {k: round(v["total_ms"] / prof_steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}

@@ -80,6 +80,36 @@ def decode_record(rec: np.ndarray, max_kpts: int) -> dict:
                 matching_scores0=rec[HEADER + K:HEADER + 2 * K].view(np.float32)[:max(int(rec[1]), 0)])
 
 
+def save_table(path: str, table: torch.Tensor, max_kpts: int) -> None:
+    """Checkpoint of a (partial) match table: the resumable artefact of a sharded run (the reference pickles the whole
+    `Epoch` per epoch, `core/epoch.py:455-473`, driven by `cfg.proc.load_existing_results`, `main_dev.py:70-92`)."""
+    t = table.detach().cpu().numpy()
+    t = t[t[:, 0] >= 0]
+    np.savez_compressed(path, records=t[np.argsort(t[:, 0], kind="stable")], max_kpts=np.int64(max_kpts))
+
+
+def load_table(path: str):
+    """-> (records int32 [n, 8 + 2K] sorted by epoch, K). `pending_epochs` tells a resumed run what is left."""
+    z = np.load(path)
+    return z["records"], int(z["max_kpts"])
+
+
+def pending_epochs(n_epochs: int, done_records: Optional[np.ndarray]) -> List[int]:
+    """Epochs without a successful record (n_matches >= 0) yet."""
+    done = set()
+    if done_records is not None and len(done_records):
+        done = {int(r[0]) for r in done_records if r[3] >= 0}
+    return [e for e in range(n_epochs) if e not in done]
+
+
+def records_to_features(rec: np.ndarray, max_kpts: int, kpts0: np.ndarray, kpts1: np.ndarray):
+    """Matched point arrays (mkpts0, mkpts1, mconf) of one record, the inputs of
+    `core.Features.append_features_from_numpy` / `sfm.RelativeOrientation` (`main_dev.py:160-172, 220-226`)."""
+    r = decode_record(rec, max_kpts)
+    v = r["matches0"] > -1
+    return kpts0[: r["n0"]][v], kpts1[r["matches0"][v]], r["matching_scores0"][v]
+
+
 class SequenceMatcher:
     """SuperPoint + LightGlue over a list of stereo pairs on one GPU, results kept on the device.
 

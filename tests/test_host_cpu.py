@@ -204,3 +204,22 @@ def test_all_gather_match_tables_gloo_world2(tmp_path):
                         "--master-port", "29531", str(script)], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert r.stdout.count("ok") == 2
+
+
+def test_match_table_checkpoint_and_resume(tmp_path):
+    from icepy4d_amd import sequence as sq
+    K = 8
+    t = sq.new_table(4, K, "cpu")
+    for row, ep in enumerate([5, 1, 3]):
+        m0 = torch.full((K,), -1, dtype=torch.int32)
+        m0[0] = ep
+        sq.write_record(t, row, ep, torch.tensor([K, K], dtype=torch.int32), m0, torch.ones(K), torch.tensor([9, 0, 0, 0], dtype=torch.int32))
+    path = str(tmp_path / "table.npz")
+    sq.save_table(path, t, K)                      # the unused 4th row (epoch -1) is dropped
+    rec, k = sq.load_table(path)
+    assert k == K and rec[:, 0].tolist() == [1, 3, 5]
+    assert sq.pending_epochs(6, rec) == [0, 2, 4]
+    kp0 = np.arange(2 * K, dtype=np.float32).reshape(K, 2)
+    kp1 = kp0 + 100
+    a, b, conf = sq.records_to_features(rec[1], K, kp0, kp1)
+    assert a.shape == (1, 2) and np.array_equal(b[0], kp1[3]) and conf[0] == 1.0
