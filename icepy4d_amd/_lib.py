@@ -12,7 +12,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libicematch.so")
+LIB_PATH = os.environ.get("ICEMATCH_LIB") or os.path.join(CSRC, "libicematch.so")  # env override: A/B builds
 
 _lib: Optional[C.CDLL] = None
 

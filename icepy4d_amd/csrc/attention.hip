@@ -45,20 +45,27 @@ __device__ __forceinline__ float4 load_row4(const float* __restrict__ base, int 
     *reinterpret_cast<float4*>((dst) + ((tid >> 4) + 32) * (stride) + (tid & 15) * 4) = r##2;                 \
     *reinterpret_cast<float4*>((dst) + ((tid >> 4) + 48) * (stride) + (tid & 15) * 4) = r##3;
 
-// S^T for one 64-key tile: two 32-key halves, 32 MFMAs each; contraction order d = s (hh = 0) / 32 + s (hh = 1)
+// S^T for one 64-key tile: two 32-key halves, 32 MFMAs each; contraction order d = s (hh = 0) / 32 + s (hh = 1).
+// The K fragments of step t+1 are requested from LDS before the MFMAs of step t are issued.
 __device__ __forceinline__ void qk_tile(const float* __restrict__ sK, int c, int hh, const float (&qf)[32], f32x16& sa, f32x16& sb) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { sa[r] = 0.f; sb[r] = 0.f; }
     const float* ka = sK + c * KS + hh * 32;
     const float* kb = ka + 32 * KS;
+    float4 fa = *reinterpret_cast<const float4*>(ka);
+    float4 fb = *reinterpret_cast<const float4*>(kb);
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-        const float4 fa = *reinterpret_cast<const float4*>(ka + t * 4);
-        const float4 fb = *reinterpret_cast<const float4*>(kb + t * 4);
+        float4 ga = fa, gb = fb;
+        if (t < 7) {
+            ga = *reinterpret_cast<const float4*>(ka + (t + 1) * 4);
+            gb = *reinterpret_cast<const float4*>(kb + (t + 1) * 4);
+        }
         sa = mfma32(fa.x, qf[4 * t + 0], sa); sb = mfma32(fb.x, qf[4 * t + 0], sb);
         sa = mfma32(fa.y, qf[4 * t + 1], sa); sb = mfma32(fb.y, qf[4 * t + 1], sb);
         sa = mfma32(fa.z, qf[4 * t + 2], sa); sb = mfma32(fb.z, qf[4 * t + 2], sb);
         sa = mfma32(fa.w, qf[4 * t + 3], sa); sb = mfma32(fb.w, qf[4 * t + 3], sb);
+        fa = ga; fb = gb;
     }
 }
 
@@ -75,6 +82,10 @@ __device__ __forceinline__ void softmax_tile(f32x16& sa, f32x16& sb, int kb, int
         }
         mx = fmaxf(mx, fmaxf(sa[r], sb[r]));
     }
+#ifdef IM_ABL_NO_SOFTMAX
+    asm volatile("" ::"v"(mx));
+    return;
+#endif
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     const float m_new = fmaxf(m_run, mx);
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
@@ -92,19 +103,29 @@ __device__ __forceinline__ void softmax_tile(f32x16& sa, f32x16& sb, int kb, int
     for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
 }
 
-// O^T += V^T . P^T for one 64-key tile: register r of P is key acc_row(r, hh) of its half
+// O^T += V^T . P^T for one 64-key tile: register r of P is key acc_row(r, hh) of its half. V fragments are read
+// from LDS in groups of four key rows, one group ahead of the MFMAs that consume them.
 __device__ __forceinline__ void pv_tile(const float* __restrict__ sV, int c, int hh, const f32x16& pa, const f32x16& pb, f32x16& o0, f32x16& o1) {
+    const float* vbase = sV + (4 * hh) * VS + c;   // acc_row(r, hh) = (r & 3) + 8 * (r >> 2) + 4 * hh
+    float va[4], vb[4], na[4], nb[4];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const float* vp = sV + acc_row(r, hh) * VS + c;
-        o0 = mfma32(vp[0], pa[r], o0);
-        o1 = mfma32(vp[32], pa[r], o1);
-    }
+    for (int q = 0; q < 4; ++q) { va[q] = vbase[q * VS]; vb[q] = vbase[q * VS + 32]; }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const float* vp = sV + (32 + acc_row(r, hh)) * VS + c;
-        o0 = mfma32(vp[0], pb[r], o0);
-        o1 = mfma32(vp[32], pb[r], o1);
+    for (int g = 0; g < 8; ++g) {      // group g: half g >> 2, key rows 8 * (g & 3) + (0..3) (+ 4 hh)
+        if (g < 7) {
+            const float* vn = vbase + (32 * ((g + 1) >> 2) + 8 * ((g + 1) & 3)) * VS;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { na[q] = vn[q * VS]; nb[q] = vn[q * VS + 32]; }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = 4 * (g & 3) + q;
+            const float p = (g < 4) ? pa[r] : pb[r];
+            o0 = mfma32(va[q], p, o0);
+            o1 = mfma32(vb[q], p, o1);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { va[q] = na[q]; vb[q] = nb[q]; }
     }
 }
 
@@ -166,14 +187,34 @@ __global__ __launch_bounds__(256, 2) void flash_attn_f32_kernel(AttnArgs a) {
 
     // iteration t: stage K(t+2), V(t+1); prefetch K(t+3), V(t+2); QK^T of tile t+1 with the softmax of tile t in
     // its shadow (one basic block, so the scheduler can interleave MFMA and VALU); PV of tile t; one barrier
+// Instruction-group pipeline of one step (LLVM sched_group_barrier; masks: 0x008 MFMA, 0x002 VALU, 0x100 DS read,
+// 0x200 DS write, 0x020 VMEM read): staging stores + prefetch loads first, then the 64 QK^T MFMAs with the
+// previous tile's softmax VALU work and the K-fragment reads in their shadow, then the 64 PV MFMAs with the
+// V-fragment reads running two pairs ahead.
 #ifndef IM_ATTN_NO_SCHED
+#define IM_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
 #define IM_SCHED_QK_SOFTMAX                                                    \
-    _Pragma("unroll") for (int _i = 0; _i < 64; ++_i) {                        \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); /* 1 MFMA */        \
-        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0); /* 4 VALU */        \
+    IM_SGB(0x200, 8); IM_SGB(0x020, 8);                                        \
+    IM_SGB(0x100, 4);                                                          \
+    _Pragma("unroll") for (int _i = 0; _i < 16; ++_i) {                        \
+        IM_SGB(0x008, 4); IM_SGB(0x002, 14); IM_SGB(0x100, 1);                 \
+    }                                                                          \
+    IM_SGB(0x100, 4);                                                          \
+    _Pragma("unroll") for (int _i = 0; _i < 32; ++_i) {                        \
+        IM_SGB(0x008, 2); IM_SGB(0x100, 1);                                    \
     }
 #else
 #define IM_SCHED_QK_SOFTMAX
+#endif
+#ifdef IM_ABL_NO_STAGE
+#define IM_ABL_STAGE(...) (void)kw; (void)vw;
+#else
+#define IM_ABL_STAGE(...) __VA_ARGS__
+#endif
+#ifdef IM_ABL_NO_BARRIER
+#define IM_ABL_BARRIER
+#else
+#define IM_ABL_BARRIER __syncthreads();
 #endif
 #define IM_STEP(TAIL)                                                                   \
     {                                                                                   \
@@ -181,16 +222,16 @@ __global__ __launch_bounds__(256, 2) void flash_attn_f32_kernel(AttnArgs a) {
         float* const kr = sK0 + ((t + 1) & 1) * (KT * KS);                              \
         float* const vw = sV0 + ((t + 1) & 1) * (KT * VS);                              \
         float* const vr = sV0 + (t & 1) * (KT * VS);                                    \
-        IM_STORE_TILE(rk, kw, KS)                                                       \
+        IM_ABL_STAGE(IM_STORE_TILE(rk, kw, KS)                                          \
         IM_STORE_TILE(rv, vw, VS)                                                       \
         IM_LOAD_TILE(rk, K, (t + 3) * KT)                                               \
-        IM_LOAD_TILE(rv, V, (t + 2) * KT)                                               \
+        IM_LOAD_TILE(rv, V, (t + 2) * KT))                                              \
         qk_tile(kr, c, hh, qf, na, nb);                                                 \
         softmax_tile<TAIL>(sa, sb, t * KT, nk, hh, m_run, l_run, o0, o1);           \
         pv_tile(vr, c, hh, sa, sb, o0, o1);                                             \
         IM_SCHED_QK_SOFTMAX                                                             \
         sa = na; sb = nb;                                                               \
-        __syncthreads();                                                                \
+        IM_ABL_BARRIER                                                                  \
     }
     int t = 0;
     for (; t < nt - 1; ++t) IM_STEP(false)

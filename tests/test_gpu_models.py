@@ -338,3 +338,59 @@ def test_sequence_graph_equals_direct_and_oracle():
         assert agree > 0.97, agree
         assert rec["n_matches"] > 50
     e.close()
+
+
+# ------------------------------------------------------------------------------------------- edge cases
+def test_edge_cases_empty_flat_and_ragged(eng):
+    """No candidates at all (threshold above every score), a flat image (one giant tie plateau), fewer candidates
+    than requested, and an image size that is not a multiple of the 8-pixel cell (reference q4 tiles are 799 x 1199)."""
+    from icepy4d_amd.engine import Engine
+    o = oracle()
+    lg_sd = synthetic.lightglue_state_dict(0, "passthrough")
+    e = Engine(0)
+    e.load_state_dict("superpoint", SP_SD)
+    e.load_state_dict("lightglue", lg_sd)
+    e.reserve(128, 160, 2, 300)
+    img = torch.from_numpy(synthetic.band_limited_noise(np.random.default_rng(3), 101, 157))
+    flat = torch.full_like(img, 128)
+    pair = torch.stack([img, flat]).contiguous().cuda()
+    # (1) threshold above every score: zero keypoints in both images, matcher returns nothing and does not hang
+    e.superpoint(pair, 4, 0.99, 4, 300)
+    e.lightglue((157, 101), (157, 101))
+    torch.cuda.synchronize()
+    assert e.n.tolist() == [0, 0]
+    out = e.matches_to_host(0, 0)
+    assert len(out["matches0"]) == 0 and out["stop"] >= 1
+    # (2) ragged size + flat image: candidates of image 0 follow the oracle, the flat image is one big tie group
+    e.superpoint(pair, 4, 0.0005, 4, 300)
+    e.lightglue((157, 101), (157, 101))
+    torch.cuda.synchronize()
+    n0, n1 = e.n.tolist()
+    with torch.inference_mode():
+        ref = o.superpoint_lg(o.frame_to_tensor(img.numpy()), SP_SD, 300)
+    assert n0 == len(ref["keypoints"])
+    kp = e.kpts[0, :n0].cpu().numpy()
+    assert len({tuple(p) for p in kp} & {tuple(p) for p in ref["keypoints"].numpy()}) >= 0.97 * n0
+    assert kp[:, 0].max() < 152 - 4 and kp[:, 1].max() < 96 - 4      # score map is 96 x 152 (floor to whole cells)
+    kp1 = e.kpts[1, :n1].cpu().numpy()
+    with torch.inference_mode():
+        ref1 = o.superpoint_lg(o.frame_to_tensor(flat.numpy()), SP_SD, 300)   # constant image: large plateaus of equal scores
+    assert n1 == len(ref1["keypoints"]) and len({tuple(p) for p in kp1}) == n1
+    sc1 = e.scores[1, :n1].cpu().numpy()
+    assert np.abs(np.sort(sc1) - np.sort(ref1["keypoint_scores"].numpy())).max() < 1e-5
+    out = e.matches_to_host(n0, n1)
+    assert out["matches0"].shape == (n0,) and out["matches1"].shape == (n1,)
+    # (3) fewer candidates than requested: row-major order, no sorting (`top_k_keypoints` early return)
+    e2 = Engine(0)
+    e2.load_state_dict("superpoint", SP_SD)
+    e2.reserve(128, 160, 1, 4096)
+    e2.superpoint(pair[:1].contiguous(), 4, 0.0005, 4, 4096)
+    torch.cuda.synchronize()
+    n = int(e2.n[0])
+    with torch.inference_mode():
+        ref_all = o.superpoint_lg(o.frame_to_tensor(img.numpy()), SP_SD, 4096)
+    assert n == len(ref_all["keypoints"]) < 4096
+    kp_all = e2.kpts[0, :n].cpu().numpy()
+    flat_idx = kp_all[:, 1] * 1000 + kp_all[:, 0]
+    assert (np.diff(flat_idx) > 0).all()                            # row-major (y, x) order
+    e.close(); e2.close()
