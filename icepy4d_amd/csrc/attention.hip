@@ -133,11 +133,17 @@ __global__ __launch_bounds__(256, 2) void flash_attn_f32_kernel(AttnArgs a) {
     if (a.active && *a.active == 0) return;
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
-    const int z = blockIdx.z, head = blockIdx.y;
+    // XCD-aware block -> tile map: workgroups are dealt round-robin over the 8 XCDs (bid % 8), each with a private
+    // 4 MB L2. The (image, head) index is the fastest-varying part of the linear block id, so with
+    // heads * batch = 8 every query block of one (image, head) lands on the same XCD and that XCD's L2 holds exactly
+    // one K/V set (2 MB at 4096 keys) instead of all eight.
+    const int hz = a.heads * a.batch;
+    const int bid = blockIdx.x;
+    const int head = (bid % hz) % a.heads, z = (bid % hz) / a.heads;
     const int y = a.cross ? (z ^ 1) : z;
     const int nq = a.n_ptr ? a.n_ptr[z] : a.n_max;
     const int nk = a.n_ptr ? a.n_ptr[y] : a.n_max;
-    const int qb = blockIdx.x * 128;
+    const int qb = (bid / hz) * 128;
     if (qb >= nq || nk <= 0) return;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -262,7 +268,7 @@ hipError_t launch_flash_attn(const AttnArgs& a, hipStream_t s) {
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    dim3 grid((a.n_max + 127) / 128, a.heads, a.batch), block(256);
+    dim3 grid(((a.n_max + 127) / 128) * a.heads * a.batch), block(256);
     hipLaunchKernelGGL(flash_attn_f32_kernel, grid, block, lds, s, a);
     return hipGetLastError();
 }

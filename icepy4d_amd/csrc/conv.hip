@@ -38,9 +38,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
     float* sW1 = sImg + IH * IW;                   // [9][64]
     float* sB1 = sW1 + 9 * 64;                     // [64]
 
+    // XCD-aware block -> tile map: linear id = tile_lo (3 bits) + 8 * (slice + nslices * tile_hi). The 64-channel
+    // output slices of one spatial tile share id % 8, i.e. the XCD, and are adjacent in launch order, so the input
+    // patch they all read is served by one L2.
     const int nslices = a.Cout / 64;
-    const int b = blockIdx.z / nslices, co0 = (blockIdx.z % nslices) * 64;
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const int tx = (a.W + TW - 1) / TW, ty = (a.H + TH - 1) / TH;
+    const int ntile = tx * ty * a.B;
+    const int bid = blockIdx.x;
+    const int tile = (bid & 7) + 8 * ((bid >> 3) / nslices);
+    const int co0 = (((bid >> 3) % nslices)) * 64;
+    if (tile >= ntile) return;
+    const int b = tile / (tx * ty);
+    const int trem = tile - b * tx * ty;
+    const int x0 = (trem % tx) * TW, y0 = (trem / tx) * TH;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 31, hh = lane >> 5;
     const float* in = a.in + (long)b * a.H * a.W * a.Cin;
@@ -191,7 +201,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
 
 template <bool POOL, bool FUSE>
 static hipError_t launch_conv_variant(const ConvArgs& a, hipStream_t s) {
-    dim3 grid((a.W + TW - 1) / TW, (a.H + TH - 1) / TH, a.B * (a.Cout / 64)), block(256);
+    const int ntile = ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH) * a.B;
+    dim3 grid(((ntile + 7) / 8) * 8 * (a.Cout / 64)), block(256);
     const size_t lds = (CONV_LDS_FLOATS + (FUSE ? FUSE_LDS_FLOATS : 0)) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {

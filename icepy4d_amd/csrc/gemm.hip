@@ -30,10 +30,14 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
     float* sA = smem;
     float* sB = smem + BM * LDS_LD;
 
-    const int z = blockIdx.z;
+    // XCD-aware block -> tile map: the row-tile index is the fastest-varying part of the linear block id, so (with
+    // a multiple of 8 row tiles) all column tiles of one row tile run on the same XCD and the A rows are fetched
+    // into one L2 instead of up to eight.
+    const int gm = (a.m_max + BM - 1) / BM;
+    const int z = blockIdx.y;
     const int M = a.m_ptr ? a.m_ptr[z] : a.m_max;
     const int Nlive = a.n_ptr ? min(*a.n_ptr, a.N) : a.N;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int m0 = (blockIdx.x % gm) * BM, n0 = (blockIdx.x / gm) * BN;
     if (m0 >= M || n0 >= Nlive) return;
 
     const int tid = threadIdx.x;
@@ -159,8 +163,8 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
     if (a.K % 32 != 0 || (a.A1 && a.ksplit % 64 != 0)) return hipErrorInvalidValue;
     const bool k64 = false;  // 64-deep slabs measured neutral-to-slower on MI355X at the LightGlue shapes; kept for tuning
     const int bm = a.big_tile ? 128 : 64, bn = bm;
-    dim3 grid((a.N + bn - 1) / bn, (a.m_max + bm - 1) / bm, a.batch), block(256);
-    if (grid.y == 0 || grid.x == 0) return hipSuccess;
+    dim3 grid(((a.N + bn - 1) / bn) * ((a.m_max + bm - 1) / bm), a.batch), block(256);
+    if (grid.x == 0) return hipSuccess;
 #define IM_GEMM_CASE(E)                                                                  \
     case E:                                                                              \
         if (a.big_tile) hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 32, E>), grid, block, 0, s, a);   \
