@@ -179,7 +179,10 @@ def main():
         result["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                               "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "avg_launch_ms": ms / cnt,
                               "launches_per_pair": cnt / prof_steps, "algorithmic_gflop_per_launch": fl / cnt / 1e9,
-                              "share_of_pair_time": ms / tot}
+                              "share_of_pair_time": ms / tot,
+                              "measured": "HIP events around each launch in an isolated pass with ONE pair in flight (with several "
+                                          "pairs in flight kernels of different pairs share the chip and per-launch durations are not "
+                                          "kernel properties); rocprofv3 --stats of `bench.py --streams 1` in profiles/ agrees"}
         result["kernel_ms_per_pair"] = {k: round(v["total_ms"] / prof_steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}
         pair_flops = 2 * 351.7e9 + 734.4e9  # C2 algorithmic FLOPs per pair
         result["pair_roofline_frac"] = pair_flops * (n_pairs / dt) / world / (PEAK_F32_MFMA_TFLOPS * 1e12)
