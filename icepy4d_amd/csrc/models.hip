@@ -252,7 +252,7 @@ int im_ctx_reserve(im_ctx* ctx, int max_h, int max_w, int max_images, int max_kp
     A(ws->part, (size_t)((K + 127) / 128 + 1) * (K + 1));
     A(ws->ridx, (size_t)K + 1); A(ws->rval, (size_t)K + 1); A(ws->cbest, (size_t)K + 1);
     A(ws->st, (size_t)1); A(ws->sel, (size_t)4);
-    A(ws->uv, (size_t)4 * (K + 1));
+    A(ws->uv, (size_t)4 * (K + 8));
     if (!ok) {
         for (void* p : ws->allocs) hipFree(p);
         delete ws;

@@ -36,7 +36,29 @@ __global__ __launch_bounds__(256) void sg_kenc_input_kernel(const float* __restr
 // ---- log-domain Sinkhorn (`log_sinkhorn_iterations`, `superglue.py:152-160`), couplings Z = [[sim, a], [a, a]]
 __device__ __forceinline__ float sg_norm(int m, int n) { return -logf((float)m + (float)n); }
 
-// u[i] = log_mu[i] - logsumexp_j(Z[i][j] + v[j]), i in [0, m]; wave per row
+// Both sweeps are single-pass, 16-byte-per-lane streaming reads of the score matrix with an online (running max,
+// rescaled sum) log-sum-exp, so every iteration reads the 4 (M)(N) bytes exactly twice (once per sweep).
+struct OnlineLSE {
+    float m = -INFINITY, s = 0.f;
+    __device__ __forceinline__ void add(float x) {
+        const float mn = fmaxf(m, x);
+        s = s * expf(m - mn) + expf(x - mn);
+        m = mn;
+    }
+    __device__ __forceinline__ void add4(float a, float b, float c, float d) {
+        const float mn = fmaxf(fmaxf(m, fmaxf(a, b)), fmaxf(c, d));
+        s = s * expf(m - mn) + ((expf(a - mn) + expf(b - mn)) + (expf(c - mn) + expf(d - mn)));
+        m = mn;
+    }
+    __device__ __forceinline__ void merge(float om, float os) {
+        const float mn = fmaxf(m, om);
+        if (mn == -INFINITY) return;
+        s = s * expf(m - mn) + os * expf(om - mn);
+        m = mn;
+    }
+};
+
+// u[i] = log_mu[i] - logsumexp_j(Z[i][j] + v[j]), i in [0, m]; wave per row, float4 per lane
 __global__ __launch_bounds__(256) void sinkhorn_row_kernel(const float* __restrict__ sim, int ld, const int* __restrict__ m_ptr,
                                                             const int* __restrict__ n_ptr, float alpha,
                                                             const float* __restrict__ v, float* __restrict__ u) {
@@ -46,36 +68,68 @@ __global__ __launch_bounds__(256) void sinkhorn_row_kernel(const float* __restri
     if (i > m || m <= 0 || n <= 0) return;
     const float* p = sim + (long)i * ld;
     const bool bin_row = i == m;
-    float mx = alpha + v[n];
-    for (int j = lane; j < n; j += 64) mx = fmaxf(mx, (bin_row ? alpha : p[j]) + v[j]);
-    mx = wave_max(mx);
-    float s = 0.f;
-    for (int j = lane; j < n; j += 64) s += expf(((bin_row ? alpha : p[j]) + v[j]) - mx);
-    s = wave_sum(s) + expf((alpha + v[n]) - mx);
+    OnlineLSE acc;
+    const int n4 = ((ld & 3) == 0) ? (n & ~3) : 0;  // vector part needs 16-byte aligned rows
+    for (int j = lane * 4; j < n4; j += 256) {
+        const float4 vv = *reinterpret_cast<const float4*>(v + j);
+        float4 x = make_float4(alpha, alpha, alpha, alpha);
+        if (!bin_row) x = *reinterpret_cast<const float4*>(p + j);
+        acc.add4(x.x + vv.x, x.y + vv.y, x.z + vv.z, x.w + vv.w);
+    }
+    for (int j = n4 + lane; j < n; j += 64) acc.add((bin_row ? alpha : p[j]) + v[j]);
+    if (lane == 0) acc.add(alpha + v[n]);  // dustbin column
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc.merge(__shfl_xor(acc.m, off), __shfl_xor(acc.s, off));
     if (lane == 0) {
         const float norm = sg_norm(m, n);
         const float log_mu = bin_row ? logf((float)n) + norm : norm;
-        u[i] = log_mu - (logf(s) + mx);
+        u[i] = log_mu - (logf(acc.s) + acc.m);
     }
 }
 
-static constexpr int SK_STRIP = 128;
+static constexpr int SK_STRIP = 256;  // rows per block of the column sweep
 
-// per column j in [0, n] and row strip: online (max, sum) of Z[i][j] + u[i] over the strip's rows i < m
+// column sweep: block = 256 columns x SK_STRIP rows; thread = 4 adjacent columns (one float4), 4 row lanes per column
+// group, so every wave instruction reads 1 KiB of one matrix row. Per-strip partial (max, sum) per column.
 __global__ __launch_bounds__(256) void sinkhorn_col_partial_kernel(const float* __restrict__ sim, int ld, const int* __restrict__ m_ptr,
                                                                     const int* __restrict__ n_ptr, float alpha,
                                                                     const float* __restrict__ u, float2* __restrict__ part, int pstride) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
+    __shared__ float2 red[4][256];
     const int m = *m_ptr, n = *n_ptr;
     const int i0 = blockIdx.y * SK_STRIP;
-    if (j > n || i0 >= m || n <= 0) return;
+    const int jb = blockIdx.x * 256;
+    if (jb > n || i0 >= m || n <= 0) return;
     const int i1 = min(i0 + SK_STRIP, m);
-    const bool bin_col = j == n;
-    float mx = -INFINITY;
-    for (int i = i0; i < i1; ++i) mx = fmaxf(mx, (bin_col ? alpha : sim[(long)i * ld + j]) + u[i]);
-    float s = 0.f;
-    for (int i = i0; i < i1; ++i) s += expf(((bin_col ? alpha : sim[(long)i * ld + j]) + u[i]) - mx);
-    part[(long)blockIdx.y * pstride + j] = make_float2(mx, s);
+    const int cg = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int j = jb + cg * 4;
+    OnlineLSE a0, a1, a2, a3;
+    const bool vec = ((ld & 3) == 0) && (j + 3 < n);
+    if (vec) {
+        for (int i = i0 + rl; i < i1; i += 4) {
+            const float4 x = *reinterpret_cast<const float4*>(sim + (long)i * ld + j);
+            const float ui = u[i];
+            a0.add(x.x + ui); a1.add(x.y + ui); a2.add(x.z + ui); a3.add(x.w + ui);
+        }
+    } else {
+        for (int i = i0 + rl; i < i1; i += 4) {
+            const float ui = u[i];
+            const float* q = sim + (long)i * ld;
+            if (j < n) a0.add(q[j] + ui); else if (j == n) a0.add(alpha + ui);
+            if (j + 1 < n) a1.add(q[j + 1] + ui); else if (j + 1 == n) a1.add(alpha + ui);
+            if (j + 2 < n) a2.add(q[j + 2] + ui); else if (j + 2 == n) a2.add(alpha + ui);
+            if (j + 3 < n) a3.add(q[j + 3] + ui); else if (j + 3 == n) a3.add(alpha + ui);
+        }
+    }
+    red[rl][cg * 4 + 0] = make_float2(a0.m, a0.s); red[rl][cg * 4 + 1] = make_float2(a1.m, a1.s);
+    red[rl][cg * 4 + 2] = make_float2(a2.m, a2.s); red[rl][cg * 4 + 3] = make_float2(a3.m, a3.s);
+    __syncthreads();
+    const int col = jb + threadIdx.x;
+    if (col <= n) {
+        OnlineLSE t;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t.merge(red[r][threadIdx.x].x, red[r][threadIdx.x].y);
+        part[(long)blockIdx.y * pstride + col] = make_float2(t.m, t.s);
+    }
 }
 
 __global__ __launch_bounds__(256) void sinkhorn_col_combine_kernel(const float2* __restrict__ part, int pstride,
@@ -86,17 +140,15 @@ __global__ __launch_bounds__(256) void sinkhorn_col_combine_kernel(const float2*
     const int m = *m_ptr, n = *n_ptr;
     if (j > n || m <= 0 || n <= 0) return;
     const int ns = (m + SK_STRIP - 1) / SK_STRIP;
-    const float last = alpha + u[m];  // dustbin row
-    float mx = last;
-    for (int s = 0; s < ns; ++s) mx = fmaxf(mx, part[(long)s * pstride + j].x);
-    float sum = expf(last - mx);
+    OnlineLSE t;
+    t.add(alpha + u[m]);  // dustbin row
     for (int s = 0; s < ns; ++s) {
         const float2 p = part[(long)s * pstride + j];
-        sum += p.y * expf(p.x - mx);
+        t.merge(p.x, p.y);
     }
     const float norm = sg_norm(m, n);
     const float log_nu = (j == n) ? logf((float)m) + norm : norm;
-    v[j] = log_nu - (logf(sum) + mx);
+    v[j] = log_nu - (logf(t.s) + t.m);
     if (j == 0) *norm_out = norm;
 }
 
@@ -316,9 +368,10 @@ int im_superglue_forward(im_ctx* ctx, const float* d_kpts, const float* d_scores
         sgm.epi = EPI_BIAS; sgm.big_tile = 1;
         IM_LAUNCH(ctx, "score_gemm", s, launch_gemm(sgm, s));
     }
+    const int voff = (K + 4) & ~3;  // keep v 16-byte aligned for the float4 sweeps
     float* u = ws->uv;
-    float* v = ws->uv + (K + 1);
-    float* norm = ws->uv + 2 * (K + 1);
+    float* v = ws->uv + voff;
+    float* norm = ws->uv + 2 * voff;
     if (ctx->prof_on) {
         im_ctx::ProfEntry pe{"sinkhorn", ctx->prof_event(), ctx->prof_event()};
         hipEventRecord(pe.e0, s);
@@ -351,9 +404,10 @@ int im_log_optimal_transport(im_ctx* ctx, const float* d_scores, int m, int n, i
     const int mn[2] = {m, n};
     IM_HIP(ctx, hipMemcpyAsync(ws->st->n, mn, sizeof(mn), hipMemcpyHostToDevice, s));
     IM_HIP(ctx, hipStreamSynchronize(s));
+    const int voff = (K + 4) & ~3;
     float* u = ws->uv;
-    float* v = ws->uv + (K + 1);
-    float* norm = ws->uv + 2 * (K + 1);
+    float* v = ws->uv + voff;
+    float* norm = ws->uv + 2 * voff;
     int rc = sinkhorn(ctx, s, d_scores, ld, &ws->st->n[0], &ws->st->n[1], m, n, bin_score, iters, u, v, norm);
     if (rc) return rc;
     const long total = (long)(m + 1) * (n + 1);
