@@ -190,6 +190,9 @@ class PairPipeline:
             stream = torch.cuda.Stream(device=eng.device)
             with torch.cuda.stream(stream):
                 sm = SequenceMatcher(eng, height, width, max_keypoints, use_graph=use_graph, **matcher_conf)
+                if use_graph:
+                    sm._capture()  # capture now, while nothing else is running on the device
+            stream.synchronize()
             self.slots.append((eng, stream, sm))
         self._next = 0
         self.device = self.slots[0][0].device
