@@ -200,12 +200,20 @@ class ImageMatcherBase:
         mk0, mk1 = [np.zeros((0, 2), np.float32)], [np.zeros((0, 2), np.float32)]
         d0, d1 = [np.zeros((256, 0), np.float32)], [np.zeros((256, 0), np.float32)]
         s0, s1 = [np.zeros(0, np.float32)], [np.zeros(0, np.float32)]
+        # Row f-1 of the scope table: the reference re-runs SuperPoint on both tiles of EVERY tile pair
+        # (`matchers.py:367-394`), i.e. up to 16 x 2 extractions for a 2 x 2 grid. Extraction is a pure function of the
+        # tile, so each distinct tile is extracted once on the device and its features are reused by all its pairs
+        # (bit-identical results, tested against the per-pair path).
+        cache = self._extract_tiles(image0, image1, t0_lims, t1_lims, tile_pairs, **config)
         for tidx0, tidx1 in tile_pairs:
             logger.info(f" - Matching tile pair ({tidx0}, {tidx1})")
             lim0, lim1 = t0_lims[tidx0], t1_lims[tidx1]
-            tile0 = self._tiler.extract_patch(image0, lim0)
-            tile1 = self._tiler.extract_patch(image1, lim1)
-            f0, f1, matches0, _ = self._match_images(tile0, tile1, **config)
+            if cache is not None:
+                f0, f1, matches0, _ = self._match_cached(cache[(0, tidx0)], cache[(1, tidx1)], **config)
+            else:
+                tile0 = self._tiler.extract_patch(image0, lim0)
+                tile1 = self._tiler.extract_patch(image1, lim1)
+                f0, f1, matches0, _ = self._match_images(tile0, tile1, **config)
             valid = matches0 > -1
             idx1 = matches0[valid]
             mk0.append(f0.keypoints[valid] + np.array(lim0[0:2]).astype("float32"))
@@ -325,6 +333,54 @@ class ImageMatcherBase:
         np.savetxt(path / "keypoints_0.txt", self.mkpts0, delimiter=delimiter, newline="\n", header=header)
         np.savetxt(path / "keypoints_1.txt", self.mkpts1, delimiter=delimiter, newline="\n", header=header)
 
+    # ------------------------------------------------------------------ per-tile feature cache (tile modes)
+    def _sp_params(self, **config):
+        """(nms_radius, threshold, border, max_keypoints, flavour) of this matcher's SuperPoint; None = no tile cache."""
+        return None
+
+    def _extract_tiles(self, image0, image1, t0_lims, t1_lims, tile_pairs, **config):
+        params = self._sp_params(**config)
+        if params is None or not tile_pairs:
+            return None
+        radius, thr, border, max_k, flavour = params
+        eng = self.engine
+        todo = sorted({(0, a) for a, _ in tile_pairs} | {(1, b) for _, b in tile_pairs})
+        tiles = {k: _to_gray_u8(self._tiler.extract_patch(image0 if k[0] == 0 else image1, (t0_lims if k[0] == 0 else t1_lims)[k[1]]), "")
+                 for k in todo}
+        hmax, wmax = max(t.shape[0] for t in tiles.values()), max(t.shape[1] for t in tiles.values())
+        eng.reserve(hmax, wmax, 2, max(int(max_k), 1))
+        cache = {}
+        by_shape = {}
+        for k in todo:
+            by_shape.setdefault(tiles[k].shape, []).append(k)
+        for shape, keys in by_shape.items():
+            for i in range(0, len(keys), 2):  # two equal-sized tiles per launch
+                grp = keys[i:i + 2]
+                batch = torch.from_numpy(np.stack([tiles[k] for k in grp])).to(eng.device)
+                eng.superpoint(batch, radius, thr, border, max_k, flavour=flavour)
+                for slot, k in enumerate(grp):
+                    cache[k] = dict(kpts=eng.kpts[slot].clone(), scores=eng.scores[slot].clone(), desc=eng.desc[slot].clone(),
+                                    n=eng.n[slot:slot + 1].clone(), shape=shape)
+        return cache
+
+    def _match_cached(self, c0: dict, c1: dict, **config):
+        raise NotImplementedError
+
+    def _load_cached_pair(self, c0: dict, c1: dict) -> None:
+        eng = self.engine
+        for slot, c in enumerate((c0, c1)):
+            eng.kpts[slot].copy_(c["kpts"]); eng.scores[slot].copy_(c["scores"]); eng.desc[slot].copy_(c["desc"])
+            eng.n[slot:slot + 1].copy_(c["n"])
+
+    def _features_from_engine(self):
+        eng = self.engine
+        k0, d0, s0 = eng.features_to_host(0)
+        k1, d1, s1 = eng.features_to_host(1)
+        out = eng.matches_to_host(len(k0), len(k1))
+        f0 = FeaturesBase(keypoints=k0, descriptors=np.ascontiguousarray(d0.T), scores=s0)
+        f1 = FeaturesBase(keypoints=k1, descriptors=np.ascontiguousarray(d1.T), scores=s1)
+        return f0, f1, out
+
     # ------------------------------------------------------------------ shared device plumbing
     def _upload_pair(self, g0: np.ndarray, g1: np.ndarray) -> List[torch.Tensor]:
         dev = self.engine.device
@@ -356,6 +412,23 @@ class SuperGlueMatcher(ImageMatcherBase):
                 "superglue": {"weights": opt["weights"], "sinkhorn_iterations": opt["sinkhorn_iterations"],
                               "match_threshold": opt["match_threshold"]},
                 "force_cpu": opt["force_cpu"]}
+
+    def _sp_cap(self) -> int:
+        sp = self._cfg["superpoint"]
+        return int(self._opt.get("max_keypoints_cap", 16384)) if sp["max_keypoints"] < 0 else int(sp["max_keypoints"])
+
+    def _sp_params(self, **config):
+        sp = self._cfg["superpoint"]
+        return sp["nms_radius"], sp["keypoint_threshold"], 4, self._sp_cap(), 1
+
+    def _match_cached(self, c0: dict, c1: dict, **config):
+        sg = self._cfg["superglue"]
+        self._load_cached_pair(c0, c1)
+        self.engine.superglue(c0["shape"], c1["shape"], sg["sinkhorn_iterations"], sg["match_threshold"])
+        torch.cuda.synchronize()
+        f0, f1, out = self._features_from_engine()
+        matches0 = out["matches0"]
+        return f0, f1, matches0, f0.scores[matches0 > -1]
 
     def _match_images(self, image0: np.ndarray, image1: np.ndarray, **config):
         """`SuperGlueMatcher._match_images` (`matchers.py:892-940`) on the GPU."""
@@ -396,6 +469,21 @@ class LightGlueMatcher(ImageMatcherBase):
         eng.load_state_dict("lightglue", _load_state_dict(opt, "lightglue", ["superpoint_lightglue.pth",
                                                                               "superpoint_lightglue_v0-1_arxiv-pth"]))
         self._lg_conf = {k: opt[k] for k in ("depth_confidence", "width_confidence", "filter_threshold") if k in opt}
+
+    def _sp_params(self, **config):
+        if config.get("resize", None) is not None:
+            return None
+        return 4, 0.0005, 4, int(config.get("max_keypoints", 10240)), 0
+
+    def _match_cached(self, c0: dict, c1: dict, **config):
+        self._load_cached_pair(c0, c1)
+        (h0, w0), (h1, w1) = c0["shape"], c1["shape"]
+        self.engine.lightglue((w0, h0), (w1, h1), **self._lg_conf)
+        torch.cuda.synchronize()
+        f0, f1, out = self._features_from_engine()
+        matches0 = out["matches0"]
+        self._last = out
+        return f0, f1, matches0, out["matching_scores0"][matches0 > -1]
 
     def _match_images(self, image0: np.ndarray, image1: np.ndarray, **config):
         """`LightGlueMatcher._match_images` (`matchers.py:1226-1304`) on the GPU: returns

@@ -394,3 +394,25 @@ def test_edge_cases_empty_flat_and_ragged(eng):
     flat_idx = kp_all[:, 1] * 1000 + kp_all[:, 0]
     assert (np.diff(flat_idx) > 0).all()                            # row-major (y, x) order
     e.close(); e2.close()
+
+
+def test_tile_feature_cache_is_bit_identical():
+    """Row f-1: extracting each tile once and reusing its features for every tile pair gives exactly the matches of the
+    reference's per-pair re-extraction (EXHAUSTIVE 2 x 2 grid: 16 pairs, 8 extractions instead of 32)."""
+    from icepy4d_amd.matching import GeometricVerification, LightGlueMatcher, Quality, TileSelection
+    g = load_golden("g4_wrappers")
+    sds = {"superpoint": SP_SD, "lightglue": synthetic.lightglue_state_dict(0, "passthrough")}
+    cfg = dict(geometric_verification=GeometricVerification.NONE, max_keypoints=256, grid=[2, 2], overlap=20)
+    m = LightGlueMatcher({"state_dicts": sds})
+    m.match(g["image0"], g["image1"], quality=Quality.HIGH, tile_selection=TileSelection.EXHAUSTIVE, **cfg)
+    a = (m.mkpts0.copy(), m.mkpts1.copy(), m.descriptors0.copy(), m.scores1.copy())
+    m2 = LightGlueMatcher({"state_dicts": sds})
+    m2._sp_params = lambda **config: None            # force the per-pair path of the reference
+    m2.match(g["image0"], g["image1"], quality=Quality.HIGH, tile_selection=TileSelection.EXHAUSTIVE, **cfg)
+    b = (m2.mkpts0, m2.mkpts1, m2.descriptors0, m2.scores1)
+    assert len(a[0]) > 100
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    # preselection mode runs end to end (pyramid + preselection match + tile matching)
+    m.match(g["image0"], g["image1"], quality=Quality.HIGH, tile_selection=TileSelection.PRESELECTION, min_matches_per_tile=3, **cfg)
+    assert len(m.mkpts0) > 50 and len(m.mkpts0) == len(m.mkpts1)
