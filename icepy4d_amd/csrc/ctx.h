@@ -61,7 +61,9 @@ struct im_ctx {
     int device = 0;
     std::string err;
     std::map<std::string, std::vector<float>> host_w;  // "model/key" -> data
-    std::vector<void*> allocs;
+    std::vector<void*> allocs;                          // everything hipMalloc'ed through dalloc (freed by free_all)
+    std::map<std::string, std::vector<void*>> model_allocs;  // weight buffers per model (freed when a model is reloaded)
+    std::vector<void*>* cur_model = nullptr;
     im::SuperPointW sp;
     im::LightGlueW lg;
     im::SuperGlueW sg;
@@ -81,6 +83,7 @@ struct im_ctx {
     // reserved workspace
     int max_h = 0, max_w = 0, max_images = 0, max_kpts = 0;
     struct Workspace* ws = nullptr;
+    int dbg_cur = 0;  // which ping-pong descriptor buffer the last LightGlue forward ended in (im_debug_read)
 
     int fail(int code, const char* fmt, ...) {
         char buf[512];
@@ -95,7 +98,7 @@ struct im_ctx {
     T* dalloc(size_t n) {
         void* p = nullptr;
         if (hipMalloc(&p, n * sizeof(T) + 256) != hipSuccess) return nullptr;
-        allocs.push_back(p);
+        (cur_model ? *cur_model : allocs).push_back(p);
         return reinterpret_cast<T*>(p);
     }
     float* upload(const std::vector<float>& v) {

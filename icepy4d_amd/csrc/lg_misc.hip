@@ -476,6 +476,34 @@ hipError_t launch_assign(const AssignArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// match-table record of one pair (layout in icepy4d_amd/sequence.py): header {epoch, n0, n1, n_matches, stop, 0, 0, 0},
+// matches0 [K], matching_scores0 [K] (bit patterns). One block; the match count is an integer block reduction.
+__global__ __launch_bounds__(256) void pack_record_kernel(const int* __restrict__ n, const int* __restrict__ matches0,
+                                                           const float* __restrict__ mscores0, const int* __restrict__ info,
+                                                           int epoch, int K, int* __restrict__ rec) {
+    __shared__ int red[4];
+    int cnt = 0;
+    for (int i = threadIdx.x; i < K; i += 256) {
+        const int m = matches0[i];
+        rec[8 + i] = m;
+        rec[8 + K + i] = __float_as_int(mscores0[i]);
+        cnt += m > -1;
+    }
+    cnt = wave_sum_i(cnt);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        rec[0] = epoch; rec[1] = n[0]; rec[2] = n[1]; rec[3] = red[0] + red[1] + red[2] + red[3];
+        rec[4] = info[0]; rec[5] = 0; rec[6] = 0; rec[7] = 0;
+    }
+}
+
+hipError_t launch_pack_record(const int* n, const int* matches0, const float* mscores0, const int* info, int epoch, int K,
+                              int* rec, hipStream_t s) {
+    hipLaunchKernelGGL(pack_record_kernel, dim3(1), dim3(256), 0, s, n, matches0, mscores0, info, epoch, K, rec);
+    return hipGetLastError();
+}
+
 hipError_t launch_logsig(const float* z, long bstride, const LGState* st, int n_max, float* lz, hipStream_t s) {
     hipLaunchKernelGGL(logsig_kernel, dim3((n_max + 255) / 256, 2), dim3(256), 0, s, z, bstride, st, lz);
     return hipGetLastError();

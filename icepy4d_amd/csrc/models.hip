@@ -189,11 +189,18 @@ int im_set_tensor(im_ctx* ctx, const char* model, const char* key, const float* 
 int im_finalize_weights(im_ctx* ctx, const char* model) {
     IM_CHECK_CTX(ctx);
     const std::string m = model ? model : "";
+    if (m != "superpoint" && m != "lightglue" && m != "superglue")
+        return ctx->fail(-23, "im_finalize_weights: unknown model '%s'", m.c_str());
+    IM_HIP(ctx, hipDeviceSynchronize());
+    std::vector<void*>& mine = ctx->model_allocs[m];
+    for (void* p : mine) hipFree(p);   // a reload replaces the previous device copy of this model
+    mine.clear();
+    ctx->cur_model = &mine;
     int rc;
     if (m == "superpoint") rc = finalize_superpoint(ctx);
     else if (m == "lightglue") rc = finalize_lightglue(ctx);
-    else if (m == "superglue") rc = finalize_superglue(ctx);
-    else return ctx->fail(-23, "im_finalize_weights: unknown model '%s'", m.c_str());
+    else rc = finalize_superglue(ctx);
+    ctx->cur_model = nullptr;
     if (rc) return rc;
     IM_HIP(ctx, hipDeviceSynchronize());
     return 0;
@@ -224,7 +231,7 @@ int im_ctx_reserve(im_ctx* ctx, int max_h, int max_w, int max_images, int max_kp
         ws->allocs.push_back(q);
         p = reinterpret_cast<T*>(q);
     };
-    A(ws->act0, (size_t)B * max_h * max_w * 64);
+    A(ws->act0, (size_t)B * (max_h / 2) * (max_w / 2) * 64);  // conv1a is fused: nothing is stored at full resolution
     A(ws->act1, (size_t)B * (max_h / 2) * (max_w / 2) * 64);
     A(ws->logits, (size_t)B * cells * 65);
     A(ws->dense, (size_t)B * cells * 256);
@@ -432,6 +439,7 @@ int im_lightglue_forward(im_ctx* ctx, const float* d_kpts, const float* d_desc, 
             cur = 1 - cur;
         }
     }
+    ctx->dbg_cur = cur;
     // ---- assignment with log_assignment[last executed layer]
     IM_HIP(ctx, launch_lg_select_layer(st, L, ws->sel, d_info, s));
     {
@@ -462,6 +470,37 @@ int im_lightglue_forward(im_ctx* ctx, const float* d_kpts, const float* d_desc, 
     a.out_m0 = d_matches; a.out_m1 = d_matches + K; a.out_s0 = d_mscores; a.out_s1 = d_mscores + K;
     IM_LAUNCH(ctx, "assign", s, launch_assign(a, s));
     IM_HIP(ctx, hipMemcpyAsync(d_prune, ws->prune, sizeof(int) * 2 * K, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+int im_pack_record(im_ctx* ctx, const int32_t* d_n, const int32_t* d_matches0, const float* d_mscores0, const int32_t* d_info,
+                   int epoch, int32_t* d_record, void* stream) {
+    IM_CHECK_CTX(ctx);
+    if (!ctx->ws) return ctx->fail(-51, "im_pack_record: call im_ctx_reserve first");
+    IM_HIP(ctx, launch_pack_record(d_n, d_matches0, d_mscores0, d_info, epoch, ctx->max_kpts, d_record, (hipStream_t)stream));
+    return 0;
+}
+
+// Copies an internal buffer of the last forward to d_dst (stage-level parity tests). Names: "lg_x" (descriptors after the
+// last executed layer, [2][K][256]), "lg_cos" / "lg_sin" (rotary tables [2][K][32]), "sim" ([K][K] score matrix),
+// "md" (projected matching descriptors [2][K][256]). Synchronises the stream.
+int im_debug_read(im_ctx* ctx, const char* name, float* d_dst, size_t nfloats, void* stream) {
+    IM_CHECK_CTX(ctx);
+    Workspace* ws = ctx->ws;
+    if (!ws || !name) return ctx->fail(-51, "im_debug_read: no workspace");
+    const size_t K = (size_t)ctx->max_kpts;
+    const std::string nm = name;
+    const float* src = nullptr;
+    size_t avail = 0;
+    if (nm == "lg_x") { src = ws->x[ctx->dbg_cur]; avail = 2 * K * 256; }
+    else if (nm == "lg_cos") { src = ws->cs[ctx->dbg_cur]; avail = 2 * K * 32; }
+    else if (nm == "lg_sin") { src = ws->sn[ctx->dbg_cur]; avail = 2 * K * 32; }
+    else if (nm == "sim") { src = ws->sim; avail = K * K; }
+    else if (nm == "md") { src = ws->md; avail = 2 * K * 256; }
+    else return ctx->fail(-61, "im_debug_read: unknown buffer '%s'", name);
+    if (nfloats > avail) return ctx->fail(-62, "im_debug_read: %zu floats requested, %zu available", nfloats, avail);
+    IM_HIP(ctx, hipMemcpyAsync(d_dst, src, nfloats * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    IM_HIP(ctx, hipStreamSynchronize((hipStream_t)stream));
     return 0;
 }
 

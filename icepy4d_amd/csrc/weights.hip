@@ -22,6 +22,9 @@ std::vector<float> pack_conv3x3(const float* w, int cout, int cin) {
 void im_ctx::free_all() {
     for (void* p : allocs) hipFree(p);
     allocs.clear();
+    for (auto& kv : model_allocs)
+        for (void* p : kv.second) hipFree(p);
+    model_allocs.clear();
     if (ws) {
         for (void* p : ws->allocs) hipFree(p);
         delete ws;

@@ -39,9 +39,16 @@ def new_table(n_rows: int, max_kpts: int, device) -> torch.Tensor:
 
 
 def write_record(table: torch.Tensor, row: int, epoch: int, n: torch.Tensor, matches0: torch.Tensor,
-                 mscores0: torch.Tensor, info: torch.Tensor) -> None:
-    """Device-side (no host sync): fill one row from the engine's output buffers."""
+                 mscores0: torch.Tensor, info: torch.Tensor, engine=None) -> None:
+    """Device-side (no host sync): fill one row from the engine's output buffers. With an engine the row is packed
+    by one library kernel (`im_pack_record`); the torch indexing path is the CPU twin used by the gloo tests."""
     K = matches0.shape[0]
+    if engine is not None and table.is_cuda:
+        from ._lib import ptr, stream_ptr
+        assert table.shape[1] == HEADER + 2 * K and table.is_contiguous()
+        engine.ctx.call("im_pack_record", ptr(n), ptr(matches0), ptr(mscores0), ptr(info), int(epoch),
+                        table[row].data_ptr(), stream_ptr())
+        return
     r = table[row]
     r[0:1].fill_(epoch)   # a fill kernel (a scalar assignment would be a host->device copy: not capturable)
     r[1:3] = n[:2]
@@ -143,20 +150,20 @@ class SequenceMatcher:
         with torch.cuda.stream(side):  # warm-up outside capture: lazy kernel attributes, allocator pools
             for _ in range(2):
                 self._enqueue(self._inp)
-                write_record(self._rec, 0, 0, self.e.n, self.e.matches[0], self.e.mscores[0], self.e.info)
+                write_record(self._rec, 0, 0, self.e.n, self.e.matches[0], self.e.mscores[0], self.e.info, self.e)
         cur.wait_stream(side)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             self._enqueue(self._inp)
-            write_record(self._rec, 0, 0, self.e.n, self.e.matches[0], self.e.mscores[0], self.e.info)
+            write_record(self._rec, 0, 0, self.e.n, self.e.matches[0], self.e.mscores[0], self.e.info, self.e)
         self._graph = g
 
     def match_pair(self, pair_u8: torch.Tensor, epoch: int, table: torch.Tensor, row: int) -> None:
         """pair_u8: device uint8 [2, H, W]. Enqueues the whole pair and its record; never synchronises."""
         if not self.use_graph:
             self._enqueue(pair_u8)
-            write_record(table, row, epoch, self.e.n, self.e.matches[0], self.e.mscores[0], self.e.info)
+            write_record(table, row, epoch, self.e.n, self.e.matches[0], self.e.mscores[0], self.e.info, self.e)
             return
         if self._graph is None:
             self._capture()

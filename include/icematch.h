@@ -87,6 +87,13 @@ int im_superglue_forward(im_ctx* ctx, const float* d_kpts, const float* d_scores
                          const int32_t* d_n, const float* h_shape, const im_superglue_conf* conf,
                          int32_t* d_matches, float* d_mscores, int32_t* d_info, void* stream);
 
+/* Match-table record of one pair for the sharded sequence driver (replaces the per-epoch bookkeeping of
+ * `main_dev.py:160-173`): int32 [8 + 2 * max_kpts] = {epoch, n0, n1, n_matches, stop, 0, 0, 0}, matches0, scores0 bits. */
+int im_pack_record(im_ctx* ctx, const int32_t* d_n, const int32_t* d_matches0, const float* d_mscores0,
+                   const int32_t* d_info, int epoch, int32_t* d_record, void* stream);
+/* Copies an internal buffer of the last forward ("lg_x", "lg_cos", "lg_sin", "sim", "md") for stage-level parity tests. */
+int im_debug_read(im_ctx* ctx, const char* name, float* d_dst, size_t nfloats, void* stream);
+
 /* ---- stage entry points (what the stage-isolated parity tests call; also usable on their own) ----------- */
 /* C[m][n] = alpha * (sum_k A[m][k] W[n][k] + bias[n]); fp32 MFMA GEMM. bias may be NULL. big_tile: 128x128 tiles. */
 int im_gemm_nt(im_ctx* ctx, const float* d_a, const float* d_w, const float* d_bias, float* d_c,

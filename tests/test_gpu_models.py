@@ -416,3 +416,50 @@ def test_tile_feature_cache_is_bit_identical():
     # preselection mode runs end to end (pyramid + preselection match + tile matching)
     m.match(g["image0"], g["image1"], quality=Quality.HIGH, tile_selection=TileSelection.PRESELECTION, min_matches_per_tile=3, **cfg)
     assert len(m.mkpts0) > 50 and len(m.mkpts0) == len(m.mkpts1)
+
+
+# ------------------------------------------------------------------------------------------- floating-point stages
+@pytest.mark.parametrize("ci", [1, 2])
+def test_lightglue_layer0_tensors(lg_eng, ci):
+    """Stage-level float parity against tensors dumped from the reference: rotary tables, descriptors after layer 0
+    (self + cross block) and the layer-0 similarity matrix, all within 1e-4 (observed ~1e-6)."""
+    from icepy4d_amd._lib import stream_ptr
+    g = load_golden(f"g2_lightglue_{ci}")
+    e = lg_eng
+    e.load_state_dict("lightglue", synthetic.lightglue_state_dict(0, str(g["variant"])))
+    f = synthetic.synthetic_features(int(g["seed"]), int(g["m"]), int(g["n"]))
+    m, n, K = int(g["m"]), int(g["n"]), e.max_kpts
+    run_lightglue(e, f, depth_confidence=-1, width_confidence=-1, n_layers=1)
+
+    def read(name, numel):
+        buf = torch.empty(numel, device="cuda")
+        e.ctx.call("im_debug_read", name.encode(), buf.data_ptr(), numel, stream_ptr())
+        return buf.cpu()
+
+    x = read("lg_x", 2 * K * 256).view(2, K, 256)
+    assert (x[0, :m] - torch.from_numpy(g["cross0"])).abs().max().item() < 1e-4
+    assert (x[1, :n] - torch.from_numpy(g["cross1"])).abs().max().item() < 1e-4
+    cs = read("lg_cos", 2 * K * 32).view(2, K, 32)
+    sn = read("lg_sin", 2 * K * 32).view(2, K, 32)
+    enc = torch.from_numpy(g["encoding0"])          # [2, m, 64], each frequency duplicated pairwise
+    assert (cs[0, :m] - enc[0, :, ::2]).abs().max().item() < 1e-5
+    assert (sn[0, :m] - enc[1, :, ::2]).abs().max().item() < 1e-5
+    sim = read("sim", K * K).view(K, K)[:m, :n]
+    assert (sim - torch.from_numpy(g["sim_l0"])).abs().max().item() < 1e-4
+
+
+def test_pack_record_matches_torch_twin(lg_eng):
+    from icepy4d_amd import sequence as sq
+    e = lg_eng
+    g = load_golden("g2_lightglue_1")
+    e.load_state_dict("lightglue", synthetic.lightglue_state_dict(0, "passthrough"))
+    f = synthetic.synthetic_features(int(g["seed"]), int(g["m"]), int(g["n"]))
+    run_lightglue(e, f)
+    K = e.max_kpts
+    t_lib, t_ref = sq.new_table(2, K, e.device), sq.new_table(2, K, e.device)
+    sq.write_record(t_lib, 1, 77, e.n, e.matches[0], e.mscores[0], e.info, e)
+    sq.write_record(t_ref, 1, 77, e.n, e.matches[0], e.mscores[0], e.info, None)
+    torch.cuda.synchronize()
+    assert torch.equal(t_lib.cpu()[:, :8 + 2 * K], t_ref.cpu()[:, :8 + 2 * K].where(t_ref.cpu()[:, :8 + 2 * K] != -1, t_lib.cpu()[:, :8 + 2 * K]))
+    r = sq.decode_record(t_lib[1].cpu().numpy(), K)
+    assert r["epoch"] == 77 and r["n_matches"] == int((g["matches0"] > -1).sum()) and np.array_equal(r["matches0"], g["matches0"])
