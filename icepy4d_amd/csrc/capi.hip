@@ -41,11 +41,24 @@ int im_gemm_nt(im_ctx* ctx, const float* d_a, const float* d_w, const float* d_b
     return 0;
 }
 
+static int conv3x3_entry(im_ctx* ctx, bool wino, const float* d_in, const float* h_weight, const float* h_bias, float* d_out,
+                         int b, int h, int w, int cin, int cout, int relu, int pool, void* stream);
+
 int im_conv3x3(im_ctx* ctx, const float* d_in, const float* h_weight, const float* h_bias, float* d_out, int b, int h,
                int w, int cin, int cout, int relu, int pool, void* stream) {
+    return conv3x3_entry(ctx, false, d_in, h_weight, h_bias, d_out, b, h, w, cin, cout, relu, pool, stream);
+}
+
+int im_conv3x3_winograd(im_ctx* ctx, const float* d_in, const float* h_weight, const float* h_bias, float* d_out, int b,
+                        int h, int w, int cin, int cout, int relu, int pool, void* stream) {
+    return conv3x3_entry(ctx, true, d_in, h_weight, h_bias, d_out, b, h, w, cin, cout, relu, pool, stream);
+}
+
+static int conv3x3_entry(im_ctx* ctx, bool wino, const float* d_in, const float* h_weight, const float* h_bias, float* d_out,
+                         int b, int h, int w, int cin, int cout, int relu, int pool, void* stream) {
     IM_CHECK_CTX(ctx);
     if (cin % 16 || cout % 64) return ctx->fail(-10, "im_conv3x3: cin %% 16 and cout %% 64 must be 0");
-    std::vector<float> packed = pack_conv3x3(h_weight, cout, cin);
+    std::vector<float> packed = wino ? pack_conv3x3_wino(h_weight, cout, cin) : pack_conv3x3(h_weight, cout, cin);
     float *dw = nullptr, *db = nullptr;
     IM_HIP(ctx, hipMalloc(&dw, packed.size() * sizeof(float)));
     IM_HIP(ctx, hipMalloc(&db, cout * sizeof(float)));
@@ -54,8 +67,18 @@ int im_conv3x3(im_ctx* ctx, const float* d_in, const float* h_weight, const floa
     ConvArgs a;
     a.in = d_in; a.w = dw; a.bias = db; a.out = d_out; a.B = b; a.H = h; a.W = w; a.Cin = cin; a.Cout = cout;
     a.relu = relu; a.pool = pool;
-    hipError_t e = launch_conv3x3(a, (hipStream_t)stream);
-    hipError_t e2 = hipStreamSynchronize((hipStream_t)stream);
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipSuccess;
+    if (ctx->prof_on) {
+        im_ctx::ProfEntry pe{wino ? "conv_wino" : "conv_direct", ctx->prof_event(), ctx->prof_event()};
+        hipEventRecord(pe.e0, st);
+        e = wino ? launch_conv3x3_wino(a, st) : launch_conv3x3(a, st);
+        hipEventRecord(pe.e1, st);
+        ctx->prof.push_back(pe);
+    } else {
+        e = wino ? launch_conv3x3_wino(a, st) : launch_conv3x3(a, st);
+    }
+    hipError_t e2 = hipStreamSynchronize(st);
     hipFree(dw);
     hipFree(db);
     IM_HIP(ctx, e);

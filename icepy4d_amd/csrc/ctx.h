@@ -13,12 +13,14 @@
 
 namespace im {
 
-std::vector<float> pack_conv3x3(const float* w, int cout, int cin);  // [cout][cin][3][3] -> [cin/16][9][cout][16]
+std::vector<float> pack_conv3x3(const float* w, int cout, int cin);       // [cout][cin][3][3] -> [cin/16][9][cout][16]
+std::vector<float> pack_conv3x3_wino(const float* w, int cout, int cin);  // -> G g G^T as [cin/8][16][cout][8]
 
 struct SuperPointW {
     bool ready = false;
     float* c1a_w = nullptr; float* c1a_b = nullptr;          // [9][64], [64]
     float* cw[10] = {nullptr}; float* cb[10] = {nullptr};     // conv1b..conv4b, convPa, convDa (packed slabs)
+    float* cww[10] = {nullptr};                               // the same layers, Winograd-transformed weights
     float* pb_w = nullptr; float* pb_b = nullptr;             // convPb [65][256], [65]
     float* db_w = nullptr; float* db_b = nullptr;             // convDb [256][256], [256]
 };

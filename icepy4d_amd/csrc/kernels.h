@@ -69,6 +69,8 @@ struct ConvArgs {
     const float* b1 = nullptr;    // conv1a bias [64]
 };
 hipError_t launch_conv3x3(const ConvArgs& a, hipStream_t s);
+// Winograd F(2x2, 3x3) variant (conv_wino.hip); a.w = weights packed by pack_conv3x3_wino: [Cin / 8][16][Cout][8]
+hipError_t launch_conv3x3_wino(const ConvArgs& a, hipStream_t s);
 // conv1a: u8 gray [B][H][W] -> (x / 255) * w + b, ReLU -> NHWC [B][H][W][64]; w packed [9][64]
 hipError_t launch_conv1a(const uint8_t* img, const float* w, const float* bias, float* out, int B, int H, int W, hipStream_t s);
 

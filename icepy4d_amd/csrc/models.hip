@@ -2,6 +2,7 @@
 // passes as a fixed sequence of kernel launches on one stream (no host synchronisation inside a forward:
 // keypoint counts, early-stop and pruning state live in device memory).
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "ctx.h"
@@ -48,8 +49,9 @@ static int finalize_superpoint(im_ctx* ctx) {
         GETW(cw, "superpoint", nm + ".weight", (size_t)SP_COUT[i] * SP_CIN[i] * 9);
         GETW(cb, "superpoint", nm + ".bias", (size_t)SP_COUT[i]);
         w.cw[i] = ctx->upload(pack_conv3x3(cw->data(), SP_COUT[i], SP_CIN[i]));
+        w.cww[i] = ctx->upload(pack_conv3x3_wino(cw->data(), SP_COUT[i], SP_CIN[i]));
         w.cb[i] = ctx->upload(*cb);
-        if (!w.cw[i] || !w.cb[i]) return ctx->fail(-22, "weights: upload failed");
+        if (!w.cw[i] || !w.cww[i] || !w.cb[i]) return ctx->fail(-22, "weights: upload failed");
     }
     GETW(pbw, "superpoint", "convPb.weight", 65 * 256);
     GETW(pbb, "superpoint", "convPb.bias", 65);
@@ -288,6 +290,9 @@ int im_superpoint_forward(im_ctx* ctx, const uint8_t* d_gray, int n_images, int 
     hipStream_t s = (hipStream_t)stream;
     const SuperPointW& W = ctx->sp;
     const int B = n_images, K = ctx->max_kpts;
+    // 3x3 layers run in Winograd F(2x2,3x3) form (conv_wino.hip); IM_CONV_DIRECT=1 selects the direct implicit GEMM
+    static const bool direct = getenv("IM_CONV_DIRECT") && getenv("IM_CONV_DIRECT")[0] == '1';
+    auto conv = [&](ConvArgs& a, int layer) { a.w = direct ? W.cw[layer] : W.cww[layer]; return direct ? launch_conv3x3(a, s) : launch_conv3x3_wino(a, s); };
     // conv1a is fused into conv1b's patch producer: the full-resolution 64-channel activation never touches HBM
     float* src = nullptr;
     float* dst = ws->act1;
@@ -295,10 +300,10 @@ int im_superpoint_forward(im_ctx* ctx, const uint8_t* d_gray, int n_images, int 
     static const int pool_after[7] = {1, 0, 1, 0, 1, 0, 0};  // conv1b, 2a, 2b, 3a, 3b, 4a, 4b
     for (int i = 0; i < 7; ++i) {
         ConvArgs a;
-        a.in = src; a.w = W.cw[i]; a.bias = W.cb[i]; a.out = dst; a.B = B; a.H = ch; a.W = cw_;
+        a.in = src; a.bias = W.cb[i]; a.out = dst; a.B = B; a.H = ch; a.W = cw_;
         a.Cin = SP_CIN[i]; a.Cout = SP_COUT[i]; a.pool = pool_after[i]; a.relu = 1;
         if (i == 0) { a.img = d_gray; a.w1 = W.c1a_w; a.b1 = W.c1a_b; }
-        IM_LAUNCH(ctx, SP_CONV3[i], s, launch_conv3x3(a, s));
+        IM_LAUNCH(ctx, SP_CONV3[i], s, conv(a, i));
         if (pool_after[i]) { ch /= 2; cw_ /= 2; }
         src = dst;
         dst = (dst == ws->act1) ? ws->act0 : ws->act1;
@@ -311,8 +316,8 @@ int im_superpoint_forward(im_ctx* ctx, const uint8_t* d_gray, int n_images, int 
     float* tmp = dst;
     {
         ConvArgs a;
-        a.in = feat; a.w = W.cw[7]; a.bias = W.cb[7]; a.out = tmp; a.B = B; a.H = hc; a.W = wc; a.Cin = 128; a.Cout = 256;
-        IM_LAUNCH(ctx, "convPa", s, launch_conv3x3(a, s));
+        a.in = feat; a.bias = W.cb[7]; a.out = tmp; a.B = B; a.H = hc; a.W = wc; a.Cin = 128; a.Cout = 256;
+        IM_LAUNCH(ctx, "convPa", s, conv(a, 7));
         GemmArgs g;
         g.A = tmp; g.lda = 256; g.W = W.pb_w; g.ldw = 256; g.bias = W.pb_b; g.N = 65; g.K = 256; g.m_max = (int)cells;
         g.C = ws->logits; g.ldc = 65; g.epi = EPI_BIAS;
@@ -325,8 +330,8 @@ int im_superpoint_forward(im_ctx* ctx, const uint8_t* d_gray, int n_images, int 
                                                       ws->keys, d_kpts, d_scores, d_n, s));
     {
         ConvArgs a;
-        a.in = feat; a.w = W.cw[8]; a.bias = W.cb[8]; a.out = tmp; a.B = B; a.H = hc; a.W = wc; a.Cin = 128; a.Cout = 256;
-        IM_LAUNCH(ctx, "convDa", s, launch_conv3x3(a, s));
+        a.in = feat; a.bias = W.cb[8]; a.out = tmp; a.B = B; a.H = hc; a.W = wc; a.Cin = 128; a.Cout = 256;
+        IM_LAUNCH(ctx, "convDa", s, conv(a, 8));
         GemmArgs g;
         g.A = tmp; g.lda = 256; g.W = W.db_w; g.ldw = 256; g.bias = W.db_b; g.N = 256; g.K = 256; g.m_max = (int)cells;
         g.C = ws->dense; g.ldc = 256; g.epi = EPI_BIAS;

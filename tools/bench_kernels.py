@@ -37,7 +37,7 @@ def main():
                 fl = 2 * 4 * 4.0 * n * n * 64
                 print(f"attn n={n} cross={cross}: {ms:.4f} ms  {fl / ms / 1e9:.1f} TFLOP/s (executed)  {fl / ms / 1e9 / 157.3 * 100:.1f}% of fp32 MFMA peak", flush=True)
     if "conv" in which:
-        import torch.nn.functional as F  # noqa: F401
+        import ctypes, json
         for (h, w, cin, cout, pool) in ((1080, 1920, 64, 64, 1), (540, 960, 64, 64, 0), (540, 960, 64, 64, 1), (270, 480, 64, 128, 0),
                                         (270, 480, 128, 128, 1), (135, 240, 128, 128, 0), (135, 240, 128, 256, 0)):
             x = torch.randn(2, h, w, cin, device="cuda")
@@ -45,15 +45,20 @@ def main():
             b = torch.randn(cout)
             ho, wo = (h // 2, w // 2) if pool else (h, w)
             out = torch.empty(2, ho, wo, cout, device="cuda")
-            # im_conv3x3 packs + uploads weights and synchronises each call: time the kernel through the profiler instead
-            ctx.call("im_conv3x3", ptr(x), ptr(wt), ptr(b), ptr(out), 2, h, w, cin, cout, 1, pool, stream_ptr())
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(3):
-                ctx.call("im_conv3x3", ptr(x), ptr(wt), ptr(b), ptr(out), 2, h, w, cin, cout, 1, pool, stream_ptr())
-            dt = (time.perf_counter() - t0) / 3 * 1e3
             fl = 2 * 2.0 * 9 * cin * cout * h * w
-            print(f"conv {h}x{w} {cin}->{cout} pool={pool}: <= {dt:.3f} ms incl. weight upload ({fl / dt / 1e9:.1f} TFLOP/s lower bound)", flush=True)
+            line = f"conv {h}x{w} {cin}->{cout} pool={pool}:"
+            for name in ("im_conv3x3", "im_conv3x3_winograd"):
+                ctx.call(name, ptr(x), ptr(wt), ptr(b), ptr(out), 2, h, w, cin, cout, 1, pool, stream_ptr())  # warm-up
+                ctx.call("im_profile_begin")
+                for _ in range(3):
+                    ctx.call(name, ptr(x), ptr(wt), ptr(b), ptr(out), 2, h, w, cin, cout, 1, pool, stream_ptr())
+                buf = ctypes.create_string_buffer(4096)
+                ctx.call("im_profile_end", buf, len(buf))
+                prof = json.loads(buf.value.decode())
+                v = next(iter(prof.values()))
+                ms = v["total_ms"] / v["count"]
+                line += f"  {name[3:]} {ms:.3f} ms ({fl / ms / 1e9:.0f} TFLOP/s alg.)"
+            print(line, flush=True)
     if "gemm" in which:
         for (m, n, k, big) in ((8192, 256, 256, 0), (8192, 512, 512, 0), (8192, 768, 256, 0), (4096, 4096, 256, 1), (64800, 256, 256, 0)):
             a = torch.randn(m, k, device="cuda"); w = torch.randn(n, k, device="cuda"); b = torch.randn(n, device="cuda")
