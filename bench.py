@@ -107,10 +107,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # untimed warm-up: W steps as asked, never fewer than 16 (first-touch of the ~3 GB workspaces and the clock ramp of a
-    # cold GPU cost the first dozen pairs ~10 %)
-    for i in range(max(args.warmup, 16)):
+    # untimed warm-up: at least W steps, and at least ~3 s of sustained load: a cold MI355X needs seconds, not
+    # milliseconds, to settle its clocks (measured: first process on a fresh box 62 pairs/s after 16 warm-up pairs,
+    # 73.5 after 200; later processes 74.4 either way)
+    t_w = time.perf_counter()
+    i = 0
+    while i < args.warmup or (time.perf_counter() - t_w < 3.0 and i < 2000):
         sm.match_pair(pool[i % len(pool)], epochs[i % len(epochs)], scratch, i % scratch.shape[0])
+        i += 1
+        if i % 8 == 0:
+            sm.synchronize()
     sm.synchronize()
     if world > 1:
         all_gather_tables(scratch.cpu() if one_dev else scratch)

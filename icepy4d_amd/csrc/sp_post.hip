@@ -275,7 +275,11 @@ __global__ __launch_bounds__(1024) void kp_topk_kernel(const unsigned long long*
         __syncthreads();
         prefix |= (unsigned long long)sh_digit << shift;
         remaining = sh_remaining;
+        const int in_bin = hist[sh_digit];
         __syncthreads();
+        // all 32 score bits are fixed after pass 4; if every key with exactly that score is wanted there is no tie at
+        // the cut, the index passes cannot change anything and the threshold key is (score, lowest possible index word)
+        if (pass == 4 && remaining == in_bin) break;
     }
     // prefix is now the k-th largest key; keys are unique so exactly k keys are >= prefix
     if (tid == 0) sh_count = 0;
