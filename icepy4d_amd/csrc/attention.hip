@@ -22,28 +22,43 @@
 #include "common.h"
 #include "kernels.h"
 
+#include <cstdlib>
+
 namespace im {
 
 static constexpr int KT = 64;       // keys per tile
 static constexpr int KS = 68;       // K tile row stride (floats): conflict-free ds_read_b128
 static constexpr int VS = 64;       // V tile row stride
-static constexpr int ATTN_LDS_FLOATS = 2 * KT * KS + 2 * KT * VS;
+static constexpr int ATTN_LDS_FLOATS = 2 * KT * KS + 2 * KT * VS;   // per key group
 
-// register staging of one 64 x 64 tile: 1024 float4, 4 per thread (thread -> row idx >> 4, 16-byte column idx & 15)
-__device__ __forceinline__ float4 load_row4(const float* __restrict__ base, int row0, int nk, int idx) {
-    const int row = min(row0 + (idx >> 4), nk - 1);
-    return *reinterpret_cast<const float4*>(base + (long)row * 64 + (idx & 15) * 4);
+// register staging of one (64 G) x 64 tile by NT = 256 G threads: 4 float4 per thread (thread -> row idx >> 4,
+// 16-byte column idx & 15). The loads are buffer loads: a wave-uniform descriptor sized to the live key rows, a
+// loop-invariant 32-bit lane offset and a scalar tile offset - no per-load address arithmetic on the VALU (which
+// would cost matrix-pipe time, see softmax_tile), and rows past the last key read as zero without any clamping.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
-#define IM_LOAD_TILE(r, base, row0)                       \
-    r##0 = load_row4(base, row0, nk, tid);                \
-    r##1 = load_row4(base, row0, nk, tid + 256);          \
-    r##2 = load_row4(base, row0, nk, tid + 512);          \
-    r##3 = load_row4(base, row0, nk, tid + 768);
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, int rows) {
+    const unsigned long long b = reinterpret_cast<unsigned long long>(base);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    void* p = reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo);
+    return __builtin_amdgcn_make_buffer_rsrc(p, 0, __builtin_amdgcn_readfirstlane(rows) * 256, 0x00020000);
+}
+#define IM_LOAD_TILE(r, rsrc, tile)                                                      \
+    {                                                                                    \
+        const unsigned so_ = (unsigned)(tile) * (G * KT * 256u);                         \
+        r##0 = buf_load4(rsrc, voff, so_);                                               \
+        r##1 = buf_load4(rsrc, voff, so_ + (NT / 16) * 256u);                            \
+        r##2 = buf_load4(rsrc, voff, so_ + 2 * (NT / 16) * 256u);                        \
+        r##3 = buf_load4(rsrc, voff, so_ + 3 * (NT / 16) * 256u);                        \
+    }
 #define IM_STORE_TILE(r, dst, stride)                                                                          \
     *reinterpret_cast<float4*>((dst) + (tid >> 4) * (stride) + (tid & 15) * 4) = r##0;                        \
-    *reinterpret_cast<float4*>((dst) + ((tid >> 4) + 16) * (stride) + (tid & 15) * 4) = r##1;                 \
-    *reinterpret_cast<float4*>((dst) + ((tid >> 4) + 32) * (stride) + (tid & 15) * 4) = r##2;                 \
-    *reinterpret_cast<float4*>((dst) + ((tid >> 4) + 48) * (stride) + (tid & 15) * 4) = r##3;
+    *reinterpret_cast<float4*>((dst) + ((tid >> 4) + NT / 16) * (stride) + (tid & 15) * 4) = r##1;            \
+    *reinterpret_cast<float4*>((dst) + ((tid >> 4) + 2 * NT / 16) * (stride) + (tid & 15) * 4) = r##2;        \
+    *reinterpret_cast<float4*>((dst) + ((tid >> 4) + 3 * NT / 16) * (stride) + (tid & 15) * 4) = r##3;
 
 // S^T for one 64-key tile: two 32-key halves, 32 MFMAs each; contraction order d = s (hh = 0) / 32 + s (hh = 1).
 // The K fragments of step t+1 are requested from LDS before the MFMAs of step t are issued.
@@ -69,38 +84,84 @@ __device__ __forceinline__ void qk_tile(const float* __restrict__ sK, int c, int
     }
 }
 
-// online softmax of one 64-key tile in the log2 domain; on return sa / sb hold P = exp2(s * c - m)
+// online softmax of one 64-key tile in the log2 domain; on return sa / sb hold P = exp2(s * c - m).
+//
+// On gfx950 the fp32 MFMA and the ordinary VALU share issue cycles: `tools/mfma_peak.hip` shows every VALU
+// instruction next to a v_mfma_f32_32x32x2_f32 stream costs its full 4 (exp2: 8) cycles of matrix-pipe time, with one
+// or two waves per SIMD alike. The softmax is therefore written for instruction COUNT, not for overlap:
+//   * max with v_max3_f32 (16 instructions for the 32 scores of a lane; the asm also avoids the canonicalising
+//     v_max x, x, x the compiler puts in front of every fmaxf of an MFMA result);
+//   * subtraction and row sum on whole vectors, which lower to packed fp32 (v_pk_add_f32: two values per lane-op);
+//   * the running max is a REFERENCE, only raised when some row of the wave exceeds it by more than 2^8: P then stays
+//     <= 256 (harmless in fp32: l <= 4096 keys x 256) and the common step has no alpha, no rescale of O, no l * alpha.
+//     Softmax is shift invariant, so O / l is the same quantity as with the exact running max.
+static constexpr float M_SLACK = 8.f;
+
+__device__ __forceinline__ float max3(float a, float b, float c) {
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+// packed fp32 (two values per lane-op); written as asm because the compiler scalarises these vector expressions
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+#define IM_PAIR(v, i) f32x2{v[2 * (i)], v[2 * (i) + 1]}
+
 template <bool TAIL>
 __device__ __forceinline__ void softmax_tile(f32x16& sa, f32x16& sb, int kb, int nk, int hh, float& m_run, float& l_run,
                                              f32x16& o0, f32x16& o1) {
-    float mx = -INFINITY;
+    if (TAIL) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        if (TAIL) {
+        for (int r = 0; r < 16; ++r) {
             if (kb + acc_row(r, hh) >= nk) sa[r] = -INFINITY;
             if (kb + 32 + acc_row(r, hh) >= nk) sb[r] = -INFINITY;
         }
-        mx = fmaxf(mx, fmaxf(sa[r], sb[r]));
     }
+    float mx0 = max3(sa[0], sb[0], sa[1]), mx1 = max3(sb[1], sa[2], sb[2]);
+#pragma unroll
+    for (int r = 3; r < 15; r += 2) { mx0 = max3(mx0, sa[r], sb[r]); mx1 = max3(mx1, sa[r + 1], sb[r + 1]); }
+    float mx = max3(mx0, mx1, fmaxf(sa[15], sb[15]));
 #ifdef IM_ABL_NO_SOFTMAX
     asm volatile("" ::"v"(mx));
     return;
 #endif
     mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    float rs = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const float pa = __builtin_amdgcn_exp2f(sa[r] - m_new), pb = __builtin_amdgcn_exp2f(sb[r] - m_new);
-        sa[r] = pa; sb[r] = pb;
-        rs += pa + pb;
+    if (__builtin_amdgcn_ballot_w64(mx > m_run + M_SLACK) != 0) {     // wave-uniform: raise the reference, rescale
+        asm volatile("" ::: "memory");                                 // keep this a branch: if-converted it costs 16 v_pk_mul per step
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);     // m_run = -inf at the first tile: alpha = 0
+        l_run *= alpha;
+        o0 *= alpha;
+        o1 *= alpha;
+        m_run = m_new;
     }
-    rs += __shfl_xor(rs, 32);
-    l_run = l_run * alpha + rs;
-    m_run = m_new;
+    // a key group whose every tile so far lies past the last key keeps m = -inf, l = 0 (only possible in the tail)
+    const float m_use = (TAIL && m_run == -INFINITY) ? 0.f : m_run;
+    const f32x2 mm = {m_use, m_use};
+    f32x2 acc[4];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+    for (int i = 0; i < 8; ++i) {
+        f32x2 pa = pk_sub(IM_PAIR(sa, i), mm), pb = pk_sub(IM_PAIR(sb, i), mm);
+        pa.x = __builtin_amdgcn_exp2f(pa.x); pa.y = __builtin_amdgcn_exp2f(pa.y);
+        pb.x = __builtin_amdgcn_exp2f(pb.x); pb.y = __builtin_amdgcn_exp2f(pb.y);
+        sa[2 * i] = pa.x; sa[2 * i + 1] = pa.y;
+        sb[2 * i] = pb.x; sb[2 * i + 1] = pb.y;
+        const f32x2 ps = pk_add(pa, pb);
+        acc[i & 3] = i < 4 ? ps : pk_add(acc[i & 3], ps);
+    }
+    const f32x2 t2 = pk_add(pk_add(acc[0], acc[1]), pk_add(acc[2], acc[3]));
+    float rs = t2.x + t2.y;
+    rs += __shfl_xor(rs, 32);
+    l_run += rs;
 }
 
 // O^T += V^T . P^T for one 64-key tile: register r of P is key acc_row(r, hh) of its half. V fragments are read
@@ -129,7 +190,13 @@ __device__ __forceinline__ void pv_tile(const float* __restrict__ sV, int c, int
     }
 }
 
-__global__ __launch_bounds__(256, 2) void flash_attn_f32_kernel(AttnArgs a) {
+// G = key groups per block. G = 2: eight waves; waves 4..7 take the same 128 queries as waves 0..3 but the odd 64-key
+// tiles, and the two partial (O, m, l) are merged through LDS at the end. At 4096 keypoints the grid is exactly one
+// block per CU, so G = 2 is what puts two waves on every SIMD: one wave's softmax / LDS / barrier stalls are covered
+// by the other's MFMAs.
+template <int G>
+__global__ __launch_bounds__(256 * G, 2 / G) void flash_attn_f32_kernel(AttnArgs a) {
+    constexpr int NT = 256 * G;
     if (a.active && *a.active == 0) return;
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -146,13 +213,14 @@ __global__ __launch_bounds__(256, 2) void flash_attn_f32_kernel(AttnArgs a) {
     const int qb = (bid / hz) * 128;
     if (qb >= nq || nk <= 0) return;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, grp = tid >> 8;
     const int c = lane & 31, hh = lane >> 5;
     const int qrow = qb + wave * 32 + c;
 
     const float* Q = a.q + (long)z * a.bstride + (long)head * a.hstride;
-    const float* K = a.k + (long)y * a.bstride + (long)head * a.hstride;
-    const float* V = a.v + (long)y * a.bstride + (long)head * a.hstride;
+    const __amdgpu_buffer_rsrc_t K = make_rsrc(a.k + (long)y * a.bstride + (long)head * a.hstride, nk);
+    const __amdgpu_buffer_rsrc_t V = make_rsrc(a.v + (long)y * a.bstride + (long)head * a.hstride, nk);
+    const unsigned voff = ((tid >> 4) * 64 + (tid & 15) * 4) * sizeof(float);
 
     // Q fragment: lane (c, hh) keeps Q[qrow][32*hh + s], s = 0..31
     float qf[32];
@@ -173,45 +241,29 @@ __global__ __launch_bounds__(256, 2) void flash_attn_f32_kernel(AttnArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
     float m_run = -INFINITY, l_run = 0.f;
-    const int nt = (nk + KT - 1) / KT;
+    const int nt = (nk + KT * G - 1) / (KT * G);   // steps of G tiles
 
     // ---- prologue: K0 -> LDS, S(0); K1, V0 -> LDS; K2, V1 in registers
     float4 rk0, rk1, rk2, rk3, rv0, rv1, rv2, rv3;
+    constexpr int KSTG = G * KT * KS, VSTG = G * KT * VS;   // one ring stage = G tiles
     float* const sK0 = smem;
-    float* const sV0 = smem + 2 * KT * KS;
+    float* const sV0 = smem + 2 * KSTG;
+    const int gk = grp * KT * KS, gv = grp * KT * VS;       // this wave's tile inside a stage
     IM_LOAD_TILE(rk, K, 0)
     IM_STORE_TILE(rk, sK0, KS)
-    IM_LOAD_TILE(rk, K, KT)
+    IM_LOAD_TILE(rk, K, 1)
     IM_LOAD_TILE(rv, V, 0)
     __syncthreads();
-    qk_tile(sK0, c, hh, qf, sa, sb);
-    IM_STORE_TILE(rk, sK0 + KT * KS, KS)
+    qk_tile(sK0 + gk, c, hh, qf, sa, sb);
+    IM_STORE_TILE(rk, sK0 + KSTG, KS)
     IM_STORE_TILE(rv, sV0, VS)
-    IM_LOAD_TILE(rk, K, 2 * KT)
-    IM_LOAD_TILE(rv, V, KT)
+    IM_LOAD_TILE(rk, K, 2)
+    IM_LOAD_TILE(rv, V, 1)
     __syncthreads();
 
-    // iteration t: stage K(t+2), V(t+1); prefetch K(t+3), V(t+2); QK^T of tile t+1 with the softmax of tile t in
-    // its shadow (one basic block, so the scheduler can interleave MFMA and VALU); PV of tile t; one barrier
-// Instruction-group pipeline of one step (LLVM sched_group_barrier; masks: 0x008 MFMA, 0x002 VALU, 0x100 DS read,
-// 0x200 DS write, 0x020 VMEM read): staging stores + prefetch loads first, then the 64 QK^T MFMAs with the
-// previous tile's softmax VALU work and the K-fragment reads in their shadow, then the 64 PV MFMAs with the
-// V-fragment reads running two pairs ahead.
-#ifndef IM_ATTN_NO_SCHED
-#define IM_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
-#define IM_SCHED_QK_SOFTMAX                                                    \
-    IM_SGB(0x200, 8); IM_SGB(0x020, 8);                                        \
-    IM_SGB(0x100, 4);                                                          \
-    _Pragma("unroll") for (int _i = 0; _i < 16; ++_i) {                        \
-        IM_SGB(0x008, 4); IM_SGB(0x002, 14); IM_SGB(0x100, 1);                 \
-    }                                                                          \
-    IM_SGB(0x100, 4);                                                          \
-    _Pragma("unroll") for (int _i = 0; _i < 32; ++_i) {                        \
-        IM_SGB(0x008, 2); IM_SGB(0x100, 1);                                    \
-    }
-#else
-#define IM_SCHED_QK_SOFTMAX
-#endif
+    // iteration t: stage K(t+2), V(t+1); prefetch K(t+3), V(t+2); QK^T of tile t+1; softmax of tile t; PV of tile t;
+    // one barrier. Steps run two per trip with the score registers and the LDS ring stages swapped statically - no
+    // register copies and no ring arithmetic; an odd leftover step takes the generic form, then the masked tail.
 #ifdef IM_ABL_NO_STAGE
 #define IM_ABL_STAGE(...) (void)kw; (void)vw;
 #else
@@ -222,27 +274,69 @@ __global__ __launch_bounds__(256, 2) void flash_attn_f32_kernel(AttnArgs a) {
 #else
 #define IM_ABL_BARRIER __syncthreads();
 #endif
-#define IM_STEP(TAIL)                                                                   \
+#define IM_STEP_FAST(KWS, KRS, VWS, VRS, SA, SB, NA, NB)                                \
     {                                                                                   \
-        float* const kw = sK0 + (t & 1) * (KT * KS);                                    \
-        float* const kr = sK0 + ((t + 1) & 1) * (KT * KS);                              \
-        float* const vw = sV0 + ((t + 1) & 1) * (KT * VS);                              \
-        float* const vr = sV0 + (t & 1) * (KT * VS);                                    \
+        float* const kw = sK0 + (KWS) * KSTG;                                           \
+        float* const vw = sV0 + (VWS) * VSTG;                                           \
         IM_ABL_STAGE(IM_STORE_TILE(rk, kw, KS)                                          \
         IM_STORE_TILE(rv, vw, VS)                                                       \
-        IM_LOAD_TILE(rk, K, (t + 3) * KT)                                               \
-        IM_LOAD_TILE(rv, V, (t + 2) * KT))                                              \
-        qk_tile(kr, c, hh, qf, na, nb);                                                 \
-        softmax_tile<TAIL>(sa, sb, t * KT, nk, hh, m_run, l_run, o0, o1);           \
+        IM_LOAD_TILE(rk, K, t + (KWS) + 3)                                              \
+        IM_LOAD_TILE(rv, V, t + (KWS) + 2))                                             \
+        qk_tile(sK0 + (KRS) * KSTG + gk, c, hh, qf, NA, NB);                            \
+        softmax_tile<false>(SA, SB, 0, nk, hh, m_run, l_run, o0, o1);                   \
+        pv_tile(sV0 + (VRS) * VSTG + gv, c, hh, SA, SB, o0, o1);                        \
+        IM_ABL_BARRIER                                                                  \
+    }
+#define IM_STEP(TAIL)                                                                   \
+    {                                                                                   \
+        float* const kw = sK0 + (t & 1) * KSTG;                                         \
+        float* const kr = sK0 + ((t + 1) & 1) * KSTG + gk;                              \
+        float* const vw = sV0 + ((t + 1) & 1) * VSTG;                                   \
+        float* const vr = sV0 + (t & 1) * VSTG + gv;                                    \
+        if (!TAIL) {                                                                    \
+            IM_ABL_STAGE(IM_STORE_TILE(rk, kw, KS)                                      \
+            IM_STORE_TILE(rv, vw, VS)                                                   \
+            IM_LOAD_TILE(rk, K, t + 3)                                                  \
+            IM_LOAD_TILE(rv, V, t + 2))                                                 \
+            qk_tile(kr, c, hh, qf, na, nb);                                             \
+        }                                                                               \
+        softmax_tile<TAIL>(sa, sb, t * (KT * G) + grp * KT, nk, hh, m_run, l_run, o0, o1); \
         pv_tile(vr, c, hh, sa, sb, o0, o1);                                             \
-        IM_SCHED_QK_SOFTMAX                                                             \
-        sa = na; sb = nb;                                                               \
+        if (!TAIL) { sa = na; sb = nb; }                                                \
         IM_ABL_BARRIER                                                                  \
     }
     int t = 0;
+    for (; t + 2 <= nt - 1; t += 2) {            // KWS doubles as the step's parity: the ring stage K(t+2) goes to
+        IM_STEP_FAST(0, 1, 1, 0, sa, sb, na, nb)
+        IM_STEP_FAST(1, 0, 0, 1, na, nb, sa, sb)
+    }
     for (; t < nt - 1; ++t) IM_STEP(false)
     IM_STEP(true)
 #undef IM_STEP
+#undef IM_STEP_FAST
+
+    // ---- merge the key groups: group 1 parks (O, m, l) in LDS ([register][thread], conflict-free), group 0 folds it in
+    if constexpr (G == 2) {
+        float* const sc = smem;
+        const int t1 = tid & 255;
+        if (grp == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sc[r * 256 + t1] = o0[r]; sc[(16 + r) * 256 + t1] = o1[r]; }
+            sc[32 * 256 + t1] = m_run;
+            sc[33 * 256 + t1] = l_run;
+        }
+        __syncthreads();
+        if (grp == 1) return;
+        const float m1 = sc[32 * 256 + t1], l1 = sc[33 * 256 + t1];
+        const float m = fmaxf(m_run, m1);               // group 0 always saw key 0, so m is finite
+        const float w0 = __builtin_amdgcn_exp2f(m_run - m), w1 = __builtin_amdgcn_exp2f(m1 - m);
+        l_run = l_run * w0 + l1 * w1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            o0[r] = o0[r] * w0 + sc[r * 256 + t1] * w1;
+            o1[r] = o1[r] * w0 + sc[(16 + r) * 256 + t1] * w1;
+        }
+    }
 
     // ---- epilogue: lane (c, hh) holds query qrow, d = db*32 + 8*g + 4*hh + (0..3) in registers 4g..4g+3
     if (qrow < nq) {
@@ -258,19 +352,26 @@ __global__ __launch_bounds__(256, 2) void flash_attn_f32_kernel(AttnArgs a) {
     }
 }
 
-hipError_t launch_flash_attn(const AttnArgs& a, hipStream_t s) {
-    if (a.n_max <= 0) return hipSuccess;
-    const size_t lds = ATTN_LDS_FLOATS * sizeof(float);
+template <int G>
+static hipError_t launch_g(const AttnArgs& a, hipStream_t s) {
+    const size_t lds = G * ATTN_LDS_FLOATS * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_f32_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_f32_kernel<G>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    dim3 grid(((a.n_max + 127) / 128) * a.heads * a.batch), block(256);
-    hipLaunchKernelGGL(flash_attn_f32_kernel, grid, block, lds, s, a);
+    dim3 grid(((a.n_max + 127) / 128) * a.heads * a.batch), block(256 * G);
+    hipLaunchKernelGGL(flash_attn_f32_kernel<G>, grid, block, lds, s, a);
     return hipGetLastError();
+}
+
+hipError_t launch_flash_attn(const AttnArgs& a, hipStream_t s) {
+    if (a.n_max <= 0) return hipSuccess;
+    static const int force = [] { const char* e = getenv("IM_ATTN_GROUPS"); return e ? atoi(e) : 0; }();
+    const int g = force ? force : 2;
+    return g == 2 ? launch_g<2>(a, s) : launch_g<1>(a, s);
 }
 
 }  // namespace im
