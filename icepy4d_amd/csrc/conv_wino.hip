@@ -8,46 +8,82 @@
 //   M[p] = sum_cin V[p] * U[p]   for the 16 positions p    -> 16 GEMMs  [tiles x Cin] x [Cin x Cout]
 //   Y = A^T M A   (2x2 outputs)                            A^T = [1 1 1 0; 0 1 -1 -1]
 //
-// Block = 512 threads = 8 waves, output region 8 x 32 pixels = 64 Winograd tiles x 64 output channels; wave w owns
-// positions 2w, 2w+1 for all tiles and channels (2 x 2 x 2 MFMA tiles of 32 x 32 = 128 accumulator registers, so two
-// waves fit per SIMD). Per 8-channel slab: the (8+2) x (32+2) halo patch and the slab's U block [16][64][8] are staged
-// through registers into LDS, every thread transforms one (tile, channel) 4x4 patch into the double-buffered V image,
-// and the MFMAs of slab s run in the same barrier interval as the transform of slab s+1. The inverse transform, bias,
-// ReLU and the optional 2x2 max-pool (exactly one Winograd tile) happen once at the end through an LDS image of M.
-// FUSE1A: the patch is conv1a(img / 255) computed on the fly, as in conv.hip.
+// On gfx950 every VALU / LDS instruction a wave issues costs matrix-pipe time (tools/mfma_peak.hip: a v_fma next to a
+// v_mfma_f32_32x32x2_f32 stream costs its full 4 cycles, with one or two waves per SIMD alike), so the kernel is built
+// for instruction count per MFMA, not for overlap:
+//   * 256 threads = 4 waves (cb, ph), output region 8 x 16 pixels = 32 Winograd tiles x 64 output channels; a wave owns
+//     the 32 tiles x 32 output channels x the 8 Winograd positions of V rows 2 ph, 2 ph + 1 (128 accumulator registers);
+//     TWO blocks share a CU and drift apart, so one block's prologue, barrier waits, epilogue and store drain run under
+//     the other block's MFMAs;
+//   * the input transform happens in REGISTERS, there is no V image: the halo patch lives in LDS as
+//     [channel quad][row][column parity][column / 2] float4 (row stride 20 slots, 2 x 9 used), so the 12 input pixels a
+//     lane needs for its tile and its two V rows are 12 conflict-free ds_read_b128 with compile-time offsets; the two
+//     1-D passes of B^T d B are 32 packed-fp32 adds for 4 channels, and the results ARE the MFMA A operands;
+//   * per 8-channel slab the U block [16][64][8] and the patch are double-buffered and filled by LDS-DMA
+//     (`buffer_load_dwordx4 ... lds`): lane-linear destinations, no staging registers, no ds_write, lane offsets fixed
+//     for the whole kernel, the slab a scalar offset; out-of-image pixels and padding slots read zero through the
+//     descriptor's range check. One barrier per slab;
+//   * epilogue: row pass of A^T M A in registers, the two V-row halves swap half of their partials through LDS (8
+//     float4 per lane each way) and each finishes 16 of the 32 tiles: bias, ReLU, optional 2x2 max-pool (= one tile);
+//   * FUSE1A: the patch is conv1a(img / 255) computed on the fly: thread t keeps the 3 x 3 image neighbourhood of its
+//     patch pixel in registers for the whole kernel, and per slab the conv1a weights of a channel quad are wave-uniform
+//     (scalar loads), so a patch value costs 9 fused multiply-adds per channel and no LDS read.
+//
+// History (same tests, conv 64 -> 64 + pool at 1080p, non-fused): 8-wave kernel with a V image in LDS 2.08 ms; its
+// 4-wave form with a register-local inverse transform 2.08; register input transform, 8 waves, one block per CU 1.60
+// (ablations: no MFMA 0.82, prologue + one slab + epilogue 0.48, no epilogue 1.39); this kernel 1.53 ms.
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 #include "kernels.h"
 
 namespace im {
 
-static constexpr int WTH = 8, WTW = 32;               // output region of a block
-static constexpr int WPH = WTH + 2, WPW = WTW + 2;    // halo patch
-static constexpr int WNT = (WTH / 2) * (WTW / 2);     // 64 tiles
 static constexpr int WCC = 8;                         // channels per slab
-static constexpr int W_SP = WPH * WPW * WCC;          // floats: patch
-static constexpr int W_SV = 16 * WNT * WCC;           // floats: one V image
 static constexpr int W_SU = 16 * 64 * WCC;            // floats: one U block
-static constexpr int W_MAIN = W_SP + 2 * W_SV + 2 * W_SU;
-static constexpr int W_SM = 16 * WNT * 32;            // floats: M image of one 32-channel half (epilogue, aliases the above)
-static constexpr int W_IH = WTH + 4, W_IW = WTW + 4;
-static constexpr int W_FUSE = W_IH * W_IW + 9 * 64 + 64;
-static constexpr int W_LDS_FLOATS = (W_MAIN > W_SM ? W_MAIN : W_SM);
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wmake_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long b = reinterpret_cast<unsigned long long>(base);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    void* p = reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo);
+    return __builtin_amdgcn_make_buffer_rsrc(p, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+// packed fp32 on float4 halves (the compiler scalarises float4 arithmetic)
+__device__ __forceinline__ float4 add4(float4 x, float4 y) {
+    f32x2 a = {x.x, x.y}, b = {x.z, x.w}, c = {y.x, y.y}, d = {y.z, y.w}, r0, r1;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(r0) : "v"(a), "v"(c));
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(r1) : "v"(b), "v"(d));
+    return make_float4(r0.x, r0.y, r1.x, r1.y);
+}
+__device__ __forceinline__ float4 sub4(float4 x, float4 y) {
+    f32x2 a = {x.x, x.y}, b = {x.z, x.w}, c = {y.x, y.y}, d = {y.z, y.w}, r0, r1;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r0) : "v"(a), "v"(c));
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r1) : "v"(b), "v"(d));
+    return make_float4(r0.x, r0.y, r1.x, r1.y);
+}
+
+static constexpr int S_TH = 8, S_TW = 16;
+static constexpr int S_PH = S_TH + 2, S_PW = S_TW + 2;
+static constexpr int S_ROW = 20, S_PAR = 10, S_QUAD = S_PH * S_ROW;   // slots
+static constexpr int S_SP = 2 * S_QUAD * 4;                 // floats per patch stage
+static constexpr int S_MAIN = 2 * S_SP + 2 * W_SU;
+static constexpr int S_IH = S_TH + 4, S_IW = S_TW + 4;
+static constexpr int S_FUSE = S_IH * S_IW;
+static constexpr int S_LDS_FLOATS = S_MAIN;
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 template <bool POOL, bool FUSE1A>
-__global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* sP = smem;
-    float* sV = smem + W_SP;            // [2][16][64][8]
-    float* sU = sV + 2 * W_SV;          // [2][16][64][8]
-    float* sM = smem;                   // epilogue alias [16][64][32]
-    float* sImg = smem + W_LDS_FLOATS;  // FUSE1A only
-    float* sW1 = sImg + W_IH * W_IW;
-    float* sB1 = sW1 + 9 * 64;
+    float* sP = smem;                   // [2][S_SP]
+    float* sU = smem + 2 * S_SP;        // [2][16][64][8]
+    float* sX = smem;                   // epilogue exchange [2][8][128] float4, aliases the above
+    float* sImg = smem + S_LDS_FLOATS;  // FUSE1A only
 
     const int nslices = a.Cout / 64;
-    const int tx = (a.W + WTW - 1) / WTW, ty = (a.H + WTH - 1) / WTH;
+    const int tx = (a.W + S_TW - 1) / S_TW, ty = (a.H + S_TH - 1) / S_TH;
     const int ntile = tx * ty * a.B;
     const int bid = blockIdx.x;
     const int rtile = (bid & 7) + 8 * ((bid >> 3) / nslices);   // XCD-aware: slices of one region share bid % 8
@@ -55,447 +91,212 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(ConvArgs a) {
     if (rtile >= ntile) return;
     const int b = rtile / (tx * ty);
     const int trem = rtile - b * tx * ty;
-    const int x0 = (trem % tx) * WTW, y0 = (trem / tx) * WTH;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int x0 = (trem % tx) * S_TW, y0 = (trem / tx) * S_TH;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 31, hh = lane >> 5;
-    const float* in = a.in + (long)b * a.H * a.W * a.Cin;
+    const int cb = wave & 1, ph = wave >> 1;
 
+    // ---- staging plan of this thread, fixed for the whole kernel: pixel slot tid of the patch image
+    const int p_row = tid / S_ROW, p_rem = tid - p_row * S_ROW;
+    const int p_par = p_rem >= S_PAR ? 1 : 0, p_s = p_rem - p_par * S_PAR;
+    const int p_px = 2 * p_s + p_par, p_gy = y0 + p_row - 1, p_gx = x0 + p_px - 1;
+    const bool p_slot = tid < S_QUAD && p_s < S_PW / 2;
+    const bool p_in = p_slot && p_gy >= 0 && p_gy < a.H && p_gx >= 0 && p_gx < a.W;
+
+    float tap[9];
     if constexpr (FUSE1A) {
         const uint8_t* img = a.img + (long)b * a.H * a.W;
-        for (int idx = tid; idx < W_IH * W_IW; idx += 512) {
-            const int iy = idx / W_IW, ix = idx - iy * W_IW;
+        for (int idx = tid; idx < S_IH * S_IW; idx += 256) {
+            const int iy = idx / S_IW, ix = idx - iy * S_IW;
             const int gy = y0 + iy - 2, gx = x0 + ix - 2;
             float v = 0.f;
             if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = (float)img[(long)gy * a.W + gx] / 255.0f;
             sImg[idx] = v;
         }
-        for (int idx = tid; idx < 9 * 64 + 64; idx += 512) sW1[idx] = idx < 576 ? a.w1[idx] : a.b1[idx - 576];
         __syncthreads();
+        const int iy = min(p_row, S_PH - 1), ix = min(p_px, S_PW - 1);
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) tap[dy * 3 + dx] = sImg[(iy + dy) * S_IW + ix + dx];
     }
 
-    f32x16 acc[2][2][2];  // [position of this wave][tile block][cout block]
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[q][i][j][r] = 0.f;
+    const __amdgpu_buffer_rsrc_t rin = wmake_rsrc(FUSE1A ? (const void*)a.w : (const void*)(a.in + (long)b * a.H * a.W * a.Cin),
+                                                  FUSE1A ? 0u : (unsigned)a.H * a.W * a.Cin * 4u);
+    const __amdgpu_buffer_rsrc_t ruw = wmake_rsrc(a.w, (unsigned)(a.Cin / WCC) * 16u * a.Cout * WCC * 4u);
+    const unsigned pv = p_in ? (unsigned)(((unsigned)p_gy * a.W + p_gx) * a.Cin) * 4u : 0xFFFFF000u;
+    // U slots tid + 256 k, k < 8: float4 (pos * 64 + co) * 2 + quad of the slab block; pos = (tid >> 7) + 2 k
+    const unsigned uv = (unsigned)((((tid >> 7) * a.Cout + co0 + ((tid >> 1) & 63)) * WCC) + (tid & 1) * 4) * 4u;
+    const unsigned u_slab_bytes = 16u * a.Cout * WCC * 4u, u_k_bytes = 2u * a.Cout * WCC * 4u;
 
-    // patch item idx of a slab: pixel idx >> 1 of the patch, channels 4 * (idx & 1) .. + 3   (680 items)
-    auto patch_item = [&](int idx, int slab) -> float4 {
-        const int pix = min(idx, WPH * WPW * 2 - 1) >> 1, c4 = idx & 1;
-        const int py = pix / WPW, px = pix - py * WPW;
-        const int gy = y0 + py - 1, gx = x0 + px - 1;
-        const bool inside = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-        float4 v;
-        if constexpr (FUSE1A) {
-            const int ch = slab * WCC + c4 * 4;
-            v = *reinterpret_cast<const float4*>(sB1 + ch);
+    auto fused_quad = [&](int ch) -> float4 {      // conv1a(img / 255) of this thread's pixel, channels ch .. ch + 3 (uniform)
+        const float4 bq = *reinterpret_cast<const float4*>(a.b1 + ch);
+        f32x2 lo = {bq.x, bq.y}, hi = {bq.z, bq.w};
 #pragma unroll
-            for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    const float pv = sImg[(py + dy) * W_IW + px + dx];
-                    const float4 wv = *reinterpret_cast<const float4*>(sW1 + (dy * 3 + dx) * 64 + ch);
-                    v.x = fmaf(pv, wv.x, v.x); v.y = fmaf(pv, wv.y, v.y); v.z = fmaf(pv, wv.z, v.z); v.w = fmaf(pv, wv.w, v.w);
-                }
-            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-        } else {
-            const int cy = min(max(gy, 0), a.H - 1), cx = min(max(gx, 0), a.W - 1);
-            v = *reinterpret_cast<const float4*>(in + ((long)cy * a.W + cx) * a.Cin + slab * WCC + c4 * 4);
+        for (int t = 0; t < 9; ++t) {
+            const float4 wv = *reinterpret_cast<const float4*>(a.w1 + t * 64 + ch);
+            const f32x2 tt = {tap[t], tap[t]};
+            lo = __builtin_elementwise_fma(tt, f32x2{wv.x, wv.y}, lo);
+            hi = __builtin_elementwise_fma(tt, f32x2{wv.z, wv.w}, hi);
         }
-        if (!inside) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 v = make_float4(fmaxf(lo.x, 0.f), fmaxf(lo.y, 0.f), fmaxf(hi.x, 0.f), fmaxf(hi.y, 0.f));
+        if (!p_in) v = make_float4(0.f, 0.f, 0.f, 0.f);
         return v;
     };
-    // U item idx of a slab: row = idx >> 1 = pos * 64 + co of the slab's [16][Cout][8] block, channels 4 * (idx & 1) ..
-    auto u_item = [&](int idx, int slab) -> float4 {
-        const int row = idx >> 1, c4 = idx & 1;
-        return *reinterpret_cast<const float4*>(a.w + (((long)slab * 16 + (row >> 6)) * a.Cout + co0 + (row & 63)) * WCC + c4 * 4);
-    };
-    float4 p0 = {}, p1 = {}, u0, u1, u2, u3;
-#define IM_WFETCH(slab)                                                                      \
-    if constexpr (!FUSE1A) { p0 = patch_item(tid, slab); p1 = patch_item(tid + 512, slab); } \
-    u0 = u_item(tid, slab); u1 = u_item(tid + 512, slab); u2 = u_item(tid + 1024, slab); u3 = u_item(tid + 1536, slab);
-#define IM_WPUT(base, i, r) *reinterpret_cast<float4*>((base) + (tid + (i) * 512) * 4) = r
-#define IM_WCOMMIT(slab)                                                                     \
-    {                                                                                        \
-        float* ub = sU + ((slab) & 1) * W_SU;                                                \
-        if constexpr (FUSE1A) {                                                              \
-            IM_WPUT(sP, 0, patch_item(tid, slab));                                           \
-            if (tid + 512 < WPH * WPW * 2) IM_WPUT(sP, 1, patch_item(tid + 512, slab));      \
-        } else {                                                                             \
-            IM_WPUT(sP, 0, p0);                                                              \
-            if (tid + 512 < WPH * WPW * 2) IM_WPUT(sP, 1, p1);                               \
-        }                                                                                    \
-        IM_WPUT(ub, 0, u0); IM_WPUT(ub, 1, u1); IM_WPUT(ub, 2, u2); IM_WPUT(ub, 3, u3);      \
-    }
-    // input transform of one (tile, channel): thread t -> tile t >> 3, channel t & 7; V image [pos][tile][8]
-    const int t_tile = tid >> 3, t_ch = tid & 7;
-    const int t_ty = t_tile >> 4, t_tx = t_tile & 15;
-#define IM_WTRANSFORM(slab)                                                                  \
-    {                                                                                        \
-        float* vb = sV + ((slab) & 1) * W_SV + t_tile * WCC + t_ch;                          \
-        const float* pp = sP + ((2 * t_ty) * WPW + 2 * t_tx) * WCC + t_ch;                   \
-        float d[4][4];                                                                       \
-        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                     \
-            _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) d[i_][j_] = pp[(i_ * WPW + j_) * WCC]; \
-        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                   \
-            const float r0 = d[0][j_] - d[2][j_], r1 = d[1][j_] + d[2][j_];                  \
-            const float r2 = d[2][j_] - d[1][j_], r3 = d[1][j_] - d[3][j_];                  \
-            d[0][j_] = r0; d[1][j_] = r1; d[2][j_] = r2; d[3][j_] = r3;                      \
-        }                                                                                    \
-        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                   \
-            vb[(i_ * 4 + 0) * WNT * WCC] = d[i_][0] - d[i_][2];                              \
-            vb[(i_ * 4 + 1) * WNT * WCC] = d[i_][1] + d[i_][2];                              \
-            vb[(i_ * 4 + 2) * WNT * WCC] = d[i_][2] - d[i_][1];                              \
-            vb[(i_ * 4 + 3) * WNT * WCC] = d[i_][1] - d[i_][3];                              \
-        }                                                                                    \
-    }
-#define IM_WMMA(slab)                                                                        \
-    {                                                                                        \
-        _Pragma("unroll") for (int q_ = 0; q_ < 2; ++q_) {                                   \
-            const float* vq = sV + ((slab) & 1) * W_SV + ((2 * wave + q_) * WNT + c) * WCC + hh * 4; \
-            const float* uq = sU + ((slab) & 1) * W_SU + ((2 * wave + q_) * 64 + c) * WCC + hh * 4;  \
-            const float4 a0 = *reinterpret_cast<const float4*>(vq);                          \
-            const float4 a1 = *reinterpret_cast<const float4*>(vq + 32 * WCC);               \
-            const float4 b0 = *reinterpret_cast<const float4*>(uq);                          \
-            const float4 b1 = *reinterpret_cast<const float4*>(uq + 32 * WCC);               \
-            IM_WSTEP(q_, x) IM_WSTEP(q_, y) IM_WSTEP(q_, z) IM_WSTEP(q_, w)                  \
-        }                                                                                    \
-    }
-#define IM_WSTEP(q_, e)                                         \
-    acc[q_][0][0] = mfma32(a0.e, b0.e, acc[q_][0][0]);          \
-    acc[q_][0][1] = mfma32(a0.e, b1.e, acc[q_][0][1]);          \
-    acc[q_][1][0] = mfma32(a1.e, b0.e, acc[q_][1][0]);          \
-    acc[q_][1][1] = mfma32(a1.e, b1.e, acc[q_][1][1]);
-
-    const int nslab = a.Cin / WCC;
-    IM_WFETCH(0)
-    IM_WCOMMIT(0)
-    if (nslab > 1) { IM_WFETCH(1) }
-    __syncthreads();
-    IM_WTRANSFORM(0)
-    __syncthreads();
-    for (int slab = 0; slab < nslab; ++slab) {
-        if (slab + 1 < nslab) {
-            IM_WCOMMIT(slab + 1)           // patch + U of slab s+1 (sP was last read by the transform of slab s)
-            if (slab + 2 < nslab) { IM_WFETCH(slab + 2) }
-        }
-        __syncthreads();
-        // The two waves that share a SIMD (w and w + 4) take the interval's two jobs in opposite order, so one wave's
-        // transform VALU/LDS work runs under the other's MFMAs instead of both queueing on the same pipe.
-        if (wave < 4) {
-            if (slab + 1 < nslab) IM_WTRANSFORM(slab + 1)
-            IM_WMMA(slab)
-        } else {
-            IM_WMMA(slab)
-            if (slab + 1 < nslab) IM_WTRANSFORM(slab + 1)
-        }
-        __syncthreads();
-    }
-#undef IM_WFETCH
-#undef IM_WPUT
-#undef IM_WCOMMIT
-#undef IM_WTRANSFORM
-#undef IM_WMMA
-#undef IM_WSTEP
-
-    // ---- inverse transform + bias + ReLU (+ pool), one 32-channel half at a time through the M image [16][64][32]
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-        if (cb) __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-            for (int tb = 0; tb < 2; ++tb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    sM[((2 * wave + q) * WNT + tb * 32 + acc_row(r, hh)) * 32 + c] = acc[q][tb][cb][r];
-        __syncthreads();
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int idx = tid + it * 512;
-            const int co_l = idx & 31, tile = idx >> 5;
-            const int tyy = tile >> 4, txx = tile & 15;
-            float m[4][4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) m[i][j] = sM[((i * 4 + j) * WNT + tile) * 32 + co_l];
-            float s0[4], s1[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                s0[j] = (m[0][j] + m[1][j]) + m[2][j];
-                s1[j] = (m[1][j] - m[2][j]) - m[3][j];
-            }
-            const int co = co0 + cb * 32 + co_l;
-            const float bv = a.bias[co];
-            float y00 = (s0[0] + s0[1]) + s0[2] + bv, y01 = (s0[1] - s0[2]) - s0[3] + bv;
-            float y10 = (s1[0] + s1[1]) + s1[2] + bv, y11 = (s1[1] - s1[2]) - s1[3] + bv;
-            if (a.relu) { y00 = fmaxf(y00, 0.f); y01 = fmaxf(y01, 0.f); y10 = fmaxf(y10, 0.f); y11 = fmaxf(y11, 0.f); }
-            const int oy = y0 + 2 * tyy, ox = x0 + 2 * txx;
-            if constexpr (POOL) {
-                const int Ho = a.H >> 1, Wo = a.W >> 1;
-                const int py = oy >> 1, px = ox >> 1;
-                if (py < Ho && px < Wo)
-                    a.out[(((long)b * Ho + py) * Wo + px) * a.Cout + co] = fmaxf(fmaxf(y00, y01), fmaxf(y10, y11));
-            } else {
-                float* o = a.out + (((long)b * a.H + oy) * a.W + ox) * a.Cout + co;
-                if (oy < a.H && ox < a.W) o[0] = y00;
-                if (oy < a.H && ox + 1 < a.W) o[a.Cout] = y01;
-                if (oy + 1 < a.H && ox < a.W) o[(long)a.W * a.Cout] = y10;
-                if (oy + 1 < a.H && ox + 1 < a.W) o[(long)a.W * a.Cout + a.Cout] = y11;
-            }
-        }
-    }
-}
-
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Variant B: 256 threads = 4 waves; wave (tb, cb) owns ALL 16 Winograd positions of tile block tb (32 tiles) x channel
-// block cb (32 channels): 16 x 16 = 256 accumulator registers, one wave per SIMD. Same LDS images and slab pipeline as
-// above, but the inverse transform A^T M A is register-local (a lane holds one output channel, a register one tile, and
-// the 16 positions are 16 accumulators), so the epilogue needs no LDS round trip and no barrier. Measured equal to
-// variant A (conv1b at 1080p: 2.0 ms both); ablations of this variant (IM_ABL_*): without MFMAs 1.21 ms, without the
-// transform 1.88, without staging 1.81, without the epilogue 1.95, prologue + one slab + epilogue only 0.49 ms, i.e.
-// the MFMA share is 0.87 ms and nothing overlaps it yet at one block per CU (selected with IM_WINO_VARIANT=B).
-template <bool POOL, bool FUSE1A>
-__global__ __launch_bounds__(256) void conv3x3_wino_kernel_b(ConvArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* sP = smem;
-    float* sV = smem + W_SP;
-    float* sU = sV + 2 * W_SV;
-    float* sImg = smem + W_MAIN;
-    float* sW1 = sImg + W_IH * W_IW;
-    float* sB1 = sW1 + 9 * 64;
-
-    const int nslices = a.Cout / 64;
-    const int tx = (a.W + WTW - 1) / WTW, ty = (a.H + WTH - 1) / WTH;
-    const int ntile = tx * ty * a.B;
-    const int bid = blockIdx.x;
-    const int rtile = (bid & 7) + 8 * ((bid >> 3) / nslices);
-    const int co0 = ((bid >> 3) % nslices) * 64;
-    if (rtile >= ntile) return;
-    const int b = rtile / (tx * ty);
-    const int trem = rtile - b * tx * ty;
-    const int x0 = (trem % tx) * WTW, y0 = (trem / tx) * WTH;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int c = lane & 31, hh = lane >> 5;
-    const int tb = wave & 1, cb = wave >> 1;
-    const float* in = a.in + (long)b * a.H * a.W * a.Cin;
-
-    if constexpr (FUSE1A) {
-        const uint8_t* img = a.img + (long)b * a.H * a.W;
-        for (int idx = tid; idx < W_IH * W_IW; idx += 256) {
-            const int iy = idx / W_IW, ix = idx - iy * W_IW;
-            const int gy = y0 + iy - 2, gx = x0 + ix - 2;
-            float v = 0.f;
-            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = (float)img[(long)gy * a.W + gx] / 255.0f;
-            sImg[idx] = v;
-        }
-        for (int idx = tid; idx < 9 * 64 + 64; idx += 256) sW1[idx] = idx < 576 ? a.w1[idx] : a.b1[idx - 576];
-        __syncthreads();
+    // fill stage (slab & 1) with slab's U block and patch
+#define IM_SSTAGE(slab)                                                                                 \
+    {                                                                                                   \
+        float* ub = sU + ((slab) & 1) * W_SU + wave * 256;                                              \
+        const unsigned so_ = (slab) * u_slab_bytes;                                                     \
+        _Pragma("unroll") for (int k_ = 0; k_ < 8; ++k_)                                                \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ruw, (lds_ptr_t)(ub + k_ * 1024), 16, uv, so_ + k_ * u_k_bytes, 0, 0); \
+        float* pb = sP + ((slab) & 1) * S_SP;                                                           \
+        if (tid < S_QUAD) {                                                                             \
+            if constexpr (FUSE1A) {                                                                     \
+                reinterpret_cast<float4*>(pb)[tid] = fused_quad((slab) * WCC);                          \
+                reinterpret_cast<float4*>(pb)[S_QUAD + tid] = fused_quad((slab) * WCC + 4);             \
+            } else {                                                                                    \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_ptr_t)(pb + wave * 256), 16, pv, (slab) * (WCC * 4u), 0, 0); \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_ptr_t)(pb + S_QUAD * 4 + wave * 256), 16, pv, (slab) * (WCC * 4u) + 16u, 0, 0); \
+            }                                                                                           \
+        }                                                                                               \
     }
 
-    f32x16 acc[16];
+    f32x16 acc[8];   // position (2 ph + (p >> 2), p & 3)
 #pragma unroll
-    for (int p = 0; p < 16; ++p)
+    for (int p = 0; p < 8; ++p)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
 
-    auto patch_item = [&](int idx, int slab) -> float4 {
-        const int pix = min(idx, WPH * WPW * 2 - 1) >> 1, c4 = idx & 1;
-        const int py = pix / WPW, px = pix - py * WPW;
-        const int gy = y0 + py - 1, gx = x0 + px - 1;
-        const bool inside = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-        float4 v;
-        if constexpr (FUSE1A) {
-            const int ch = slab * WCC + c4 * 4;
-            v = *reinterpret_cast<const float4*>(sB1 + ch);
-#pragma unroll
-            for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    const float pv = sImg[(py + dy) * W_IW + px + dx];
-                    const float4 wv = *reinterpret_cast<const float4*>(sW1 + (dy * 3 + dx) * 64 + ch);
-                    v.x = fmaf(pv, wv.x, v.x); v.y = fmaf(pv, wv.y, v.y); v.z = fmaf(pv, wv.z, v.z); v.w = fmaf(pv, wv.w, v.w);
-                }
-            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-        } else {
-            const int cy = min(max(gy, 0), a.H - 1), cx = min(max(gx, 0), a.W - 1);
-            v = *reinterpret_cast<const float4*>(in + ((long)cy * a.W + cx) * a.Cin + slab * WCC + c4 * 4);
-        }
-        if (!inside) v = make_float4(0.f, 0.f, 0.f, 0.f);
-        return v;
-    };
-    auto u_item = [&](int idx, int slab) -> float4 {
-        const int row = idx >> 1, c4 = idx & 1;
-        return *reinterpret_cast<const float4*>(a.w + (((long)slab * 16 + (row >> 6)) * a.Cout + co0 + (row & 63)) * WCC + c4 * 4);
-    };
-    float4 p0 = {}, p1 = {}, p2 = {}, u0, u1, u2, u3, u4, u5, u6, u7;
-#define IM_BFETCH(slab)                                                                                          \
-    if constexpr (!FUSE1A) { p0 = patch_item(tid, slab); p1 = patch_item(tid + 256, slab); p2 = patch_item(tid + 512, slab); } \
-    u0 = u_item(tid, slab); u1 = u_item(tid + 256, slab); u2 = u_item(tid + 512, slab); u3 = u_item(tid + 768, slab);  \
-    u4 = u_item(tid + 1024, slab); u5 = u_item(tid + 1280, slab); u6 = u_item(tid + 1536, slab); u7 = u_item(tid + 1792, slab);
-#define IM_BPUT(base, i, r) *reinterpret_cast<float4*>((base) + (tid + (i) * 256) * 4) = r
-#define IM_BCOMMIT(slab)                                                                     \
-    {                                                                                        \
-        float* ub = sU + ((slab) & 1) * W_SU;                                                \
-        if constexpr (FUSE1A) {                                                              \
-            IM_BPUT(sP, 0, patch_item(tid, slab)); IM_BPUT(sP, 1, patch_item(tid + 256, slab)); \
-            if (tid + 512 < WPH * WPW * 2) IM_BPUT(sP, 2, patch_item(tid + 512, slab));      \
-        } else {                                                                             \
-            IM_BPUT(sP, 0, p0); IM_BPUT(sP, 1, p1);                                          \
-            if (tid + 512 < WPH * WPW * 2) IM_BPUT(sP, 2, p2);                               \
-        }                                                                                    \
-        IM_BPUT(ub, 0, u0); IM_BPUT(ub, 1, u1); IM_BPUT(ub, 2, u2); IM_BPUT(ub, 3, u3);      \
-        IM_BPUT(ub, 4, u4); IM_BPUT(ub, 5, u5); IM_BPUT(ub, 6, u6); IM_BPUT(ub, 7, u7);      \
-    }
-    // input transform: thread t handles (tile, channel) items t and t + 256
-#define IM_BTRANSFORM1(slab, item)                                                           \
-    {                                                                                        \
-        const int tt_ = (item) >> 3, tc_ = (item) & 7;                                       \
-        float* vb = sV + ((slab) & 1) * W_SV + tt_ * WCC + tc_;                              \
-        const float* pp = sP + ((2 * (tt_ >> 4)) * WPW + 2 * (tt_ & 15)) * WCC + tc_;        \
-        float d[4][4];                                                                       \
-        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                     \
-            _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) d[i_][j_] = pp[(i_ * WPW + j_) * WCC]; \
-        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                   \
-            const float r0 = d[0][j_] - d[2][j_], r1 = d[1][j_] + d[2][j_];                  \
-            const float r2 = d[2][j_] - d[1][j_], r3 = d[1][j_] - d[3][j_];                  \
-            d[0][j_] = r0; d[1][j_] = r1; d[2][j_] = r2; d[3][j_] = r3;                      \
-        }                                                                                    \
-        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                   \
-            vb[(i_ * 4 + 0) * WNT * WCC] = d[i_][0] - d[i_][2];                              \
-            vb[(i_ * 4 + 1) * WNT * WCC] = d[i_][1] + d[i_][2];                              \
-            vb[(i_ * 4 + 2) * WNT * WCC] = d[i_][2] - d[i_][1];                              \
-            vb[(i_ * 4 + 3) * WNT * WCC] = d[i_][1] - d[i_][3];                              \
-        }                                                                                    \
-    }
-#define IM_BTRANSFORM(slab) IM_BTRANSFORM1(slab, tid) IM_BTRANSFORM1(slab, tid + 256)
-#define IM_BMMA(slab)                                                                        \
-    {                                                                                        \
-        const float* vq = sV + ((slab) & 1) * W_SV + (tb * 32 + c) * WCC + hh * 4;           \
-        const float* uq = sU + ((slab) & 1) * W_SU + (cb * 32 + c) * WCC + hh * 4;           \
-        _Pragma("unroll") for (int p_ = 0; p_ < 16; ++p_) {                                  \
-            const float4 av = *reinterpret_cast<const float4*>(vq + p_ * WNT * WCC);         \
-            const float4 bv = *reinterpret_cast<const float4*>(uq + p_ * 64 * WCC);          \
-            acc[p_] = mfma32(av.x, bv.x, acc[p_]); acc[p_] = mfma32(av.y, bv.y, acc[p_]);    \
-            acc[p_] = mfma32(av.z, bv.z, acc[p_]); acc[p_] = mfma32(av.w, bv.w, acc[p_]);    \
-        }                                                                                    \
+    // lane (c, hh): tile c of the 4 x 8 tile grid, channel quad hh; B operand: output channel cb * 32 + c
+    const int t_ty = c >> 3, t_tx = c & 7;
+    const int a_slot = hh * S_QUAD + (2 * t_ty + ph) * S_ROW + t_tx;         // patch row 2 ty + ph, parity 0, quad hh
+    const int b_slot = ((ph * 8) * 64 + cb * 32 + c) * 2 + hh;               // position 8 ph, this lane's channel
+#define IM_SD(i, j) pa[a_slot + (i) * S_ROW + ((j) & 1) * S_PAR + ((j) >> 1)]
+#define IM_SMMA(slab)                                                                                   \
+    {                                                                                                   \
+        const float4* pa = reinterpret_cast<const float4*>(sP + ((slab) & 1) * S_SP);                   \
+        const float4* ua = reinterpret_cast<const float4*>(sU + ((slab) & 1) * W_SU) + b_slot;          \
+        float4 v[8];                                                                                    \
+        {                                                                                               \
+            float4 t0[4], t1[4];                                                                        \
+            if (ph == 0) {              /* V rows 0, 1 from patch rows 0, 1, 2 */                       \
+                _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                      \
+                    const float4 d0 = IM_SD(0, j_), d1 = IM_SD(1, j_), d2 = IM_SD(2, j_);               \
+                    t0[j_] = sub4(d0, d2); t1[j_] = add4(d1, d2);                                       \
+                }                                                                                       \
+            } else {                    /* V rows 2, 3 from patch rows 1, 2, 3 (= rows 0, 1, 2 relative to ph) */ \
+                _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                      \
+                    const float4 d1 = IM_SD(0, j_), d2 = IM_SD(1, j_), d3 = IM_SD(2, j_);               \
+                    t0[j_] = sub4(d2, d1); t1[j_] = sub4(d1, d3);                                       \
+                }                                                                                       \
+            }                                                                                           \
+            v[0] = sub4(t0[0], t0[2]); v[1] = add4(t0[1], t0[2]); v[2] = sub4(t0[2], t0[1]); v[3] = sub4(t0[1], t0[3]); \
+            v[4] = sub4(t1[0], t1[2]); v[5] = add4(t1[1], t1[2]); v[6] = sub4(t1[2], t1[1]); v[7] = sub4(t1[1], t1[3]); \
+        }                                                                                               \
+        float4 u[8];                                                                                    \
+        _Pragma("unroll") for (int p_ = 0; p_ < 8; ++p_) u[p_] = ua[p_ * 128];                          \
+        _Pragma("unroll") for (int p_ = 0; p_ < 8; ++p_) acc[p_] = mfma32(v[p_].x, u[p_].x, acc[p_]);   \
+        _Pragma("unroll") for (int p_ = 0; p_ < 8; ++p_) acc[p_] = mfma32(v[p_].y, u[p_].y, acc[p_]);   \
+        _Pragma("unroll") for (int p_ = 0; p_ < 8; ++p_) acc[p_] = mfma32(v[p_].z, u[p_].z, acc[p_]);   \
+        _Pragma("unroll") for (int p_ = 0; p_ < 8; ++p_) acc[p_] = mfma32(v[p_].w, u[p_].w, acc[p_]);   \
     }
 
     const int nslab = a.Cin / WCC;
-    IM_BFETCH(0)
-    IM_BCOMMIT(0)
-    if (nslab > 1) { IM_BFETCH(1) }
+    IM_SSTAGE(0)
     __syncthreads();
-    IM_BTRANSFORM(0)
-    __syncthreads();
-#ifdef IM_ABL_NO_LOOP
-    for (int slab = 0; slab + 1 < 1; ++slab) {
-#else
-    for (int slab = 0; slab + 1 < nslab; ++slab) {
-#endif
-#ifndef IM_ABL_NO_STAGE
-        IM_BCOMMIT(slab + 1)
-        if (slab + 2 < nslab) { IM_BFETCH(slab + 2) }
-#endif
-        __syncthreads();
-#ifndef IM_ABL_NO_MMA
-        IM_BMMA(slab)
-#endif
-#ifndef IM_ABL_NO_TRANSFORM
-        IM_BTRANSFORM(slab + 1)
-#endif
-        __syncthreads();
+    for (int slab = 0; slab < nslab; ++slab) {
+        if (slab + 1 < nslab) IM_SSTAGE(slab + 1)   // stage (slab + 1) & 1 was last read in step slab - 1
+        IM_SMMA(slab)
+        __syncthreads();                            // also waits for the DMA of this step (vmcnt(0))
     }
-    IM_BMMA(nslab - 1)
-#undef IM_BFETCH
-#undef IM_BPUT
-#undef IM_BCOMMIT
-#undef IM_BTRANSFORM1
-#undef IM_BTRANSFORM
-#undef IM_BMMA
+#undef IM_SSTAGE
+#undef IM_SD
+#undef IM_SMMA
 
-#ifdef IM_ABL_NO_EPI
-    { float keep = 0.f;
-      _Pragma("unroll") for (int p_ = 0; p_ < 16; ++p_) keep += acc[p_][0];
-      if (keep == 123.456f) a.out[0] = keep;
-      return; }
-#endif
-    // ---- register-local inverse transform: lane = output channel, register r = tile tb*32 + acc_row(r, hh)
+    // ---- inverse transform Y = A^T M A. Row pass (over j) in registers: s[il][b]; the column pass needs both V-row halves:
+    //   Y[0][b] = s[0][b] + s[1][b] + s[2][b],   Y[1][b] = s[1][b] - s[2][b] - s[3][b]
+    // ph 0 holds {s0 + s1, s1}, ph 1 holds {s2, -(s2 + s3)}; ph 0 keeps accumulator registers 0..7, ph 1 registers 8..15,
+    // and each sends the other its partials of the registers it gives away ([sender][slot][thread] float4).
+    f32x16 e00, e01, e10, e11;
+    {
+        const f32x16 sa0 = (acc[0] + acc[1]) + acc[2], sa1 = (acc[1] - acc[2]) - acc[3];
+        const f32x16 sb0 = (acc[4] + acc[5]) + acc[6], sb1 = (acc[5] - acc[6]) - acc[7];
+        if (ph == 0) { e00 = sa0 + sb0; e01 = sa1 + sb1; e10 = sb0; e11 = sb1; }
+        else { e00 = sa0; e01 = sa1; e10 = -(sa0 + sb0); e11 = -(sa1 + sb1); }
+    }
     const int co = co0 + cb * 32 + c;
     const float bv = a.bias[co];
+    auto finish = [&](auto PH) {
+        constexpr int P = decltype(PH)::value;
+        constexpr int G = P == 0 ? 8 : 0;     // first register given away
+        constexpr int K = P == 0 ? 0 : 8;     // first register kept
+        float4* xs = reinterpret_cast<float4*>(sX) + (P * 8) * 128 + (tid & 127);
+#define IM_SX(e, k) make_float4(e[G + 4 * (k)], e[G + 1 + 4 * (k)], e[G + 2 + 4 * (k)], e[G + 3 + 4 * (k)])
+        xs[0 * 128] = IM_SX(e00, 0); xs[1 * 128] = IM_SX(e00, 1);
+        xs[2 * 128] = IM_SX(e01, 0); xs[3 * 128] = IM_SX(e01, 1);
+        xs[4 * 128] = IM_SX(e10, 0); xs[5 * 128] = IM_SX(e10, 1);
+        xs[6 * 128] = IM_SX(e11, 0); xs[7 * 128] = IM_SX(e11, 1);
+#undef IM_SX
+        __syncthreads();
+        const float4* xr = reinterpret_cast<const float4*>(sX) + ((P ^ 1) * 8) * 128 + (tid & 127);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int tile = tb * 32 + acc_row(r, hh);
-        const int tyy = tile >> 4, txx = tile & 15;
-        float s0[4], s1[4];
+        for (int k = 0; k < 2; ++k) {
+            const float4 x00 = xr[(0 + k) * 128], x01 = xr[(2 + k) * 128], x10 = xr[(4 + k) * 128], x11 = xr[(6 + k) * 128];
+            const float a00[4] = {x00.x, x00.y, x00.z, x00.w}, a01[4] = {x01.x, x01.y, x01.z, x01.w};
+            const float a10[4] = {x10.x, x10.y, x10.z, x10.w}, a11[4] = {x11.x, x11.y, x11.z, x11.w};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            s0[j] = (acc[0 + j][r] + acc[4 + j][r]) + acc[8 + j][r];
-            s1[j] = (acc[4 + j][r] - acc[8 + j][r]) - acc[12 + j][r];
+            for (int q = 0; q < 4; ++q) {
+                const int r = K + 4 * k + q;
+                float y00 = e00[r] + a00[q] + bv, y01 = e01[r] + a01[q] + bv, y10 = e10[r] + a10[q] + bv, y11 = e11[r] + a11[q] + bv;
+                if (a.relu) { y00 = fmaxf(y00, 0.f); y01 = fmaxf(y01, 0.f); y10 = fmaxf(y10, 0.f); y11 = fmaxf(y11, 0.f); }
+                const int tl = acc_row(r, hh);
+                const int tyy = tl >> 3, txx = tl & 7;
+                const int oy = y0 + 2 * tyy, ox = x0 + 2 * txx;
+                if constexpr (POOL) {
+                    const int Ho = a.H >> 1, Wo = a.W >> 1;
+                    const int py = oy >> 1, px = ox >> 1;
+                    if (py < Ho && px < Wo) a.out[(((long)b * Ho + py) * Wo + px) * a.Cout + co] = fmaxf(fmaxf(y00, y01), fmaxf(y10, y11));
+                } else {
+                    float* o = a.out + (((long)b * a.H + oy) * a.W + ox) * a.Cout + co;
+                    if (oy < a.H && ox < a.W) o[0] = y00;
+                    if (oy < a.H && ox + 1 < a.W) o[a.Cout] = y01;
+                    if (oy + 1 < a.H && ox < a.W) o[(long)a.W * a.Cout] = y10;
+                    if (oy + 1 < a.H && ox + 1 < a.W) o[(long)a.W * a.Cout + a.Cout] = y11;
+                }
+            }
         }
-        float y00 = (s0[0] + s0[1]) + s0[2] + bv, y01 = (s0[1] - s0[2]) - s0[3] + bv;
-        float y10 = (s1[0] + s1[1]) + s1[2] + bv, y11 = (s1[1] - s1[2]) - s1[3] + bv;
-        if (a.relu) { y00 = fmaxf(y00, 0.f); y01 = fmaxf(y01, 0.f); y10 = fmaxf(y10, 0.f); y11 = fmaxf(y11, 0.f); }
-        const int oy = y0 + 2 * tyy, ox = x0 + 2 * txx;
-        if constexpr (POOL) {
-            const int Ho = a.H >> 1, Wo = a.W >> 1;
-            const int py = oy >> 1, px = ox >> 1;
-            if (py < Ho && px < Wo) a.out[(((long)b * Ho + py) * Wo + px) * a.Cout + co] = fmaxf(fmaxf(y00, y01), fmaxf(y10, y11));
-        } else {
-            float* o = a.out + (((long)b * a.H + oy) * a.W + ox) * a.Cout + co;
-            if (oy < a.H && ox < a.W) o[0] = y00;
-            if (oy < a.H && ox + 1 < a.W) o[a.Cout] = y01;
-            if (oy + 1 < a.H && ox < a.W) o[(long)a.W * a.Cout] = y10;
-            if (oy + 1 < a.H && ox + 1 < a.W) o[(long)a.W * a.Cout + a.Cout] = y11;
-        }
-    }
+    };
+    if (ph == 0) finish(std::integral_constant<int, 0>{});
+    else finish(std::integral_constant<int, 1>{});
 }
 
 
+// a.w must be the Winograd-packed weights [Cin/8][16][Cout][8] (pack_conv3x3_wino)
 template <bool POOL, bool FUSE>
-static hipError_t launch_wino_variant(const ConvArgs& a, hipStream_t s) {
-    const int ntile = ((a.W + WTW - 1) / WTW) * ((a.H + WTH - 1) / WTH) * a.B;
-    static const char variant = getenv("IM_WINO_VARIANT") ? getenv("IM_WINO_VARIANT")[0] : 'A';  // A (default) / B: tuning switch
-    if (variant == 'A') {
-        dim3 grid(((ntile + 7) / 8) * 8 * (a.Cout / 64)), block(512);
-        const size_t lds = (W_LDS_FLOATS + (FUSE ? W_FUSE : 0)) * sizeof(float);
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<POOL, FUSE>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-            attr_set = true;
-        }
-        hipLaunchKernelGGL((conv3x3_wino_kernel<POOL, FUSE>), grid, block, lds, s, a);
-        return hipGetLastError();
-    }
+static hipError_t launch_wino(const ConvArgs& a, hipStream_t s) {
+    const int ntile = ((a.W + S_TW - 1) / S_TW) * ((a.H + S_TH - 1) / S_TH) * a.B;
     dim3 grid(((ntile + 7) / 8) * 8 * (a.Cout / 64)), block(256);
-    const size_t lds = (W_MAIN + (FUSE ? W_FUSE : 0)) * sizeof(float);
-    static bool attr_set_b = false;
-    if (!attr_set_b) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel_b<POOL, FUSE>),
+    const size_t lds = (S_LDS_FLOATS + (FUSE ? S_FUSE : 0)) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<POOL, FUSE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        attr_set_b = true;
+        attr_set = true;
     }
-    hipLaunchKernelGGL((conv3x3_wino_kernel_b<POOL, FUSE>), grid, block, lds, s, a);
+    hipLaunchKernelGGL((conv3x3_wino_kernel<POOL, FUSE>), grid, block, lds, s, a);
     return hipGetLastError();
 }
 
-// a.w must be the Winograd-packed weights [Cin/8][16][Cout][8] (pack_conv3x3_wino)
 hipError_t launch_conv3x3_wino(const ConvArgs& a, hipStream_t s) {
     if (a.Cin % WCC != 0 || a.Cout % 64 != 0) return hipErrorInvalidValue;
     if (a.img) {
         if (a.Cin != 64 || !a.w1 || !a.b1) return hipErrorInvalidValue;
-        return a.pool ? launch_wino_variant<true, true>(a, s) : launch_wino_variant<false, true>(a, s);
+        return a.pool ? launch_wino<true, true>(a, s) : launch_wino<false, true>(a, s);
     }
-    return a.pool ? launch_wino_variant<true, false>(a, s) : launch_wino_variant<false, false>(a, s);
+    return a.pool ? launch_wino<true, false>(a, s) : launch_wino<false, false>(a, s);
 }
 
 }  // namespace im
