@@ -94,8 +94,44 @@ static void runv(int blocks_per_cu, float* out) {
     }
 }
 
+// NC independent accumulator chains per wave (NC = 1: every MFMA waits for the previous one's result)
+template <int NC>
+__global__ __launch_bounds__(256) void kc(float* out, int iters, float seed) {
+    const int lane = threadIdx.x & 63;
+    f32x16 a[NC];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) a[i] = f32x16{};
+    float x = seed * lane, y = seed + lane;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 32 / NC; ++u)
+#pragma unroll
+            for (int i = 0; i < NC; ++i) a[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a[i], 0, 0, 0);
+    }
+    float s = 0;
+    for (int i = 0; i < NC; ++i)
+        for (int r = 0; r < 16; ++r) s += a[i][r];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+template <int NC>
+static void runc(int blocks_per_cu, float* out) {
+    const int iters = 2000, grid = 256 * blocks_per_cu;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int rep = 0; rep < 2; ++rep) {
+        hipEventRecord(e0);
+        for (int j = 0; j < 10; ++j) hipLaunchKernelGGL((kc<NC>), dim3(grid), dim3(256), 0, 0, out, iters, 1e-9f);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        const double fl = 10.0 * grid * 4 * iters * 32.0 * 4096;
+        if (rep == 1) printf("%d dependent chain(s) per wave, %d waves/SIMD: %7.1f TFLOP/s  (%.1f%%)\n", NC, blocks_per_cu, fl / ms / 1e9, fl / ms / 1e9 / 157.3 * 100);
+    }
+}
+
 int main() {
-    float* out; hipMalloc(&out, 256 * 4 * 256 * sizeof(float));
+    float* out; hipMalloc(&out, 256 * 8 * 256 * sizeof(float));
     // settle clocks
     for (int j = 0; j < 300; ++j) hipLaunchKernelGGL(k<0>, dim3(512), dim3(256), 0, 0, out, 4000, 1e-9f);
     hipDeviceSynchronize();
@@ -109,5 +145,6 @@ int main() {
         runv<0, 0>(w, out); runv<1, 0>(w, out); runv<2, 0>(w, out); runv<4, 0>(w, out); runv<8, 0>(w, out); runv<16, 0>(w, out); runv<32, 0>(w, out);
         runv<0, 1>(w, out); runv<0, 2>(w, out); runv<0, 4>(w, out); runv<0, 8>(w, out);
     }
+    for (int w = 1; w <= 4; w *= 2) { runc<1>(w, out); runc<2>(w, out); runc<4>(w, out); }
     return 0;
 }
