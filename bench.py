@@ -107,23 +107,36 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # untimed warm-up: at least W steps, and at least ~3 s of sustained load: a cold MI355X needs seconds, not
-    # milliseconds, to settle its clocks (measured: first process on a fresh box 62 pairs/s after 16 warm-up pairs,
-    # 73.5 after 200; later processes 74.4 either way)
-    t_w = time.perf_counter()
+    # untimed warm-up: at least W steps, then batches of 16 pairs until the batch time stops falling (two consecutive
+    # batches within 2 %) or 20 s have passed. A cold MI355X needs seconds of sustained load, not milliseconds, to
+    # settle its clocks: the first process on a fresh box measured 62-67 pairs/s after a 3 s warm-up and 83-85 in every
+    # later process, with identical per-kernel durations at the end of both.
     i = 0
-    while i < args.warmup or (time.perf_counter() - t_w < 3.0 and i < 2000):
+    while i < args.warmup:
         sm.match_pair(pool[i % len(pool)], epochs[i % len(epochs)], scratch, i % scratch.shape[0])
         i += 1
-        if i % 8 == 0:
-            sm.synchronize()
     sm.synchronize()
-    if world > 1:
-        all_gather_tables(scratch.cpu() if one_dev else scratch)
+    t_w = time.perf_counter()
+    prev, stable = None, 0
+    while time.perf_counter() - t_w < 20.0 and stable < 2:
+        t_b = time.perf_counter()
+        for _ in range(16):
+            sm.match_pair(pool[i % len(pool)], epochs[i % len(epochs)], scratch, i % scratch.shape[0])
+            i += 1
+        sm.synchronize()
+        cur = time.perf_counter() - t_b
+        stable = stable + 1 if prev is not None and abs(cur - prev) < 0.02 * prev else 0
+        prev = cur
+    warm_pairs = i
+    sm.synchronize()
+    # the gather / sort of the match tables is part of the timed region: run it once untimed as well, so that the lazy
+    # loading of torch's indexing and sort kernels (100+ ms in a fresh process) is not billed to the 50 timed steps
+    all_gather_tables(scratch.cpu() if one_dev else scratch)
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         sm.match_pair(pool[(args.warmup + i) % len(pool)], epochs[args.warmup + i], table, i)
+    t_enq = time.perf_counter() - t0            # host time to enqueue every step (graph launches are asynchronous)
     sm.synchronize()
     full = all_gather_tables(table.cpu() if one_dev else table)
     barrier()
@@ -147,6 +160,7 @@ def main():
                    "height": H, "width": W, "max_keypoints": KPTS, "pairs_per_step": 1, "hip_graph": not args.no_graph,
                    "pairs_in_flight": args.streams,
                    "mean_keypoints": n0, "mean_matches": nm},
+        "host_enqueue_ms_per_step": 1e3 * t_enq / args.steps, "untimed_pairs_before_timing": warm_pairs,
     }
 
     if rank == 0:
