@@ -30,14 +30,11 @@ struct LightGlueW {
     float* wr = nullptr;                    // posenc.Wr [32][2]
     // per layer (9): contiguous blocks so that a device-side layer index can select them
     float* qkv_w = nullptr; float* qkv_b = nullptr;      // [L][768][256] rows permuted to [q|k|v][head][d], [L][768]
-    float* out_w = nullptr; float* out_b = nullptr;      // [L][256][256]
-    float* sf0_w = nullptr; float* sf0_b = nullptr;      // self ffn.0 [L][512][512]
+    float* sf0_w = nullptr; float* sf0_b = nullptr;      // self ffn.0 [L][512][512] with out_proj folded into columns 256..511
     float* sln_g = nullptr; float* sln_b = nullptr;      // [L][512]
     float* sf3_w = nullptr; float* sf3_b = nullptr;      // [L][256][512]
-    float* cqk_w = nullptr; float* cqk_b = nullptr;      // cross to_qk [L][256][256]
-    float* cv_w = nullptr;  float* cv_b = nullptr;
-    float* co_w = nullptr;  float* co_b = nullptr;
-    float* cf0_w = nullptr; float* cf0_b = nullptr;
+    float* cqv_w = nullptr; float* cqv_b = nullptr;      // cross [to_qk ; to_v] [L][512][256]
+    float* cf0_w = nullptr; float* cf0_b = nullptr;      // cross ffn.0 with to_out folded in
     float* cln_g = nullptr; float* cln_b = nullptr;
     float* cf3_w = nullptr; float* cf3_b = nullptr;
     float* fp_w = nullptr;  float* fp_b = nullptr;       // log_assignment.final_proj [L][256][256], [L][256]

@@ -153,6 +153,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
                         a.C[(long)z * a.c_bstride + (long)row * a.ldc + col] = rv + val;
                     } else if constexpr (EPI == EPI_HEADS) {
                         a.q[(long)z * a.head_bstride + (long)(col >> 6) * a.head_stride + (long)row * 64 + (col & 63)] = a.alpha * val;
+                    } else if constexpr (EPI == EPI_HEADS_QV) {
+                        const int hd = col & 255;
+                        float* dst = (col >> 8) ? a.v : a.q;
+                        dst[(long)z * a.head_bstride + (long)(hd >> 6) * a.head_stride + (long)row * 64 + (hd & 63)] = (col >> 8) ? val : a.alpha * val;
                     }
                 }
             }
@@ -177,6 +181,7 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
         IM_GEMM_CASE(EPI_HEADS)
         IM_GEMM_CASE(EPI_QKV_ROPE)
         IM_GEMM_CASE(EPI_BIAS_RELU)
+        IM_GEMM_CASE(EPI_HEADS_QV)
         default: return hipErrorInvalidValue;
     }
 #undef IM_GEMM_CASE

@@ -15,6 +15,7 @@ enum GemmEpi {
     EPI_HEADS = 2,      // head-major store: q[z][col / 64][row][col % 64] = alpha * (acc + bias)
     EPI_QKV_ROPE = 3,   // N = 768 = [q | k | v] x [head][64]; rotary on q, k; head-major stores
     EPI_BIAS_RELU = 4,  // C = max(acc + bias, 0)
+    EPI_HEADS_QV = 5,   // N = 512 = [qk | v] x [head][64]: head-major stores to q (scaled by alpha) and v (unscaled)
 };
 
 struct GemmArgs {

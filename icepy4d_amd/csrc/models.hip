@@ -104,22 +104,59 @@ static int finalize_lightglue(im_ctx* ctx) {
         w.qkv_w = ctx->upload(pw);
         w.qkv_b = ctx->upload(pb);
     }
-    CAT_UP(w.out_w, "transformers.%d.self_attn.out_proj.weight", 256 * 256, L);
-    CAT_UP(w.out_b, "transformers.%d.self_attn.out_proj.bias", 256, L);
-    CAT_UP(w.sf0_w, "transformers.%d.self_attn.ffn.0.weight", 512 * 512, L);
-    CAT_UP(w.sf0_b, "transformers.%d.self_attn.ffn.0.bias", 512, L);
+    // out_proj / to_out are folded into the second half of ffn.0 (`lightglue.py:160-162, 212-216`: the message is used
+    // only as ffn input): ffn.0([x | Wo a + bo]) = W0a x + (W0b Wo) a + (W0b bo + b0). Products accumulated in double;
+    // one 256 -> 256 GEMM launch and the `message` round trip through HBM less per block.
+    auto fold = [&](const char* ow, const char* ob, const char* fw, const char* fb, float*& dw, float*& db) -> int {
+        std::vector<float> o_w, o_b, f_w, f_b;
+        if (cat(ow, 256 * 256, o_w, L) || cat(ob, 256, o_b, L) || cat(fw, 512 * 512, f_w, L) || cat(fb, 512, f_b, L)) return -20;
+        std::vector<double> row(256);
+        for (int l = 0; l < L; ++l) {
+            const float* Wo = &o_w[(size_t)l * 65536];
+            const float* bo = &o_b[(size_t)l * 256];
+            for (int n = 0; n < 512; ++n) {
+                float* w0 = &f_w[((size_t)l * 512 + n) * 512 + 256];
+                double bacc = f_b[(size_t)l * 512 + n];
+                for (int k = 0; k < 256; ++k) row[k] = 0.0;
+                for (int j = 0; j < 256; ++j) {
+                    const double wj = w0[j];
+                    const float* wor = Wo + (size_t)j * 256;
+                    for (int k = 0; k < 256; ++k) row[k] += wj * (double)wor[k];
+                    bacc += wj * (double)bo[j];
+                }
+                for (int k = 0; k < 256; ++k) w0[k] = (float)row[k];
+                f_b[(size_t)l * 512 + n] = (float)bacc;
+            }
+        }
+        dw = ctx->upload(f_w);
+        db = ctx->upload(f_b);
+        return (dw && db) ? 0 : -22;
+    };
+    if (int rc = fold("transformers.%d.self_attn.out_proj.weight", "transformers.%d.self_attn.out_proj.bias",
+                      "transformers.%d.self_attn.ffn.0.weight", "transformers.%d.self_attn.ffn.0.bias", w.sf0_w, w.sf0_b))
+        return ctx->fail(rc, "weights: self ffn.0 / out_proj");
     CAT_UP(w.sln_g, "transformers.%d.self_attn.ffn.1.weight", 512, L);
     CAT_UP(w.sln_b, "transformers.%d.self_attn.ffn.1.bias", 512, L);
     CAT_UP(w.sf3_w, "transformers.%d.self_attn.ffn.3.weight", 256 * 512, L);
     CAT_UP(w.sf3_b, "transformers.%d.self_attn.ffn.3.bias", 256, L);
-    CAT_UP(w.cqk_w, "transformers.%d.cross_attn.to_qk.weight", 256 * 256, L);
-    CAT_UP(w.cqk_b, "transformers.%d.cross_attn.to_qk.bias", 256, L);
-    CAT_UP(w.cv_w, "transformers.%d.cross_attn.to_v.weight", 256 * 256, L);
-    CAT_UP(w.cv_b, "transformers.%d.cross_attn.to_v.bias", 256, L);
-    CAT_UP(w.co_w, "transformers.%d.cross_attn.to_out.weight", 256 * 256, L);
-    CAT_UP(w.co_b, "transformers.%d.cross_attn.to_out.bias", 256, L);
-    CAT_UP(w.cf0_w, "transformers.%d.cross_attn.ffn.0.weight", 512 * 512, L);
-    CAT_UP(w.cf0_b, "transformers.%d.cross_attn.ffn.0.bias", 512, L);
+    {   // [to_qk ; to_v] as one 256 -> 512 projection
+        std::vector<float> qw, qb, vw, vb, pw((size_t)L * 512 * 256), pb((size_t)L * 512);
+        if (cat("transformers.%d.cross_attn.to_qk.weight", 256 * 256, qw, L) || cat("transformers.%d.cross_attn.to_qk.bias", 256, qb, L) ||
+            cat("transformers.%d.cross_attn.to_v.weight", 256 * 256, vw, L) || cat("transformers.%d.cross_attn.to_v.bias", 256, vb, L))
+            return -20;
+        for (int l = 0; l < L; ++l) {
+            memcpy(&pw[(size_t)l * 512 * 256], &qw[(size_t)l * 65536], 65536 * sizeof(float));
+            memcpy(&pw[(size_t)l * 512 * 256 + 65536], &vw[(size_t)l * 65536], 65536 * sizeof(float));
+            memcpy(&pb[(size_t)l * 512], &qb[(size_t)l * 256], 256 * sizeof(float));
+            memcpy(&pb[(size_t)l * 512 + 256], &vb[(size_t)l * 256], 256 * sizeof(float));
+        }
+        w.cqv_w = ctx->upload(pw);
+        w.cqv_b = ctx->upload(pb);
+        if (!w.cqv_w || !w.cqv_b) return ctx->fail(-22, "weights: upload failed");
+    }
+    if (int rc = fold("transformers.%d.cross_attn.to_out.weight", "transformers.%d.cross_attn.to_out.bias",
+                      "transformers.%d.cross_attn.ffn.0.weight", "transformers.%d.cross_attn.ffn.0.bias", w.cf0_w, w.cf0_b))
+        return ctx->fail(rc, "weights: cross ffn.0 / to_out");
     CAT_UP(w.cln_g, "transformers.%d.cross_attn.ffn.1.weight", 512, L);
     CAT_UP(w.cln_b, "transformers.%d.cross_attn.ffn.1.bias", 512, L);
     CAT_UP(w.cf3_w, "transformers.%d.cross_attn.ffn.3.weight", 256 * 512, L);
@@ -365,27 +402,17 @@ static int lg_block(im_ctx* ctx, hipStream_t s, int layer, bool cross, float* x,
         at.scale = 0.125f;  // SDPA default 1/sqrt(64) (`lightglue.py:120-123`)
     } else {
         GemmArgs g = base;
-        g.A = x; g.a_bstride = xb; g.lda = 256; g.W = W.cqk_w + (long)layer * 65536; g.ldw = 256;
-        g.bias = W.cqk_b + (long)layer * 256; g.N = 256; g.K = 256; g.epi = EPI_HEADS;
-        g.q = ws->q; g.head_bstride = (long)K * 256; g.head_stride = (long)K * 64;
-        g.alpha = (float)0.35355339059327373;  // scale**0.5 = 64**-0.25 (`lightglue.py:201`)
-        IM_LAUNCH(ctx, "lg_proj_gemm", s, launch_gemm(g, s));
-        g.W = W.cv_w + (long)layer * 65536; g.bias = W.cv_b + (long)layer * 256; g.q = ws->v; g.alpha = 1.f;
+        g.A = x; g.a_bstride = xb; g.lda = 256; g.W = W.cqv_w + (long)layer * 512 * 256; g.ldw = 256;
+        g.bias = W.cqv_b + (long)layer * 512; g.N = 512; g.K = 256; g.epi = EPI_HEADS_QV;
+        g.q = ws->q; g.v = ws->v; g.head_bstride = (long)K * 256; g.head_stride = (long)K * 64;
+        g.alpha = (float)0.35355339059327373;  // scale**0.5 = 64**-0.25 on to_qk (`lightglue.py:201`); to_v unscaled
         IM_LAUNCH(ctx, "lg_proj_gemm", s, launch_gemm(g, s));
         at.scale = 1.f;
     }
     IM_LAUNCH(ctx, cross ? "flash_attn_cross" : "flash_attn_self", s, launch_flash_attn(at, s));
-    {   // out_proj / to_out
+    {   // ffn.0 on cat([x, out_proj(att)]) with out_proj folded into the weights: the second source is the attention output
         GemmArgs g = base;
-        g.A = ws->att; g.a_bstride = xb; g.lda = 256;
-        g.W = (cross ? W.co_w : W.out_w) + (long)layer * 65536; g.ldw = 256;
-        g.bias = (cross ? W.co_b : W.out_b) + (long)layer * 256; g.N = 256; g.K = 256;
-        g.C = ws->msg; g.c_bstride = xb; g.ldc = 256; g.epi = EPI_BIAS;
-        IM_LAUNCH(ctx, "lg_proj_gemm", s, launch_gemm(g, s));
-    }
-    {   // ffn.0 on cat([x, msg])
-        GemmArgs g = base;
-        g.A = x; g.a_bstride = xb; g.lda = 256; g.A1 = ws->msg; g.a1_bstride = xb; g.lda1 = 256; g.ksplit = 256;
+        g.A = x; g.a_bstride = xb; g.lda = 256; g.A1 = ws->att; g.a1_bstride = xb; g.lda1 = 256; g.ksplit = 256;
         g.W = (cross ? W.cf0_w : W.sf0_w) + (long)layer * 512 * 512; g.ldw = 512;
         g.bias = (cross ? W.cf0_b : W.sf0_b) + (long)layer * 512; g.N = 512; g.K = 512;
         g.C = ws->h; g.c_bstride = (long)K * 512; g.ldc = 512; g.epi = EPI_BIAS;
