@@ -126,8 +126,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
                                                   FUSE1A ? 0u : (unsigned)a.H * a.W * a.Cin * 4u);
     const __amdgpu_buffer_rsrc_t ruw = wmake_rsrc(a.w, (unsigned)(a.Cin / WCC) * 16u * a.Cout * WCC * 4u);
     const unsigned pv = p_in ? (unsigned)(((unsigned)p_gy * a.W + p_gx) * a.Cin) * 4u : 0xFFFFF000u;
-    // U slots tid + 256 k, k < 8: float4 (pos * 64 + co) * 2 + quad of the slab block; pos = (tid >> 7) + 2 k
-    const unsigned uv = (unsigned)((((tid >> 7) * a.Cout + co0 + ((tid >> 1) & 63)) * WCC) + (tid & 1) * 4) * 4u;
+    // U image in LDS: [pos][channel quad][64 output channels] float4, so that the 16 lanes of a ds_read_b128 lane
+    // group read 16 consecutive slots (with the quad innermost the even / odd slots of one quad gave a 2-way bank
+    // conflict on every B-operand read). DMA slot tid + 256 k, k < 8: pos = (tid >> 7) + 2 k, quad = (tid >> 6) & 1,
+    // output channel tid & 63; the source block stays [pos][Cout][8].
+    const unsigned uv = (unsigned)((((tid >> 7) * a.Cout + co0 + (tid & 63)) * WCC) + ((tid >> 6) & 1) * 4) * 4u;
     const unsigned u_slab_bytes = 16u * a.Cout * WCC * 4u, u_k_bytes = 2u * a.Cout * WCC * 4u;
 
     auto fused_quad = [&](int ch) -> float4 {      // conv1a(img / 255) of this thread's pixel, channels ch .. ch + 3 (uniform)
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
     // lane (c, hh): tile c of the 4 x 8 tile grid, channel quad hh; B operand: output channel cb * 32 + c
     const int t_ty = c >> 3, t_tx = c & 7;
     const int a_slot = hh * S_QUAD + (2 * t_ty + ph) * S_ROW + t_tx;         // patch row 2 ty + ph, parity 0, quad hh
-    const int b_slot = ((ph * 8) * 64 + cb * 32 + c) * 2 + hh;               // position 8 ph, this lane's channel
+    const int b_slot = ((ph * 8) * 2 + hh) * 64 + cb * 32 + c;               // position 8 ph, quad hh, this lane's channel
 #define IM_SD(i, j) pa[a_slot + (i) * S_ROW + ((j) & 1) * S_PAR + ((j) >> 1)]
 #define IM_SMMA(slab)                                                                                   \
     {                                                                                                   \
