@@ -47,7 +47,6 @@ struct SuperGlueW {
     bool ready = false;
     float* kenc_w[5] = {nullptr}; float* kenc_b[5] = {nullptr};  // BN folded; layer 0 K padded 3 -> 32
     float* proj_w = nullptr; float* proj_b = nullptr;    // [18][3][256][256] head-major output rows, [18][3][256]
-    float* merge_w = nullptr; float* merge_b = nullptr;  // [18][256][256] head-major input columns
     float* mlp0_w = nullptr; float* mlp0_b = nullptr;    // [18][512][512] BN folded, second half of K head-major-agnostic
     float* mlp3_w = nullptr; float* mlp3_b = nullptr;    // [18][256][512]
     float* fp_w = nullptr; float* fp_b = nullptr;        // final_proj [256][256]

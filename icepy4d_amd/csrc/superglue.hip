@@ -260,13 +260,33 @@ int finalize_superglue(im_ctx* ctx) {
         if (!w0 || !b0 || !w3 || !b3) return -20;
         std::vector<float> ww(*w0), bb(*b0);
         if (fold_bn(ctx, p + ".mlp.1", 512, 512, ww, bb)) return -20;
+        // `merge` feeds only mlp.0 (`superglue.py:104-116`: mlp(cat([x, message]))): fold it into the message half of the
+        // (BatchNorm-folded) mlp.0 weights, mlp0([x | Wm a + bm]) = W0a x + (W0b Wm) a + (W0b bm + b0), accumulated in
+        // double. One 256 -> 256 GEMM launch and the message round trip less per layer.
+        {
+            const float* Wm = &mg_w[(size_t)l * 65536];     // head-permuted merge weights [256 out][256 in (h * 64 + d)]
+            const float* bm = &mg_b[(size_t)l * 256];
+            std::vector<double> row(256);
+            for (int n = 0; n < 512; ++n) {
+                float* w0r = &ww[(size_t)n * 512 + 256];
+                double bacc = bb[n];
+                for (int k = 0; k < 256; ++k) row[k] = 0.0;
+                for (int j = 0; j < 256; ++j) {
+                    const double wj = w0r[j];
+                    const float* wmr = Wm + (size_t)j * 256;
+                    for (int k = 0; k < 256; ++k) row[k] += wj * (double)wmr[k];
+                    bacc += wj * (double)bm[j];
+                }
+                for (int k = 0; k < 256; ++k) w0r[k] = (float)row[k];
+                bb[n] = (float)bacc;
+            }
+        }
         memcpy(&m0_w[(size_t)l * 512 * 512], ww.data(), ww.size() * sizeof(float));
         memcpy(&m0_b[(size_t)l * 512], bb.data(), 512 * sizeof(float));
         memcpy(&m3_w[(size_t)l * 256 * 512], w3->data(), w3->size() * sizeof(float));
         memcpy(&m3_b[(size_t)l * 256], b3->data(), 256 * sizeof(float));
     }
     W.proj_w = ctx->upload(qkv_w); W.proj_b = ctx->upload(qkv_b);
-    W.merge_w = ctx->upload(mg_w); W.merge_b = ctx->upload(mg_b);
     W.mlp0_w = ctx->upload(m0_w); W.mlp0_b = ctx->upload(m0_b);
     W.mlp3_w = ctx->upload(m3_w); W.mlp3_b = ctx->upload(m3_b);
     const auto* fw = sg_find(ctx, "final_proj.weight", 65536);
@@ -275,7 +295,7 @@ int finalize_superglue(im_ctx* ctx) {
     if (!fw || !fb || !bs) return -20;
     W.fp_w = ctx->upload(*fw); W.fp_b = ctx->upload(*fb);
     W.bin_score = (*bs)[0];
-    if (!W.proj_w || !W.merge_w || !W.mlp0_w || !W.mlp3_w || !W.fp_w) return ctx->fail(-22, "weights: upload failed");
+    if (!W.proj_w || !W.mlp0_w || !W.mlp3_w || !W.fp_w) return ctx->fail(-22, "weights: upload failed");
     W.ready = true;
     return 0;
 }
@@ -337,13 +357,7 @@ int im_superglue_forward(im_ctx* ctx, const float* d_kpts, const float* d_scores
         }
         {
             GemmArgs g = base;
-            g.A = ws->att; g.a_bstride = xb; g.lda = 256; g.W = W.merge_w + (long)l * 65536; g.ldw = 256;
-            g.bias = W.merge_b + (long)l * 256; g.N = 256; g.K = 256; g.C = ws->msg; g.c_bstride = xb; g.ldc = 256; g.epi = EPI_BIAS;
-            IM_LAUNCH(ctx, "sg_merge_gemm", s, launch_gemm(g, s));
-        }
-        {
-            GemmArgs g = base;
-            g.A = x; g.a_bstride = xb; g.lda = 256; g.A1 = ws->msg; g.a1_bstride = xb; g.lda1 = 256; g.ksplit = 256;
+            g.A = x; g.a_bstride = xb; g.lda = 256; g.A1 = ws->att; g.a1_bstride = xb; g.lda1 = 256; g.ksplit = 256;   // merge folded in
             g.W = W.mlp0_w + (long)l * 512 * 512; g.ldw = 512; g.bias = W.mlp0_b + (long)l * 512; g.N = 512; g.K = 512;
             g.C = ws->h; g.c_bstride = (long)K * 512; g.ldc = 512; g.epi = EPI_BIAS_RELU;
             IM_LAUNCH(ctx, "sg_mlp0_gemm", s, launch_gemm(g, s));
