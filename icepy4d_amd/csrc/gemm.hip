@@ -18,6 +18,18 @@
 
 namespace im {
 
+typedef unsigned int gu32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 gbuf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+    const gu32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t gmake_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long b = reinterpret_cast<unsigned long long>(base);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    void* p = reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo);
+    return __builtin_amdgcn_make_buffer_rsrc(p, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+
 template <int BM, int BN, int BK, int EPI>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
     if (a.active && *a.active == 0) return;
@@ -59,18 +71,31 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // Register staging of the next slab in named registers (arrays indexed inside helper lambdas / loops ended up
-    // in scratch). Rows beyond the live counts are clamped to the last valid row; their products are never stored.
+    // Register staging of the next slab in named registers (arrays indexed inside helper lambdas / loops ended up in
+    // scratch). Buffer loads: descriptors sized to the live rows (rows beyond them read as zero; their products are never
+    // stored), lane offsets fixed for the whole kernel, the slab is a scalar offset - no address arithmetic on the VALU,
+    // which on gfx950 would cost matrix-pipe time (tools/mfma_peak.hip).
     static_assert((A_IT == 1 || A_IT == 2 || A_IT == 4) && (B_IT == 1 || B_IT == 2 || B_IT == 4), "staging registers");
+    const __amdgpu_buffer_rsrc_t rA0 = gmake_rsrc(A0, (unsigned)M * a.lda * 4u);
+    const __amdgpu_buffer_rsrc_t rA1 = gmake_rsrc(A1 ? A1 : A0, A1 ? (unsigned)M * a.lda1 * 4u : 0u);
+    const __amdgpu_buffer_rsrc_t rW = gmake_rsrc(Wp, (unsigned)Nlive * a.ldw * 4u);
+    unsigned va0[A_IT], va1[A_IT], vb[B_IT];
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        const unsigned row = m0 + (tid + i * 256) / F4, col = ((tid + i * 256) % F4) * 4;
+        va0[i] = (row * a.lda + col) * 4u;
+        va1[i] = (row * a.lda1 + col) * 4u;
+    }
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) vb[i] = ((unsigned)(n0 + (tid + i * 256) / F4) * a.ldw + ((tid + i * 256) % F4) * 4) * 4u;
     float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
     ra1 = ra2 = ra3 = rb1 = rb2 = rb3 = make_float4(0.f, 0.f, 0.f, 0.f);
-#define IM_LD_A(i) *reinterpret_cast<const float4*>(src + (long)min(m0 + (tid + (i) * 256) / F4, M - 1) * ld + kk + ((tid + (i) * 256) % F4) * 4)
-#define IM_LD_B(i, k0_) *reinterpret_cast<const float4*>(Wp + (long)min(n0 + (tid + (i) * 256) / F4, Nlive - 1) * a.ldw + (k0_) + ((tid + (i) * 256) % F4) * 4)
+#define IM_LD_A(i) gbuf_load4(second_ ? rA1 : rA0, second_ ? va1[i] : va0[i], so_)
+#define IM_LD_B(i, k0_) gbuf_load4(rW, vb[i], (k0_) * 4u)
 #define IM_LOAD_SLAB(k0_)                                                                  \
     {                                                                                      \
-        const float* src = A0;                                                             \
-        int ld = a.lda, kk = (k0_);                                                        \
-        if (A1 && (k0_) >= a.ksplit) { src = A1; ld = a.lda1; kk = (k0_) - a.ksplit; }     \
+        const bool second_ = A1 && (k0_) >= a.ksplit;                                      \
+        const unsigned so_ = (second_ ? (k0_) - a.ksplit : (k0_)) * 4u;                    \
         ra0 = IM_LD_A(0);                                                                  \
         if constexpr (A_IT > 1) ra1 = IM_LD_A(1);                                          \
         if constexpr (A_IT > 2) { ra2 = IM_LD_A(2); ra3 = IM_LD_A(3); }                    \
@@ -116,48 +141,73 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
 #undef IM_LD_B
 #undef IM_ST
 
-    // ---- epilogue: lane holds column n = .. + c, rows acc_row(r, hh)
+    // ---- epilogue: lane holds column n = .. + c, rows row0 + 4 hh + (r & 3) + 8 (r >> 2). Buffer stores: the descriptor
+    // covers the live rows only, so rows past them are dropped by the range check; a dead column gets an out-of-range
+    // lane offset; the row of register r is a scalar offset. No per-element branch, no 64-bit address arithmetic.
+    constexpr unsigned OOB = 0xFFFFF000u;
 #pragma unroll
     for (int i = 0; i < MB; ++i)
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-            const int col = n0 + wn0 + j * 32 + c;
+            const int colbase = n0 + wn0 + j * 32;            // wave-uniform
+            const int col = colbase + c;
             const bool col_ok = col < Nlive;
             const float bv = (bias && col_ok) ? bias[col] : 0.f;
+            const unsigned rowl = m0 + wm0 + i * 32 + 4 * hh; // row of register 0 of this lane
+            if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_RELU || EPI == EPI_BIAS_RESID) {
+                const __amdgpu_buffer_rsrc_t rC = gmake_rsrc(a.C + (long)z * a.c_bstride, (unsigned)M * a.ldc * 4u);
+                const unsigned vo = col_ok ? (rowl * a.ldc + col) * 4u : OOB;
+                const unsigned rstep = (unsigned)a.ldc * 4u;
+                float rv[16];
+                if constexpr (EPI == EPI_BIAS_RESID) {
+                    const __amdgpu_buffer_rsrc_t rR = gmake_rsrc(a.R + (long)z * a.r_bstride, (unsigned)M * a.ldr * 4u);
+                    const unsigned vr = col_ok ? (rowl * a.ldr + col) * 4u : OOB;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm0 + i * 32 + acc_row(r, hh);
-                float val = acc[i][j][r] + bv;
-                if constexpr (EPI == EPI_QKV_ROPE) {
+                    for (int r = 0; r < 16; ++r)
+                        rv[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rR, vr, ((r & 3) + 8 * (r >> 2)) * (unsigned)a.ldr * 4u, 0));
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float val = acc[i][j][r] + bv;
+                    if constexpr (EPI == EPI_BIAS) val = a.alpha * val;
+                    else if constexpr (EPI == EPI_BIAS_RELU) val = fmaxf(val, 0.f);
+                    else val = rv[r] + val;
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), rC, vo, ((r & 3) + 8 * (r >> 2)) * rstep, 0);
+                }
+            } else {
+                // head-major stores [head][row][64]; which / head are wave-uniform (a tile spans 32 of a head's 64 columns)
+                int which = 0, hd = colbase;
+                if constexpr (EPI == EPI_QKV_ROPE || EPI == EPI_HEADS_QV) { which = colbase >> 8; hd = colbase & 255; }
+                float* dst = a.q;
+                if constexpr (EPI == EPI_QKV_ROPE) dst = which == 0 ? a.q : (which == 1 ? a.k : a.v);
+                if constexpr (EPI == EPI_HEADS_QV) dst = which ? a.v : a.q;
+                const __amdgpu_buffer_rsrc_t rD = gmake_rsrc(dst + (long)z * a.head_bstride + (long)(hd >> 6) * a.head_stride, (unsigned)M * 256u);
+                const int d = (hd & 63) + c;
+                const unsigned vo = col_ok ? (rowl * 64 + d) * 4u : OOB;
+                float scale = a.alpha;
+                if constexpr (EPI == EPI_QKV_ROPE) scale = 1.f;
+                if constexpr (EPI == EPI_HEADS_QV) scale = which ? 1.f : a.alpha;
+                const bool rope = EPI == EPI_QKV_ROPE && which < 2 && a.cs;
+                if (rope) {
                     // rotary (`lightglue/lightglue.py:49-57`): pairs (2i, 2i+1) share a frequency;
                     // out = t * cos + rotate_half(t) * sin, rotate_half: (x0, x1) -> (-x1, x0)
-                    float partner = __shfl_xor(val, 1);
-                    if (row < M && col_ok) {
-                        const int which = col >> 8, hd = col & 255, head = hd >> 6, d = hd & 63;
-                        float outv = val;
-                        if (which < 2 && a.cs) {
-                            const long e = (long)z * a.enc_bstride + (long)row * 32 + (d >> 1);
-                            const float cs = a.cs[e], sn = a.sn[e];
-                            outv = (d & 1) ? (val * cs) + (partner * sn) : (val * cs) + ((-partner) * sn);
-                        }
-                        float* dst = which == 0 ? a.q : (which == 1 ? a.k : a.v);
-                        dst[(long)z * a.head_bstride + (long)head * a.head_stride + (long)row * 64 + d] = outv;
+                    const __amdgpu_buffer_rsrc_t rCs = gmake_rsrc(a.cs + (long)z * a.enc_bstride, (unsigned)M * 128u);
+                    const __amdgpu_buffer_rsrc_t rSn = gmake_rsrc(a.sn + (long)z * a.enc_bstride, (unsigned)M * 128u);
+                    const unsigned ve = (rowl * 32 + (d >> 1)) * 4u;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const unsigned so = ((r & 3) + 8 * (r >> 2)) * 128u;
+                        const float cs = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rCs, ve, so, 0));
+                        const float sn = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rSn, ve, so, 0));
+                        const float val = acc[i][j][r] + bv;
+                        const float partner = __shfl_xor(val, 1);
+                        const float outv = (d & 1) ? (val * cs) + (partner * sn) : (val * cs) + ((-partner) * sn);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(outv), rD, vo, ((r & 3) + 8 * (r >> 2)) * 256u, 0);
                     }
-                } else if (row < M && col_ok) {
-                    if constexpr (EPI == EPI_BIAS) {
-                        a.C[(long)z * a.c_bstride + (long)row * a.ldc + col] = a.alpha * val;
-                    } else if constexpr (EPI == EPI_BIAS_RELU) {
-                        a.C[(long)z * a.c_bstride + (long)row * a.ldc + col] = fmaxf(val, 0.f);
-                    } else if constexpr (EPI == EPI_BIAS_RESID) {
-                        const float rv = a.R[(long)z * a.r_bstride + (long)row * a.ldr + col];
-                        a.C[(long)z * a.c_bstride + (long)row * a.ldc + col] = rv + val;
-                    } else if constexpr (EPI == EPI_HEADS) {
-                        a.q[(long)z * a.head_bstride + (long)(col >> 6) * a.head_stride + (long)row * 64 + (col & 63)] = a.alpha * val;
-                    } else if constexpr (EPI == EPI_HEADS_QV) {
-                        const int hd = col & 255;
-                        float* dst = (col >> 8) ? a.v : a.q;
-                        dst[(long)z * a.head_bstride + (long)(hd >> 6) * a.head_stride + (long)row * 64 + (hd & 63)] = (col >> 8) ? val : a.alpha * val;
-                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(scale * (acc[i][j][r] + bv)), rD, vo, ((r & 3) + 8 * (r >> 2)) * 256u, 0);
                 }
             }
         }
