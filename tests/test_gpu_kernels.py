@@ -115,3 +115,62 @@ def test_flash_attn(ctx, n0, n1, cross):
         err = (out[z, :ns[z]].double() - ref).abs().max().item()
         assert err < 2e-5, (z, err)
         assert torch.isnan(out[z, ns[z]:]).all()  # rows beyond the live count are untouched
+
+
+@pytest.mark.parametrize("n0,n1", [(1, 63), (64, 65), (127, 129), (191, 193), (130, 1), (257, 256)])
+def test_flash_attn_key_group_edges(ctx, n0, n1):
+    """Key counts around the 64-key tile / 128-key step boundaries of the two-key-group kernel, self and cross; the
+    K / V rows beyond the live counts hold NaN (the kernel must not read them: buffer range check) and the output rows
+    beyond the live counts must stay untouched."""
+    from icepy4d_amd._lib import ptr, stream_ptr
+    nmax, heads = 320, 4
+    g = torch.Generator().manual_seed(1000 * n0 + n1)
+    q = torch.randn(2, heads, nmax, 64, generator=g)
+    k = torch.randn(2, heads, nmax, 64, generator=g)
+    v = torch.randn(2, heads, nmax, 64, generator=g)
+    ns = [n0, n1]
+    kp, vp = k.clone(), v.clone()
+    for z in range(2):
+        kp[z, :, ns[z]:] = float("nan")
+        vp[z, :, ns[z]:] = float("nan")
+    dn = torch.tensor(ns, dtype=torch.int32, device="cuda")
+    dq, dk, dv = dev(q), dev(kp), dev(vp)
+    for cross in (0, 1):
+        dout = torch.full((2, nmax, heads * 64), float("nan"), device="cuda")
+        ctx.call("im_flash_attn", ptr(dq), ptr(dk), ptr(dv), ptr(dout), ptr(dn), nmax, 2, heads, cross, 0.125, stream_ptr())
+        torch.cuda.synchronize()
+        out = dout.cpu()
+        for z in range(2):
+            y = z ^ 1 if cross else z
+            qq, kk, vv = q[z, :, :ns[z]].double(), k[y, :, :ns[y]].double(), v[y, :, :ns[y]].double()
+            ref = (torch.softmax(qq @ kk.transpose(-1, -2) * 0.125, -1) @ vv).transpose(0, 1).reshape(ns[z], heads * 64)
+            err = (out[z, :ns[z]].double() - ref).abs().max().item()
+            assert err < 2e-5, (cross, z, err)
+            assert torch.isnan(out[z, ns[z]:]).all()
+
+
+def test_flash_attn_large_dynamic_range(ctx):
+    """Scores spanning hundreds of units with the row maxima arriving late: exercises the lazily raised reference maximum
+    (the rescale path must fire, P must never overflow) against an fp64 softmax."""
+    from icepy4d_amd._lib import ptr, stream_ptr
+    n, heads = 1024, 4
+    g = torch.Generator().manual_seed(77)
+    q = torch.randn(2, heads, n, 64, generator=g) * 4.0
+    k = torch.randn(2, heads, n, 64, generator=g) * 4.0
+    v = torch.randn(2, heads, n, 64, generator=g)
+    k[:, :, 900:] *= 3.0          # the largest scores sit in the last tiles
+    dn = torch.tensor([n, n], dtype=torch.int32, device="cuda")
+    dq, dk, dv = dev(q), dev(k), dev(v)
+    dout = torch.empty(2, n, heads * 64, device="cuda")
+    ctx.call("im_flash_attn", ptr(dq), ptr(dk), ptr(dv), ptr(dout), ptr(dn), n, 2, heads, 0, 1.0, stream_ptr())
+    torch.cuda.synchronize()
+    out = dout.cpu()
+    assert torch.isfinite(out).all()
+    for z in range(2):
+        ref = (torch.softmax(q[z].double() @ k[z].double().transpose(-1, -2), -1) @ v[z].double()).transpose(0, 1).reshape(n, heads * 64)
+        # scores of magnitude ~600 carry ~1e-4 of fp32 rounding each, which the softmax turns into relative error of P:
+        # the yardstick is what plain fp32 arithmetic (torch CPU) loses on the same inputs
+        ref32 = (torch.softmax(q[z] @ k[z].transpose(-1, -2), -1) @ v[z]).transpose(0, 1).reshape(n, heads * 64)
+        err32 = (ref32.double() - ref).abs().max().item()
+        err = (out[z].double() - ref).abs().max().item()
+        assert err < max(4 * err32, 1e-4), (z, err, err32)
