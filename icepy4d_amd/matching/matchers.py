@@ -205,6 +205,8 @@ class ImageMatcherBase:
         # tile, so each distinct tile is extracted once on the device and its features are reused by all its pairs
         # (bit-identical results, tested against the per-pair path).
         cache = self._extract_tiles(image0, image1, t0_lims, t1_lims, tile_pairs, **config)
+        if cache is not None and not self._opt.get("host_tile_merge", False):
+            return self._match_tiles_device(cache, tile_pairs, t0_lims, t1_lims, t0_origin, t1_origin, **config)
         for tidx0, tidx1 in tile_pairs:
             logger.info(f" - Matching tile pair ({tidx0}, {tidx1})")
             lim0, lim1 = t0_lims[tidx0], t1_lims[tidx1]
@@ -366,6 +368,61 @@ class ImageMatcherBase:
     def _match_cached(self, c0: dict, c1: dict, **config):
         raise NotImplementedError
 
+    def _enqueue_cached(self, c0: dict, c1: dict, **config) -> None:
+        """Enqueue the matcher on one cached tile pair (no synchronisation); results land in the engine's buffers."""
+        raise NotImplementedError
+
+    def _match_tiles_device(self, cache, tile_pairs, t0_lims, t1_lims, t0_origin, t1_origin, **config):
+        """Row f-1 of the scope table, second half: the whole tile loop of `matchers.py:367-469` without a host round
+        trip per tile pair. Every pair is enqueued back to back (its [K] match vector is kept on the device); then ONE
+        selection over all pairs gathers the matched keypoints from the per-tile feature banks, shifts them by the tile
+        and image origins (same two fp32 additions, same order as the host loop), removes duplicate image-0 points the
+        way `np.unique(axis=0)` does (lexicographic order, first occurrence kept: q6) and only the surviving rows -
+        keypoints, 256-float descriptors, scores - cross PCIe. Output identical to the host merge (tested)."""
+        eng = self.engine
+        dev, K = eng.device, eng.max_kpts
+        keys = sorted({(0, a) for a, _ in tile_pairs} | {(1, b) for _, b in tile_pairs})
+        slot = {k: i for i, k in enumerate(keys)}
+        KP = torch.stack([cache[k]["kpts"] for k in keys])          # [T, K, 2]
+        SC = torch.stack([cache[k]["scores"] for k in keys])        # [T, K]
+        DE = torch.stack([cache[k]["desc"] for k in keys])          # [T, K, 256]
+        NN = torch.cat([cache[k]["n"] for k in keys]).long()        # [T]
+        P = len(tile_pairs)
+        M = torch.empty(P, K, dtype=torch.int32, device=dev)
+        for p, (tidx0, tidx1) in enumerate(tile_pairs):
+            logger.info(f" - Matching tile pair ({tidx0}, {tidx1})")
+            self._enqueue_cached(cache[(0, tidx0)], cache[(1, tidx1)], **config)
+            M[p].copy_(eng.matches[0])
+        s0 = torch.tensor([slot[(0, a)] for a, _ in tile_pairs], device=dev)
+        s1 = torch.tensor([slot[(1, b)] for _, b in tile_pairs], device=dev)
+        off0 = torch.tensor([[float(t0_lims[a][0]), float(t0_lims[a][1])] for a, _ in tile_pairs], dtype=torch.float32, device=dev)
+        off1 = torch.tensor([[float(t1_lims[b][0]), float(t1_lims[b][1])] for _, b in tile_pairs], dtype=torch.float32, device=dev)
+        org0 = torch.tensor([float(t0_origin[0]), float(t0_origin[1])], dtype=torch.float32, device=dev)
+        org1 = torch.tensor([float(t1_origin[0]), float(t1_origin[1])], dtype=torch.float32, device=dev)
+        valid = (M > -1) & (torch.arange(K, device=dev)[None, :] < NN[s0][:, None])
+        p_idx, i_idx = torch.nonzero(valid, as_tuple=True)          # pair-major, keypoint order inside a pair: the host loop's order
+        j_idx = M[p_idx, i_idx].long()
+        t0i, t1i = s0[p_idx], s1[p_idx]
+        kp0 = (KP[t0i, i_idx] + off0[p_idx]) + org0
+        kp1 = (KP[t1i, j_idx] + off1[p_idx]) + org1
+        S = kp0.shape[0]
+        if S:
+            mk0, inv = torch.unique(kp0, dim=0, return_inverse=True)
+            first = torch.full((mk0.shape[0],), S, dtype=torch.long, device=dev).scatter_reduce_(
+                0, inv, torch.arange(S, device=dev), reduce="amin")
+        else:
+            mk0, first = kp0, torch.zeros(0, dtype=torch.long, device=dev)
+        features0 = FeaturesBase(keypoints=mk0.cpu().numpy(),
+                                 descriptors=np.ascontiguousarray(DE[t0i[first], i_idx[first]].cpu().numpy().T),
+                                 scores=SC[t0i[first], i_idx[first]].cpu().numpy())
+        features1 = FeaturesBase(keypoints=kp1[first].cpu().numpy(),
+                                 descriptors=np.ascontiguousarray(DE[t1i[first], j_idx[first]].cpu().numpy().T),
+                                 scores=SC[t1i[first], j_idx[first]].cpu().numpy())
+        matches0 = np.arange(features0.keypoints.shape[0])
+        mconf = features0.scores[matches0 > -1]  # q5: keypoint scores, not match confidences
+        logger.info("Matching by tile completed.")
+        return features0, features1, matches0, mconf
+
     def _load_cached_pair(self, c0: dict, c1: dict) -> None:
         eng = self.engine
         for slot, c in enumerate((c0, c1)):
@@ -421,10 +478,13 @@ class SuperGlueMatcher(ImageMatcherBase):
         sp = self._cfg["superpoint"]
         return sp["nms_radius"], sp["keypoint_threshold"], 4, self._sp_cap(), 1
 
-    def _match_cached(self, c0: dict, c1: dict, **config):
+    def _enqueue_cached(self, c0: dict, c1: dict, **config) -> None:
         sg = self._cfg["superglue"]
         self._load_cached_pair(c0, c1)
         self.engine.superglue(c0["shape"], c1["shape"], sg["sinkhorn_iterations"], sg["match_threshold"])
+
+    def _match_cached(self, c0: dict, c1: dict, **config):
+        self._enqueue_cached(c0, c1, **config)
         torch.cuda.synchronize()
         f0, f1, out = self._features_from_engine()
         matches0 = out["matches0"]
@@ -475,10 +535,13 @@ class LightGlueMatcher(ImageMatcherBase):
             return None
         return 4, 0.0005, 4, int(config.get("max_keypoints", 10240)), 0
 
-    def _match_cached(self, c0: dict, c1: dict, **config):
+    def _enqueue_cached(self, c0: dict, c1: dict, **config) -> None:
         self._load_cached_pair(c0, c1)
         (h0, w0), (h1, w1) = c0["shape"], c1["shape"]
         self.engine.lightglue((w0, h0), (w1, h1), **self._lg_conf)
+
+    def _match_cached(self, c0: dict, c1: dict, **config):
+        self._enqueue_cached(c0, c1, **config)
         torch.cuda.synchronize()
         f0, f1, out = self._features_from_engine()
         matches0 = out["matches0"]

@@ -413,9 +413,33 @@ def test_tile_feature_cache_is_bit_identical():
     assert len(a[0]) > 100
     for x, y in zip(a, b):
         assert np.array_equal(x, y)
+    # the cached features merged on the host (per-pair round trips) give the same result as the device-side merge
+    m3 = LightGlueMatcher({"state_dicts": sds, "host_tile_merge": True})
+    m3.match(g["image0"], g["image1"], quality=Quality.HIGH, tile_selection=TileSelection.EXHAUSTIVE, **cfg)
+    for x, y in zip(a, (m3.mkpts0, m3.mkpts1, m3.descriptors0, m3.scores1)):
+        assert np.array_equal(x, y)
     # preselection mode runs end to end (pyramid + preselection match + tile matching)
     m.match(g["image0"], g["image1"], quality=Quality.HIGH, tile_selection=TileSelection.PRESELECTION, min_matches_per_tile=3, **cfg)
     assert len(m.mkpts0) > 50 and len(m.mkpts0) == len(m.mkpts1)
+
+
+def test_tile_merge_on_device_superglue():
+    """Device-side tile merge (one selection + unique over all tile pairs) against the host loop, SuperGlue semantics."""
+    from icepy4d_amd.matching import GeometricVerification, Quality, SuperGlueMatcher, TileSelection
+    g = load_golden("g4_wrappers")
+    sds = {"superpoint": SP_SD, "superglue": synthetic.superglue_state_dict(0, "passthrough")}
+    opt = {"state_dicts": sds, "weights": "outdoor", "keypoint_threshold": 0.001, "max_keypoints": 256, "match_threshold": 0.05,
+           "force_cpu": False}
+    cfg = dict(geometric_verification=GeometricVerification.NONE, grid=[2, 2], overlap=20)
+    out = []
+    for host in (False, True):
+        m = SuperGlueMatcher({**opt, "host_tile_merge": host})
+        m.match(g["image0"], g["image1"], quality=Quality.HIGH, tile_selection=TileSelection.GRID, **cfg)
+        out.append((m.mkpts0.copy(), m.mkpts1.copy(), m.descriptors0.copy(), m.descriptors1.copy(), m.scores0.copy(), m.scores1.copy(),
+                    m.mconf.copy()))
+    assert len(out[0][0]) > 0
+    for x, y in zip(*out):
+        assert np.array_equal(x, y)
 
 
 # ------------------------------------------------------------------------------------------- floating-point stages
