@@ -68,13 +68,16 @@ class Engine:
 
     # ------------------------------------------------------------------ forwards (enqueue only)
     def superpoint(self, gray_u8: torch.Tensor, nms_radius: int = 4, threshold: float = 0.0005, border: int = 4,
-                   max_kpts: Optional[int] = None, flavour: int = 0) -> None:
-        """gray_u8: device uint8 [B, H, W]. Fills self.kpts / scores / desc / n."""
+                   max_kpts: Optional[int] = None, flavour: int = 0, slot: int = 0) -> None:
+        """gray_u8: device uint8 [B, H, W]. Fills self.kpts / scores / desc / n for images slot .. slot + B - 1
+        (two images of different size are two calls with slot 0 and 1)."""
         assert gray_u8.dtype == torch.uint8 and gray_u8.is_cuda and gray_u8.dim() == 3 and gray_u8.is_contiguous()
         B, H, W = gray_u8.shape
+        assert 0 <= slot and slot + B <= self.max_images
         k = -1 if max_kpts is None else int(max_kpts)
         self.ctx.call("im_superpoint_forward", ptr(gray_u8), B, H, W, int(nms_radius), float(threshold), int(border), k,
-                      int(flavour), ptr(self.kpts), ptr(self.scores), ptr(self.desc), ptr(self.n), _lib.stream_ptr())
+                      int(flavour), ptr(self.kpts[slot:]), ptr(self.scores[slot:]), ptr(self.desc[slot:]), ptr(self.n[slot:]),
+                      _lib.stream_ptr())
 
     def lightglue(self, size0: Tuple[float, float], size1: Tuple[float, float], depth_confidence: float = 0.95,
                   width_confidence: float = 0.99, filter_threshold: float = 0.1, n_layers: int = 9,

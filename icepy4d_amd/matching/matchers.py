@@ -498,12 +498,8 @@ class SuperGlueMatcher(ImageMatcherBase):
         unlimited = sp["max_keypoints"] < 0
         cap = int(self._opt.get("max_keypoints_cap", 16384)) if unlimited else int(sp["max_keypoints"])
         eng.reserve(max(g0.shape[0], g1.shape[0]), max(g0.shape[1], g1.shape[1]), 2, max(cap, 1))
-        ups = self._upload_pair(g0, g1)
-        if len(ups) == 1:
-            eng.superpoint(ups[0], sp["nms_radius"], sp["keypoint_threshold"], 4, cap, flavour=1)
-        else:
-            raise NotImplementedError("image0 and image1 of different size are matched tile by tile in icepy4d; "
-                                      "both images of a pair must have the same shape")
+        for slot, up in enumerate(self._upload_pair(g0, g1)):   # one batched launch, or one per image if the sizes differ
+            eng.superpoint(up, sp["nms_radius"], sp["keypoint_threshold"], 4, cap, flavour=1, slot=slot)
         eng.superglue(g0.shape, g1.shape, sg["sinkhorn_iterations"], sg["match_threshold"])
         torch.cuda.synchronize()
         k0, d0, s0 = eng.features_to_host(0)
@@ -555,12 +551,10 @@ class LightGlueMatcher(ImageMatcherBase):
         if config.get("resize", None) is not None:
             raise NotImplementedError("resize is not supported: icepy4d always calls extract(resize=None)")
         g0, g1 = _to_gray_u8(image0, "lightglue"), _to_gray_u8(image1, "lightglue")
-        if g0.shape != g1.shape:
-            raise NotImplementedError("both images of a pair must have the same shape")
         eng = self.engine
-        eng.reserve(g0.shape[0], g0.shape[1], 2, int(max_keypoints))
-        pair = self._upload_pair(g0, g1)[0]
-        eng.superpoint(pair, 4, 0.0005, 4, int(max_keypoints), flavour=0)
+        eng.reserve(max(g0.shape[0], g1.shape[0]), max(g0.shape[1], g1.shape[1]), 2, int(max_keypoints))
+        for slot, up in enumerate(self._upload_pair(g0, g1)):   # one batched launch, or one per image if the sizes differ
+            eng.superpoint(up, 4, 0.0005, 4, int(max_keypoints), flavour=0, slot=slot)
         eng.lightglue((g0.shape[1], g0.shape[0]), (g1.shape[1], g1.shape[0]), **self._lg_conf)
         torch.cuda.synchronize()
         k0, d0, s0 = eng.features_to_host(0)

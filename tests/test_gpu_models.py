@@ -340,6 +340,24 @@ def test_sequence_graph_equals_direct_and_oracle():
     e.close()
 
 
+def test_matcher_images_of_different_size():
+    """`_match_images` with image0 / image1 of different shapes (the reference extracts them independently,
+    `lightglue/superpoint.py:224-227`): two SuperPoint launches, one LightGlue call; keypoints identical to the oracle,
+    match vector >= 97 % identical."""
+    from icepy4d_amd.matching import LightGlueMatcher
+    from oracle import ref_cpu as o
+    lg_sd = synthetic.lightglue_state_dict(0, "passthrough")
+    a, b = synthetic.translated_pair(5, 160, 232, 8, 8)
+    b = np.ascontiguousarray(b[:136, :200])
+    m = LightGlueMatcher({"state_dicts": {"superpoint": SP_SD, "lightglue": lg_sd}})
+    f0, f1, matches0, mconf = m._match_images(a, b, max_keypoints=512)
+    F0, F1, m0, ref_conf, _ = o.match_images_lightglue(a, b, SP_SD, lg_sd, max_keypoints=512)
+    assert np.array_equal(f0.keypoints, F0[0]) and np.array_equal(f1.keypoints, F1[0])
+    assert np.abs(f1.descriptors - F1[1]).max() < 1e-4
+    assert (matches0 > -1).sum() > 20
+    assert np.mean(matches0 == m0) > 0.97
+
+
 # ------------------------------------------------------------------------------------------- edge cases
 def test_edge_cases_empty_flat_and_ragged(eng):
     """No candidates at all (threshold above every score), a flat image (one giant tie plateau), fewer candidates
