@@ -7,18 +7,20 @@
 // With cross = 1 and q = k = the shared `to_qk` projection this is exactly LightGlue's bidirectional
 // cross attention: softmax over the rows of sim for image 0, over its columns for image 1.
 //
-// Work split: one wave owns 32 query rows, a block is 4 waves = 128 queries of one (image, head); all four
-// waves stream the same 64-key K/V tiles through LDS. Both products keep the QUERY on the MFMA lane:
+// Work split: one wave owns 32 query rows; a block is 128 queries of one (image, head) x G key groups of 4 waves each
+// (G = 2: 8 waves; group g takes every G-th 64-key tile and the partial (O, m, l) are merged through LDS at the end).
+// The four waves of a group stream the same K/V tiles through LDS. Both products keep the QUERY on the MFMA lane:
 //     S^T (keys x queries)  = K . Q^T     A = K tile from LDS (16-byte reads, permuted d order), B = Q in registers
 //     O^T (d x queries)    += V^T . P^T   A = V tile from LDS, B = P = exp2(S^T - m) straight from the accumulator layout
-// so the online-softmax statistics (running max m, running sum l) are one scalar per lane and rescaling the
+// so the online-softmax statistics (reference max m, running sum l) are one scalar per lane and rescaling the
 // output accumulator is a per-lane multiply.
 //
-// Pipeline (one barrier per 64-key tile): K and V tiles live in two LDS rings of depth 2, K running one tile
-// ahead of V. Iteration t issues the QK^T MFMAs of tile t+1 and, in their shadow, the softmax VALU work of tile t,
-// then the PV MFMAs of tile t; global loads for K(t+3) / V(t+2) are in flight meanwhile (register staging).
-// Loads beyond the live key count are clamped to the last valid row (their scores are masked to -inf in the
-// last tile), so the main loop has no divergent branch.
+// Pipeline (one barrier per step of G tiles): K and V tiles live in two LDS rings of depth 2, K running one step
+// ahead of V. Step t issues the QK^T MFMAs of step t+1, the softmax of step t, then the PV MFMAs of step t; the loads
+// for K(t+3) / V(t+2) are in flight meanwhile (register staging by buffer loads: rows past the live key count read as
+// zero through the descriptor's range check and are masked to -inf in the last step, so the loop has no divergent
+// branch and no address arithmetic). On gfx950 VALU / LDS instructions are NOT hidden behind fp32 MFMAs
+// (tools/mfma_peak.hip), so everything next to the MFMAs is written for instruction count - see softmax_tile.
 #include "common.h"
 #include "kernels.h"
 

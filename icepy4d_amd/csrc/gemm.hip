@@ -8,7 +8,7 @@
 // (`lightglue/lightglue.py:280`, `superglue.py:279`).
 //
 // Tiling: 256 threads = 4 waves in a 2x2 grid; each wave owns (BM/2)x(BN/2) of the block tile as
-// 32x32 MFMA tiles. K is consumed in slabs of BK (32 or 64) staged through LDS (row stride BK + 4 floats:
+// 32x32 MFMA tiles. K is consumed in slabs of BK = 32 (64-deep slabs measured neutral-to-slower at the LightGlue shapes) staged through LDS (row stride BK + 4 floats:
 // the ds_read_b128 fragment reads are bank-conflict free). The contraction index inside a slab is
 // permuted (lane-half h reads k = h BK/2 .. contiguously) so that one 16-byte LDS read feeds four
 // MFMAs; A and B use the same permutation, so the product is unchanged up to summation order.
@@ -215,14 +215,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
 
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
     if (a.K % 32 != 0 || (a.A1 && a.ksplit % 64 != 0)) return hipErrorInvalidValue;
-    const bool k64 = false;  // 64-deep slabs measured neutral-to-slower on MI355X at the LightGlue shapes; kept for tuning
     const int bm = a.big_tile ? 128 : 64, bn = bm;
     dim3 grid(((a.N + bn - 1) / bn) * ((a.m_max + bm - 1) / bm), a.batch), block(256);
     if (grid.x == 0) return hipSuccess;
 #define IM_GEMM_CASE(E)                                                                  \
     case E:                                                                              \
         if (a.big_tile) hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 32, E>), grid, block, 0, s, a);   \
-        else if (k64) hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 64, E>), grid, block, 0, s, a);      \
         else hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 32, E>), grid, block, 0, s, a);               \
         break;
     switch (a.epi) {
