@@ -211,17 +211,33 @@ __global__ __launch_bounds__(256 * G, 2 / G) void flash_attn_f32_kernel(AttnArgs
     const int head = (bid % hz) % a.heads, z = (bid % hz) / a.heads;
     const int y = a.cross ? (z ^ 1) : z;
     const int nq = a.n_ptr ? a.n_ptr[z] : a.n_max;
-    const int nk = a.n_ptr ? a.n_ptr[y] : a.n_max;
-    const int qb = (bid / hz) * 128;
-    if (qb >= nq || nk <= 0) return;
+    const int nk_all = a.n_ptr ? a.n_ptr[y] : a.n_max;
+    const int nqb = (a.n_max + 127) / 128;
+    const int qblk = (bid / hz) % nqb, split = (bid / hz) / nqb;
+    const int qb = qblk * 128;
+    if (qb >= nq || nk_all <= 0) return;
+    // Split-KV: with few live queries (pruned pairs, small tiles) 128-query blocks leave most CUs idle, so the keys of a
+    // query block are cut into n_split ranges of whole steps that run on separate blocks (the grid always holds
+    // ATTN_MAX_SPLIT blocks per query block; the surplus exits here). Decided on the device: the live counts are not
+    // known to the host.
+    int n_split = 1, k0 = 0, nk = nk_all;
+    if (a.part) {
+        const int steps_all = (nk_all + KT * G - 1) / (KT * G);
+        const int want = nq > 2048 ? 1 : (nq > 1024 ? 2 : ATTN_MAX_SPLIT);
+        const int steps_per = (steps_all + want - 1) / want;
+        n_split = (steps_all + steps_per - 1) / steps_per;
+        k0 = split * steps_per * (KT * G);
+        nk = min(nk_all - k0, steps_per * (KT * G));
+    }
+    if (split >= n_split) return;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, grp = tid >> 8;
     const int c = lane & 31, hh = lane >> 5;
     const int qrow = qb + wave * 32 + c;
 
     const float* Q = a.q + (long)z * a.bstride + (long)head * a.hstride;
-    const __amdgpu_buffer_rsrc_t K = make_rsrc(a.k + (long)y * a.bstride + (long)head * a.hstride, nk);
-    const __amdgpu_buffer_rsrc_t V = make_rsrc(a.v + (long)y * a.bstride + (long)head * a.hstride, nk);
+    const __amdgpu_buffer_rsrc_t K = make_rsrc(a.k + (long)y * a.bstride + (long)head * a.hstride + (long)k0 * 64, nk);
+    const __amdgpu_buffer_rsrc_t V = make_rsrc(a.v + (long)y * a.bstride + (long)head * a.hstride + (long)k0 * 64, nk);
     const unsigned voff = ((tid >> 4) * 64 + (tid & 15) * 4) * sizeof(float);
 
     // Q fragment: lane (c, hh) keeps Q[qrow][32*hh + s], s = 0..31
@@ -333,10 +349,57 @@ __global__ __launch_bounds__(256 * G, 2 / G) void flash_attn_f32_kernel(AttnArgs
         const float m = fmaxf(m_run, m1);               // group 0 always saw key 0, so m is finite
         const float w0 = __builtin_amdgcn_exp2f(m_run - m), w1 = __builtin_amdgcn_exp2f(m1 - m);
         l_run = l_run * w0 + l1 * w1;
+        m_run = m;                                      // (O, l) are now relative to m: the split-KV merge below needs it
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             o0[r] = o0[r] * w0 + sc[r * 256 + t1] * w1;
             o1[r] = o1[r] * w0 + sc[(16 + r) * 256 + t1] * w1;
+        }
+    }
+
+    // ---- split-KV: park the partial (O, m, l); the last block of this query block merges all of them in split order
+    if (n_split > 1) {
+        const long prow = (((long)z * a.heads + head) * a.n_max + min(qrow, a.n_max - 1)) * 66;
+        const long pstride = (long)a.batch * a.heads * a.n_max * 66;
+        float* pp = a.part + (long)split * pstride + prow;
+        if (qrow < nq) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            *reinterpret_cast<float2*>(pp + 8 * g + 4 * hh) = make_float2(o0[4 * g], o0[4 * g + 1]);
+            *reinterpret_cast<float2*>(pp + 8 * g + 4 * hh + 2) = make_float2(o0[4 * g + 2], o0[4 * g + 3]);
+            *reinterpret_cast<float2*>(pp + 32 + 8 * g + 4 * hh) = make_float2(o1[4 * g], o1[4 * g + 1]);
+            *reinterpret_cast<float2*>(pp + 32 + 8 * g + 4 * hh + 2) = make_float2(o1[4 * g + 2], o1[4 * g + 3]);
+        }
+        if (hh == 0) { pp[64] = m_run; pp[65] = l_run; }
+        }
+        __threadfence();
+        __syncthreads();
+        int* flag = reinterpret_cast<int*>(smem);
+        if (tid == 0) {
+            int* cnt = a.counters + ((long)z * a.heads + head) * nqb + qblk;
+            const int old = atomicAdd(cnt, 1);
+            *flag = (old == n_split - 1);
+            if (old == n_split - 1) *cnt = 0;            // ready for the next launch
+        }
+        __syncthreads();
+        if (!*flag) return;
+        __threadfence();
+        float m = -INFINITY;
+        for (int sidx = 0; sidx < n_split; ++sidx) m = fmaxf(m, a.part[(long)sidx * pstride + prow + 64]);
+        l_run = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+        for (int sidx = 0; sidx < n_split; ++sidx) {
+            const float* ps = a.part + (long)sidx * pstride + prow;
+            const float w = __builtin_amdgcn_exp2f(ps[64] - m);
+            l_run += w * ps[65];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    o0[4 * g + q] += w * ps[8 * g + 4 * hh + q];
+                    o1[4 * g + q] += w * ps[32 + 8 * g + 4 * hh + q];
+                }
         }
     }
 
@@ -364,7 +427,7 @@ static hipError_t launch_g(const AttnArgs& a, hipStream_t s) {
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    dim3 grid(((a.n_max + 127) / 128) * a.heads * a.batch), block(256 * G);
+    dim3 grid(((a.n_max + 127) / 128) * a.heads * a.batch * (a.part ? ATTN_MAX_SPLIT : 1)), block(256 * G);
     hipLaunchKernelGGL(flash_attn_f32_kernel<G>, grid, block, lds, s, a);
     return hipGetLastError();
 }

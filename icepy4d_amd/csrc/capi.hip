@@ -93,6 +93,17 @@ int im_flash_attn(im_ctx* ctx, const float* d_q, const float* d_k, const float* 
     a.q = d_q; a.k = d_k; a.v = d_v; a.hstride = (long)n_max * 64; a.bstride = a.hstride * heads;
     a.out = d_out; a.ldo = heads * 64; a.out_bstride = (long)n_max * a.ldo;
     a.n_ptr = d_n; a.n_max = n_max; a.batch = batch; a.heads = heads; a.cross = cross; a.scale = scale;
+    // split-KV scratch of the stage entry point (the model paths use the reserved workspace): grown on demand
+    const size_t nf = attn_part_floats(n_max, batch, heads), ni = attn_counter_ints(n_max, batch, heads);
+    if (nf > ctx->stage_attn_floats || ni > ctx->stage_attn_ints) {
+        IM_HIP(ctx, hipDeviceSynchronize());
+        float* p = ctx->dalloc<float>(nf);
+        int* c = ctx->dalloc<int>(ni);
+        if (!p || !c) return ctx->fail(-11, "im_flash_attn: out of device memory");
+        IM_HIP(ctx, hipMemset(c, 0, ni * sizeof(int)));
+        ctx->stage_attn_part = p; ctx->stage_attn_cnt = c; ctx->stage_attn_floats = nf; ctx->stage_attn_ints = ni;
+    }
+    a.part = ctx->stage_attn_part; a.counters = ctx->stage_attn_cnt;
     IM_HIP(ctx, launch_flash_attn(a, (hipStream_t)stream));
     return 0;
 }

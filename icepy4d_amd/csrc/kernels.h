@@ -52,7 +52,14 @@ struct AttnArgs {
     int n_max = 0; int batch = 2; int heads = 4; int cross = 0;
     float scale = 1.f;
     const int* active = nullptr;
+    // split-KV workspace (optional): when set, (image, head, query block)s with few queries are cut into up to
+    // ATTN_MAX_SPLIT key ranges on separate blocks; the last block to finish merges the partials (fixed order)
+    float* part = nullptr;       // [ATTN_MAX_SPLIT][batch][heads][n_max][66]  (64 x O, m, l)
+    int* counters = nullptr;     // [batch * heads * ceil(n_max / 128)], zero before the first launch, self-resetting
 };
+static constexpr int ATTN_MAX_SPLIT = 4;
+inline size_t attn_part_floats(int n_max, int batch, int heads) { return (size_t)ATTN_MAX_SPLIT * batch * heads * n_max * 66; }
+inline size_t attn_counter_ints(int n_max, int batch, int heads) { return (size_t)batch * heads * ((n_max + 127) / 128); }
 hipError_t launch_flash_attn(const AttnArgs& a, hipStream_t s);
 
 // ------------------------------------------------------------------ conv.hip

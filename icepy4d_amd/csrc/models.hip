@@ -290,6 +290,7 @@ int im_ctx_reserve(im_ctx* ctx, int max_h, int max_w, int max_images, int max_kp
     }
     A(ws->q, (size_t)2 * K * 256); A(ws->k, (size_t)2 * K * 256); A(ws->v, (size_t)2 * K * 256);
     A(ws->att, (size_t)2 * K * 256); A(ws->msg, (size_t)2 * K * 256); A(ws->h, (size_t)2 * K * 512);
+    A(ws->attn_part, attn_part_floats((int)K, 2, 4)); A(ws->attn_cnt, attn_counter_ints((int)K, 2, 4));
     A(ws->conf, (size_t)2 * K); A(ws->msc, (size_t)2 * K); A(ws->keep_idx, (size_t)2 * K); A(ws->prune, (size_t)2 * K);
     A(ws->md, (size_t)2 * K * 256); A(ws->z, (size_t)2 * K); A(ws->lz, (size_t)2 * K);
     A(ws->sim, (size_t)(K + 1) * (K + 1));
@@ -308,6 +309,7 @@ int im_ctx_reserve(im_ctx* ctx, int max_h, int max_w, int max_images, int max_kp
     ctx->max_h = max_h; ctx->max_w = max_w; ctx->max_images = max_images; ctx->max_kpts = max_kpts;
     IM_HIP(ctx, hipMemset(ws->st, 0, sizeof(LGState)));
     IM_HIP(ctx, hipMemset(ws->sel, 0, 4 * sizeof(int)));
+    IM_HIP(ctx, hipMemset(ws->attn_cnt, 0, attn_counter_ints((int)K, 2, 4) * sizeof(int)));
     IM_HIP(ctx, hipDeviceSynchronize());
     return 0;
 }
@@ -391,7 +393,7 @@ static int lg_block(im_ctx* ctx, hipStream_t s, int layer, bool cross, float* x,
     AttnArgs at;
     at.q = ws->q; at.k = cross ? ws->q : ws->k; at.v = ws->v; at.hstride = (long)K * 64; at.bstride = (long)K * 256;
     at.out = ws->att; at.out_bstride = xb; at.ldo = 256; at.n_ptr = n_ptr; at.n_max = K; at.batch = 2; at.heads = 4;
-    at.cross = cross ? 1 : 0; at.active = active;
+    at.cross = cross ? 1 : 0; at.active = active; at.part = ws->attn_part; at.counters = ws->attn_cnt;
     if (!cross) {
         GemmArgs g = base;
         g.A = x; g.a_bstride = xb; g.lda = 256; g.W = W.qkv_w + (long)layer * 768 * 256; g.ldw = 256;

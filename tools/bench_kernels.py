@@ -36,6 +36,15 @@ def main():
                 ms = timeit(lambda: ctx.call("im_flash_attn", ptr(q), ptr(k), ptr(v), ptr(out), ptr(dn), n, 2, 4, cross, 0.125, stream_ptr()))
                 fl = 2 * 4 * 4.0 * n * n * 64
                 print(f"attn n={n} cross={cross}: {ms:.4f} ms  {fl / ms / 1e9:.1f} TFLOP/s (executed)  {fl / ms / 1e9 / 157.3 * 100:.1f}% of fp32 MFMA peak", flush=True)
+    if "attn" in which:   # pruned pairs: the buffers are sized for 4096 keypoints, fewer are live (decided on the device)
+        nmax = 4096
+        q = torch.randn(2, 4, nmax, 64, device="cuda"); k = torch.randn_like(q); v = torch.randn_like(q)
+        out = torch.empty(2, nmax, 256, device="cuda")
+        for n in (3000, 2048, 1500, 1000, 500):
+            dn = torch.tensor([n, n], dtype=torch.int32, device="cuda")
+            ms = timeit(lambda: ctx.call("im_flash_attn", ptr(q), ptr(k), ptr(v), ptr(out), ptr(dn), nmax, 2, 4, 1, 0.125, stream_ptr()))
+            fl = 2 * 4 * 4.0 * n * n * 64
+            print(f"attn n_max=4096 live n={n} cross=1: {ms:.4f} ms  {fl / ms / 1e9:.1f} TFLOP/s (executed)", flush=True)
     if "conv" in which:
         import ctypes, json
         for (h, w, cin, cout, pool) in ((1080, 1920, 64, 64, 1), (540, 960, 64, 64, 0), (540, 960, 64, 64, 1), (270, 480, 64, 128, 0),
