@@ -169,7 +169,7 @@ class ImageMatcherBase:
             logger.error("Geometric verification skipped: keypoint sets are not paired (use a tile mode)")
         elif gv_method is not GeometricVerification.NONE:
             F, inl = geometric_verification(self._mkpts0, self._mkpts1, method=gv_method, confidence=confidence,
-                                            threshold=threshold)
+                                            threshold=threshold, engine=self.engine)   # hypotheses scored on the device
             self._F = F
             self._filter_matches_by_mask(inl)
             self.timer.update("geometric_verification")

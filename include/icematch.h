@@ -124,6 +124,13 @@ int im_assign_from_sim(im_ctx* ctx, const float* d_sim, int m, int n, int ld, co
 int im_log_optimal_transport(im_ctx* ctx, const float* d_scores, int m, int n, int ld, float bin_score, int iters,
                              float* d_out, void* stream);
 
+/* Fundamental-matrix RANSAC over matched keypoints (`src/icepy4d/matching/geometric_verification.py:11-102`, which
+ * calls pydegensac / cv2 USAC_MAGSAC on the CPU): n_hyp seeded 8-point hypotheses scored by Sampson error in parallel.
+ * d_p0, d_p1 [n][2] float (x, y); d_F [9] double = matrix of the best hypothesis (unit Frobenius norm); d_mask [n] uint8
+ * its inliers; d_info {inlier count, hypothesis index}. The least-squares refit on the inliers is left to the caller. */
+int im_ransac_fundamental(im_ctx* ctx, const float* d_p0, const float* d_p1, int n, int n_hyp, double threshold,
+                          unsigned int seed, double* d_F, uint8_t* d_mask, int32_t* d_info, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

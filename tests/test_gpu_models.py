@@ -340,6 +340,36 @@ def test_sequence_graph_equals_direct_and_oracle():
     e.close()
 
 
+def test_geometric_verification_on_device():
+    """Row f-2: the device RANSAC (all hypotheses at once) against the numpy twin on a synthetic two-view geometry with
+    20 % and 50 % gross outliers and sub-pixel noise: same inliers found (the refit is shared), outliers rejected, the
+    refitted F satisfies the epipolar constraint; seeded => two runs give identical masks."""
+    from icepy4d_amd.engine import Engine
+    from icepy4d_amd.matching import GeometricVerification, geometric_verification
+    e = Engine(0)
+    for n_pts, n_out, seed in ((500, 100, 1), (2000, 1000, 2), (64, 8, 3)):
+        rng = np.random.default_rng(seed)
+        X = np.c_[rng.uniform(-1, 1, n_pts), rng.uniform(-1, 1, n_pts), rng.uniform(4, 8, n_pts)]
+        Kc = np.array([[800, 0, 320], [0, 800, 240], [0, 0, 1.0]])
+        p0 = (Kc @ X.T).T
+        p0 = p0[:, :2] / p0[:, 2:]
+        X1 = X + np.array([0.5, 0.05, 0.1])
+        p1 = (Kc @ X1.T).T
+        p1 = p1[:, :2] / p1[:, 2:] + rng.normal(0, 0.05, size=(n_pts, 2))
+        p1[:n_out] += rng.uniform(20, 60, size=(n_out, 2)) * rng.choice([-1, 1], size=(n_out, 2))
+        p0, p1 = p0.astype(np.float32), p1.astype(np.float32)
+        Fd, md = geometric_verification(p0, p1, GeometricVerification.PYDEGENSAC, threshold=1.0, engine=e)
+        Fd2, md2 = geometric_verification(p0, p1, GeometricVerification.PYDEGENSAC, threshold=1.0, engine=e)
+        Fh, mh = geometric_verification(p0, p1, GeometricVerification.PYDEGENSAC, threshold=1.0)
+        assert Fd is not None and np.array_equal(md, md2) and np.array_equal(Fd, Fd2)
+        assert md[n_out:].mean() > 0.97 and md[:n_out].mean() < 0.05, (md[n_out:].mean(), md[:n_out].mean())
+        assert np.mean(md == mh) > 0.97, np.mean(md == mh)
+        x0 = np.c_[p0[n_out:], np.ones(n_pts - n_out)]
+        x1 = np.c_[p1[n_out:], np.ones(n_pts - n_out)]
+        assert np.abs(np.einsum("ni,ij,nj->n", x1, Fd, x0)).mean() < 1e-3 * np.abs(Fd).max() * 800
+    e.close()
+
+
 def test_matcher_images_of_different_size():
     """`_match_images` with image0 / image1 of different shapes (the reference extracts them independently,
     `lightglue/superpoint.py:224-227`): two SuperPoint launches, one LightGlue call; keypoints identical to the oracle,

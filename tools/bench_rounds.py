@@ -11,7 +11,7 @@ H, W, K = 1080, 1920, 4096
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 50
-sp, lg = synthetic.superpoint_state_dict(0), synthetic.lightglue_state_dict(0, "passthrough")
+sp, lg = synthetic.superpoint_state_dict(0), synthetic.lightglue_state_dict(0, os.environ.get("IM_LG_VARIANT", "passthrough"))
 
 def make_engine():
     e = Engine(0); e.load_state_dict("superpoint", sp); e.load_state_dict("lightglue", lg)
