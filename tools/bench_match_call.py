@@ -1,0 +1,19 @@
+#!/usr/bin/env python3
+"""Wall time of the drop-in call `matcher.match(image0, image1, ...)` (host arrays in, numpy results out), the way
+icepy4d's `main_dev.py:115-132` uses it. Usage: python tools/bench_match_call.py [H W K reps]"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from icepy4d_amd import matching, synthetic
+
+H, W, K, REPS = (int(x) for x in (sys.argv[1:5] if len(sys.argv) >= 5 else (1080, 1920, 4096, 5)))
+a, b = synthetic.translated_pair(0, H, W, 16, 8)
+m = matching.LightGlueMatcher({"state_dicts": {"superpoint": synthetic.superpoint_state_dict(0),
+                                               "lightglue": synthetic.lightglue_state_dict(0, "passthrough")}})
+for gv in (matching.GeometricVerification.NONE, matching.GeometricVerification.PYDEGENSAC):
+    for r in range(REPS):
+        t0 = time.perf_counter()
+        m.match(a, b, quality=matching.Quality.HIGH, tile_selection=matching.TileSelection.GRID, grid=[1, 1], overlap=0,
+                max_keypoints=K, geometric_verification=gv, threshold=2)
+        dt = time.perf_counter() - t0
+        print(f"{gv.name:10s} rep {r}: {dt * 1e3:.1f} ms, {len(m.mkpts0)} matches", flush=True)
