@@ -106,9 +106,14 @@ class Engine:
                       ptr(self.matches), ptr(self.mscores), ptr(self.info), _lib.stream_ptr())
 
     # ------------------------------------------------------------------ results to host (synchronises)
-    def features_to_host(self, image: int):
+    def features_to_host(self, image: int, channels_first: bool = False):
+        """(keypoints [n, 2], descriptors [n, 256] - or [256, n], the reference's layout, transposed on the device when
+        channels_first - and scores [n])."""
         n = int(self.n[image].item())
-        return (self.kpts[image, :n].cpu().numpy(), self.desc[image, :n].cpu().numpy(), self.scores[image, :n].cpu().numpy())
+        d = self.desc[image, :n]
+        if channels_first:
+            d = d.T.contiguous()
+        return (self.kpts[image, :n].cpu().numpy(), d.cpu().numpy(), self.scores[image, :n].cpu().numpy())
 
     def matches_to_host(self, n0: int, n1: int):
         m = self.matches.cpu().numpy().astype(np.int64)

@@ -431,11 +431,11 @@ class ImageMatcherBase:
 
     def _features_from_engine(self):
         eng = self.engine
-        k0, d0, s0 = eng.features_to_host(0)
-        k1, d1, s1 = eng.features_to_host(1)
+        k0, d0, s0 = eng.features_to_host(0, channels_first=True)
+        k1, d1, s1 = eng.features_to_host(1, channels_first=True)
         out = eng.matches_to_host(len(k0), len(k1))
-        f0 = FeaturesBase(keypoints=k0, descriptors=np.ascontiguousarray(d0.T), scores=s0)
-        f1 = FeaturesBase(keypoints=k1, descriptors=np.ascontiguousarray(d1.T), scores=s1)
+        f0 = FeaturesBase(keypoints=k0, descriptors=d0, scores=s0)
+        f1 = FeaturesBase(keypoints=k1, descriptors=d1, scores=s1)
         return f0, f1, out
 
     # ------------------------------------------------------------------ shared device plumbing
@@ -502,11 +502,11 @@ class SuperGlueMatcher(ImageMatcherBase):
             eng.superpoint(up, sp["nms_radius"], sp["keypoint_threshold"], 4, cap, flavour=1, slot=slot)
         eng.superglue(g0.shape, g1.shape, sg["sinkhorn_iterations"], sg["match_threshold"])
         torch.cuda.synchronize()
-        k0, d0, s0 = eng.features_to_host(0)
-        k1, d1, s1 = eng.features_to_host(1)
+        k0, d0, s0 = eng.features_to_host(0, channels_first=True)
+        k1, d1, s1 = eng.features_to_host(1, channels_first=True)
         out = eng.matches_to_host(len(k0), len(k1))
-        features0 = FeaturesBase(keypoints=k0, descriptors=np.ascontiguousarray(d0.T), scores=s0)
-        features1 = FeaturesBase(keypoints=k1, descriptors=np.ascontiguousarray(d1.T), scores=s1)
+        features0 = FeaturesBase(keypoints=k0, descriptors=d0, scores=s0)
+        features1 = FeaturesBase(keypoints=k1, descriptors=d1, scores=s1)
         matches0 = out["matches0"]
         mconf = features0.scores[matches0 > -1]  # q5 (`matchers.py:936-938`)
         return features0, features1, matches0, mconf
@@ -557,11 +557,11 @@ class LightGlueMatcher(ImageMatcherBase):
             eng.superpoint(up, 4, 0.0005, 4, int(max_keypoints), flavour=0, slot=slot)
         eng.lightglue((g0.shape[1], g0.shape[0]), (g1.shape[1], g1.shape[0]), **self._lg_conf)
         torch.cuda.synchronize()
-        k0, d0, s0 = eng.features_to_host(0)
-        k1, d1, s1 = eng.features_to_host(1)
+        k0, d0, s0 = eng.features_to_host(0, channels_first=True)
+        k1, d1, s1 = eng.features_to_host(1, channels_first=True)
         out = eng.matches_to_host(len(k0), len(k1))
-        features0 = FeaturesBase(keypoints=k0, descriptors=np.ascontiguousarray(d0.T), scores=s0)
-        features1 = FeaturesBase(keypoints=k1, descriptors=np.ascontiguousarray(d1.T), scores=s1)
+        features0 = FeaturesBase(keypoints=k0, descriptors=d0, scores=s0)
+        features1 = FeaturesBase(keypoints=k1, descriptors=d1, scores=s1)
         matches0 = out["matches0"]
         mconf = out["matching_scores0"][matches0 > -1]
         self._last = out
