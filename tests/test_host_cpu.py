@@ -223,3 +223,25 @@ def test_match_table_checkpoint_and_resume(tmp_path):
     kp1 = kp0 + 100
     a, b, conf = sq.records_to_features(rec[1], K, kp0, kp1)
     assert a.shape == (1, 2) and np.array_equal(b[0], kp1[3]) and conf[0] == 1.0
+
+
+def test_committed_bench_line_has_the_contract_fields():
+    """The bench line committed under profiles/ (produced by `python bench.py` on the GPU box) carries every field the
+    measurement contract names; guards bench.py against silently dropping one."""
+    import json
+    line = open(os.path.join(ROOT, "profiles", "r01_bench.json")).read().strip().splitlines()[-1]
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "pairs/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("reference", "port") and c["value"] > 0
+    assert abs(d["value"] - 1e3 / d["ms_per_step"] * d["n_gpus"]) < 1e-6 * d["value"]
