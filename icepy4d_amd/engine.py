@@ -24,6 +24,7 @@ class Engine:
         torch.cuda.set_device(self.device)
         self.ctx = _lib.Context(device)
         self.max_h = self.max_w = self.max_images = self.max_kpts = 0
+        self.generation = 0          # bumped whenever the buffers are reallocated (captured graphs become stale)
         self._loaded = set()
 
     # ------------------------------------------------------------------ weights
@@ -55,6 +56,7 @@ class Engine:
         max_kpts = max(max_kpts, self.max_kpts)
         self.ctx.call("im_ctx_reserve", max_h, max_w, max_images, max_kpts)
         self.max_h, self.max_w, self.max_images, self.max_kpts = max_h, max_w, max_images, max_kpts
+        self.generation += 1
         K, B = max_kpts, max_images
         d = self.device
         self.kpts = torch.zeros(B, K, 2, device=d)

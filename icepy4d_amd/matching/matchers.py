@@ -525,6 +525,7 @@ class LightGlueMatcher(ImageMatcherBase):
         eng.load_state_dict("lightglue", _load_state_dict(opt, "lightglue", ["superpoint_lightglue.pth",
                                                                               "superpoint_lightglue_v0-1_arxiv-pth"]))
         self._lg_conf = {k: opt[k] for k in ("depth_confidence", "width_confidence", "filter_threshold") if k in opt}
+        self._graphs = {}
 
     def _sp_params(self, **config):
         if config.get("resize", None) is not None:
@@ -553,9 +554,25 @@ class LightGlueMatcher(ImageMatcherBase):
         g0, g1 = _to_gray_u8(image0, "lightglue"), _to_gray_u8(image1, "lightglue")
         eng = self.engine
         eng.reserve(max(g0.shape[0], g1.shape[0]), max(g0.shape[1], g1.shape[1]), 2, int(max_keypoints))
-        for slot, up in enumerate(self._upload_pair(g0, g1)):   # one batched launch, or one per image if the sizes differ
-            eng.superpoint(up, 4, 0.0005, 4, int(max_keypoints), flavour=0, slot=slot)
-        eng.lightglue((g0.shape[1], g0.shape[0]), (g1.shape[1], g1.shape[0]), **self._lg_conf)
+        if g0.shape == g1.shape and self._opt.get("use_graph", True):
+            # the ~190 launches of a pair have no host dependency: captured once per (shape, keypoint budget) into a HIP
+            # graph and replayed on later calls (icepy4d matches the same camera pair epoch after epoch)
+            key = (g0.shape, int(max_keypoints), eng.generation)
+            sm = self._graphs.get(key)
+            if sm is None:
+                from ..sequence import SequenceMatcher
+                self._graphs = {k: v for k, v in self._graphs.items() if k[2] == eng.generation}   # stale captures
+                sm = SequenceMatcher(eng, g0.shape[0], g0.shape[1], int(max_keypoints), **self._lg_conf)
+                if eng.generation != key[2]:
+                    key = (g0.shape, int(max_keypoints), eng.generation)
+                sm._capture()
+                self._graphs[key] = sm
+            sm._inp.copy_(torch.from_numpy(np.stack([g0, g1])), non_blocking=True)
+            sm._graph.replay()
+        else:
+            for slot, up in enumerate(self._upload_pair(g0, g1)):   # one batched launch, or one per image if the sizes differ
+                eng.superpoint(up, 4, 0.0005, 4, int(max_keypoints), flavour=0, slot=slot)
+            eng.lightglue((g0.shape[1], g0.shape[0]), (g1.shape[1], g1.shape[0]), **self._lg_conf)
         torch.cuda.synchronize()
         k0, d0, s0 = eng.features_to_host(0, channels_first=True)
         k1, d1, s1 = eng.features_to_host(1, channels_first=True)

@@ -10,10 +10,13 @@ H, W, K, REPS = (int(x) for x in (sys.argv[1:5] if len(sys.argv) >= 5 else (1080
 a, b = synthetic.translated_pair(0, H, W, 16, 8)
 m = matching.LightGlueMatcher({"state_dicts": {"superpoint": synthetic.superpoint_state_dict(0),
                                                "lightglue": synthetic.lightglue_state_dict(0, "passthrough")}})
-for gv in (matching.GeometricVerification.NONE, matching.GeometricVerification.PYDEGENSAC):
+cases = (("NONE (whole image, HIP-graph replay)", matching.TileSelection.NONE, matching.GeometricVerification.NONE),
+         ("GRID 1x1 (tile path)", matching.TileSelection.GRID, matching.GeometricVerification.NONE),
+         ("GRID 1x1 + device RANSAC", matching.TileSelection.GRID, matching.GeometricVerification.PYDEGENSAC))
+for name, sel, gv in cases:
     for r in range(REPS):
         t0 = time.perf_counter()
-        m.match(a, b, quality=matching.Quality.HIGH, tile_selection=matching.TileSelection.GRID, grid=[1, 1], overlap=0,
+        m.match(a, b, quality=matching.Quality.HIGH, tile_selection=sel, grid=[1, 1], overlap=0,
                 max_keypoints=K, geometric_verification=gv, threshold=2)
         dt = time.perf_counter() - t0
-        print(f"{gv.name:10s} rep {r}: {dt * 1e3:.1f} ms, {len(m.mkpts0)} matches", flush=True)
+        print(f"{name:38s} rep {r}: {dt * 1e3:.1f} ms, {len(m.mkpts0)} points", flush=True)
