@@ -131,6 +131,12 @@ int im_log_optimal_transport(im_ctx* ctx, const float* d_scores, int m, int n, i
 int im_ransac_fundamental(im_ctx* ctx, const float* d_p0, const float* d_p1, int n, int n_hyp, double threshold,
                           unsigned int seed, double* d_F, uint8_t* d_mask, int32_t* d_info, void* stream);
 
+/* EXPERIMENT, not used by any model path: im_flash_attn with every fp32 product emulated on the
+ * BF16 matrix cores (3-way operand split, six cross products, fp32 accumulation). resplit = 0 reuses the bf16 planes of
+ * the previous call (timing of the attention kernel alone). */
+int im_flash_attn_bf16x3(im_ctx* ctx, const float* d_q, const float* d_k, const float* d_v, float* d_out, const int32_t* d_n,
+                         int n_max, int batch, int heads, int cross, float scale, int resplit, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
