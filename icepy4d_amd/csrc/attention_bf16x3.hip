@@ -105,17 +105,27 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
     asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
     return r;
 }
+__device__ __forceinline__ f32x2 xpk_sub(f32x2 a, f32x2 b) {
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f32x2 xpk_add(f32x2 a, f32x2 b) {
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
 template <int OFF>
 __device__ __forceinline__ void split8(const float (&x)[16], bf16x8& p0, bf16x8& p1, bf16x8& p2) {
     xu32x4 u0, u1, u2;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const float a = x[OFF + 2 * i], b = x[OFF + 2 * i + 1];
-        const unsigned w0 = cvt_pk_bf16(a, b);
-        const float ra = a - __uint_as_float(w0 << 16), rb = b - __uint_as_float(w0 & 0xFFFF0000u);
-        const unsigned w1 = cvt_pk_bf16(ra, rb);
-        const float sa_ = ra - __uint_as_float(w1 << 16), sb_ = rb - __uint_as_float(w1 & 0xFFFF0000u);
-        u0[i] = w0; u1[i] = w1; u2[i] = cvt_pk_bf16(sa_, sb_);
+        const f32x2 v = {x[OFF + 2 * i], x[OFF + 2 * i + 1]};
+        const unsigned w0 = cvt_pk_bf16(v.x, v.y);
+        const f32x2 r = xpk_sub(v, f32x2{__uint_as_float(w0 << 16), __uint_as_float(w0 & 0xFFFF0000u)});
+        const unsigned w1 = cvt_pk_bf16(r.x, r.y);
+        const f32x2 q = xpk_sub(r, f32x2{__uint_as_float(w1 << 16), __uint_as_float(w1 & 0xFFFF0000u)});
+        u0[i] = w0; u1[i] = w1; u2[i] = cvt_pk_bf16(q.x, q.y);
     }
     p0 = as_bf16x8(u0); p1 = as_bf16x8(u1); p2 = as_bf16x8(u2);
 }
@@ -206,9 +216,14 @@ __global__ __launch_bounds__(512, 1) void flash_attn_bf16x3_kernel(AttnArgs a, c
             sa = xmfma(k2, qf[0][m], sa); sa = xmfma(k1, qf[1][m], sa); sa = xmfma(k0, qf[2][m], sa);
             sa = xmfma(k1, qf[0][m], sa); sa = xmfma(k0, qf[1][m], sa); sa = xmfma(k0, qf[0][m], sa);
         }
+        // The first readers of the fresh accumulator are inline-asm VALU instructions (v_max3 / v_pk_add), which the
+        // compiler's hazard recogniser does not cover: an MFMA result must not be read by the VALU for up to 19 wait
+        // states after issue. Tie the wait to the accumulator so it cannot move.
+        asm volatile("s_nop 15\n\ts_nop 7" : "+v"(sa));
         // ---- online softmax (log2 domain, lazily raised reference maximum), keys beyond the live count masked
         const int kbase = t * (2 * BT) + grp * BT;
         if (kbase + BT > nk) {
+            asm volatile("" ::: "memory");              // keep this a branch: only the last step of a group needs it
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 if (kbase + acc_row(r, hh) >= nk) sa[r] = -INFINITY;
