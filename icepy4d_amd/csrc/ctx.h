@@ -69,6 +69,7 @@ struct im_ctx {
     // optional per-launch timing (HIP events on the launch stream), see im_profile_begin / im_profile_end
     struct ProfEntry { const char* name; hipEvent_t e0, e1; };
     bool prof_on = false;
+    hipStream_t prof_stream = nullptr;   // stream of the last timed launch (event-overhead calibration in im_profile_end)
     std::vector<ProfEntry> prof;
     std::vector<hipEvent_t> prof_pool;
     hipEvent_t prof_event() {
@@ -120,6 +121,7 @@ struct im_ctx {
     do {                                                                     \
         if ((ctx)->prof_on) {                                                \
             im_ctx::ProfEntry _pe{name, (ctx)->prof_event(), (ctx)->prof_event()}; \
+            (ctx)->prof_stream = (stream);                                   \
             hipEventRecord(_pe.e0, (stream));                                \
             hipError_t _le = (expr);                                         \
             hipEventRecord(_pe.e1, (stream));                                \
