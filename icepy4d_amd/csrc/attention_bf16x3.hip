@@ -308,6 +308,32 @@ __global__ __launch_bounds__(512, 1) void flash_attn_bf16x3_kernel(AttnArgs a, c
 
 }  // namespace im
 
+namespace im {
+
+size_t attn_x3_plane_elems(int n_max, int batch, int heads) { return (size_t)3 * batch * heads * ((n_max + 63) / 64 * 64) * 64; }
+
+// split (optional) + attention on pre-allocated plane buffers of attn_x3_plane_elems() bf16 each
+hipError_t launch_flash_attn_bf16x3(const AttnArgs& a, unsigned short* qp, unsigned short* kp, unsigned short* vtp, bool resplit,
+                                    hipStream_t s) {
+    if (a.n_max <= 0) return hipSuccess;
+    const int npad = (a.n_max + 63) / 64 * 64;
+    if (resplit)
+        hipLaunchKernelGGL(attn_split3_kernel, dim3(npad / 64, a.heads, a.batch), dim3(256), 0, s, a.q, a.k, a.v, a.bstride, a.hstride,
+                           a.n_ptr, a.n_max, npad, a.scale * 1.4426950408889634f, qp, kp, vtp);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_bf16x3_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)X_LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(flash_attn_bf16x3_kernel, dim3(((a.n_max + 127) / 128) * a.heads * a.batch), dim3(512), X_LDS_BYTES, s, a, qp, kp,
+                       vtp, npad);
+    return hipGetLastError();
+}
+
+}  // namespace im
+
 using namespace im;
 
 // Stage entry point of the experiment: d_q, d_k, d_v fp32 [batch][heads][n_max][64] as for im_flash_attn. resplit = 0
@@ -316,9 +342,7 @@ extern "C" int im_flash_attn_bf16x3(im_ctx* ctx, const float* d_q, const float* 
                                     int n_max, int batch, int heads, int cross, float scale, int resplit, void* stream) {
     IM_CHECK_CTX(ctx);
     if (n_max <= 0) return 0;
-    hipStream_t s = (hipStream_t)stream;
-    const int npad = (n_max + 63) / 64 * 64;
-    const size_t elems = (size_t)3 * batch * heads * npad * 64;
+    const size_t elems = attn_x3_plane_elems(n_max, batch, heads);
     if (elems > ctx->x3_elems) {
         IM_HIP(ctx, hipDeviceSynchronize());
         ctx->x3_q = ctx->dalloc<unsigned short>(elems);
@@ -332,17 +356,6 @@ extern "C" int im_flash_attn_bf16x3(im_ctx* ctx, const float* d_q, const float* 
     a.q = d_q; a.k = d_k; a.v = d_v; a.hstride = (long)n_max * 64; a.bstride = a.hstride * heads;
     a.out = d_out; a.ldo = heads * 64; a.out_bstride = (long)n_max * a.ldo;
     a.n_ptr = d_n; a.n_max = n_max; a.batch = batch; a.heads = heads; a.cross = cross; a.scale = scale;
-    if (resplit)
-        hipLaunchKernelGGL(attn_split3_kernel, dim3(npad / 64, heads, batch), dim3(256), 0, s, d_q, d_k, d_v, a.bstride, a.hstride, d_n,
-                           n_max, npad, scale * 1.4426950408889634f, ctx->x3_q, ctx->x3_k, ctx->x3_vt);
-    static bool attr_set = false;
-    if (!attr_set) {
-        IM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_bf16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)X_LDS_BYTES));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(flash_attn_bf16x3_kernel, dim3(((n_max + 127) / 128) * heads * batch), dim3(512), X_LDS_BYTES, s, a, ctx->x3_q,
-                       ctx->x3_k, ctx->x3_vt, npad);
-    IM_HIP(ctx, hipGetLastError());
+    IM_HIP(ctx, launch_flash_attn_bf16x3(a, ctx->x3_q, ctx->x3_k, ctx->x3_vt, resplit != 0, (hipStream_t)stream));
     return 0;
 }

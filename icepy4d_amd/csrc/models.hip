@@ -306,6 +306,10 @@ int im_ctx_reserve(im_ctx* ctx, int max_h, int max_w, int max_images, int max_kp
     A(ws->q, (size_t)2 * K * 256); A(ws->k, (size_t)2 * K * 256); A(ws->v, (size_t)2 * K * 256);
     A(ws->att, (size_t)2 * K * 256); A(ws->msg, (size_t)2 * K * 256); A(ws->h, (size_t)2 * K * 512);
     A(ws->attn_part, attn_part_floats((int)K, 2, 4)); A(ws->attn_cnt, attn_counter_ints((int)K, 2, 4));
+    if (getenv("IM_ATTN_BF16X3")) {   // experiment, opt-in: planes for the bf16 x 3 attention
+        const size_t xe = attn_x3_plane_elems((int)K, 2, 4);
+        A(ws->x3_q, xe); A(ws->x3_k, xe); A(ws->x3_vt, xe);
+    }
     A(ws->conf, (size_t)2 * K); A(ws->msc, (size_t)2 * K); A(ws->keep_idx, (size_t)2 * K); A(ws->prune, (size_t)2 * K);
     A(ws->md, (size_t)2 * K * 256); A(ws->z, (size_t)2 * K); A(ws->lz, (size_t)2 * K);
     A(ws->sim, (size_t)(K + 1) * (K + 1));
@@ -426,7 +430,12 @@ static int lg_block(im_ctx* ctx, hipStream_t s, int layer, bool cross, float* x,
         IM_LAUNCH(ctx, "lg_proj_gemm", s, launch_gemm(g, s));
         at.scale = 1.f;
     }
-    IM_LAUNCH(ctx, cross ? "flash_attn_cross" : "flash_attn_self", s, launch_flash_attn(at, s));
+    if (ws->x3_q) {   // experiment (IM_ATTN_BF16X3=1 at reserve time): operand split pass + bf16 x 3 attention
+        if (cross) at.k = ws->q;
+        IM_LAUNCH(ctx, cross ? "flash_attn_cross" : "flash_attn_self", s, launch_flash_attn_bf16x3(at, ws->x3_q, ws->x3_k, ws->x3_vt, true, s));
+    } else {
+        IM_LAUNCH(ctx, cross ? "flash_attn_cross" : "flash_attn_self", s, launch_flash_attn(at, s));
+    }
     {   // ffn.0 on cat([x, out_proj(att)]) with out_proj folded into the weights: the second source is the attention output
         GemmArgs g = base;
         g.A = x; g.a_bstride = xb; g.lda = 256; g.A1 = ws->att; g.a1_bstride = xb; g.lda1 = 256; g.ksplit = 256;
