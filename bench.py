@@ -55,8 +55,13 @@ def main():
     ap.add_argument("--pool", type=int, default=4, help="distinct synthetic pairs per rank (cycled)")
     ap.add_argument("--no-graph", action="store_true", help="enqueue launches directly instead of replaying a HIP graph")
     ap.add_argument("--streams", type=int, default=3, help="pairs in flight per GPU (independent contexts on separate HIP streams)")
+    ap.add_argument("--attn-bf16x3", action="store_true",
+                    help="EXPERIMENT (DESIGN.md section 8), not the reported configuration: attention with fp32 products emulated "
+                         "on the bf16 matrix cores")
     args = ap.parse_args()
 
+    if args.attn_bf16x3:
+        os.environ["IM_ATTN_BF16X3"] = "1"   # read by the library when a workspace is reserved
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -158,7 +163,7 @@ def main():
                                "(9 layers, CPU-path semantics: pruning evaluated every layer), seeded weights; epochs sharded "
                                "round-robin, one all-gather of match tables at the end",
                    "height": H, "width": W, "max_keypoints": KPTS, "pairs_per_step": 1, "hip_graph": not args.no_graph,
-                   "pairs_in_flight": args.streams,
+                   "pairs_in_flight": args.streams, "attention": "bf16x3 experiment" if os.environ.get("IM_ATTN_BF16X3") else "fp32 MFMA",
                    "mean_keypoints": n0, "mean_matches": nm},
         "host_enqueue_ms_per_step": 1e3 * t_enq / args.steps, "untimed_pairs_before_timing": warm_pairs,
     }
