@@ -245,3 +245,44 @@ def test_committed_bench_line_has_the_contract_fields():
         assert k in c, k
     assert c["kind"] in ("reference", "port") and c["value"] > 0
     assert abs(d["value"] - 1e3 / d["ms_per_step"] * d["n_gpus"]) < 1e-6 * d["value"]
+
+
+def test_sfm_relative_orientation_and_triangulation():
+    """Row f-4: `estimate_pose` recovers a synthetic relative orientation (R exactly, t up to scale and sign convention
+    x1 = R x0 + t) with gross outliers present; the vectorised linear triangulation equals a restatement of the
+    reference's per-point formulation (`sfm/triangulation.py:166-186`: null vector of [P_i | -x_i]) and reproduces the 3-D
+    points."""
+    from icepy4d_amd import sfm
+    rng = np.random.default_rng(3)
+    n = 300
+    X = np.c_[rng.uniform(-2, 2, n), rng.uniform(-1.5, 1.5, n), rng.uniform(5, 9, n)]
+    K = np.array([[1200.0, 0, 640], [0, 1200.0, 480], [0, 0, 1]])
+    ang = 0.12
+    R = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]])
+    t = np.array([-1.0, 0.05, 0.1])
+    P0, P1 = K @ np.eye(3, 4), K @ np.c_[R, t]
+    h = np.c_[X, np.ones(n)]
+    x0 = (P0 @ h.T).T; x0 = x0[:, :2] / x0[:, 2:]
+    x1 = (P1 @ h.T).T; x1 = x1[:, :2] / x1[:, 2:]
+    x1n = x1 + rng.normal(0, 0.1, x1.shape)
+    x1n[:40] += rng.uniform(30, 80, size=(40, 2))
+    Re, te, inl = sfm.estimate_pose(x0, x1n, K, K, thresh=1.0)
+    assert inl[40:].mean() > 0.95 and inl[:40].mean() < 0.1
+    assert np.abs(Re - R).max() < 5e-3
+    assert np.abs(te / np.linalg.norm(te) - t / np.linalg.norm(t)).max() < 2e-2
+    assert sfm.estimate_pose(x0[:4], x1[:4], K, K, 1.0) is None
+
+    def ref_nviews(P, ip):   # the reference's formulation, restated
+        M = np.zeros([3 * len(P), 4 + len(P)])
+        for i, (x, p) in enumerate(zip(ip, P)):
+            M[3 * i:3 * i + 3, :4] = p
+            M[3 * i:3 * i + 3, 4 + i] = -x
+        V = np.linalg.svd(M)[-1]
+        Xh = V[-1, :4]
+        return Xh / Xh[3]
+
+    h0, h1 = np.c_[x0, np.ones(n)], np.c_[x1, np.ones(n)]
+    Xt = sfm.triangulate_points_linear(P0, P1, h0, h1)
+    ref = np.array([ref_nviews([P0, P1], [a, b]) for a, b in zip(h0, h1)])
+    assert np.abs(Xt - ref).max() < 1e-8 and np.abs(Xt[:, :3] - X).max() < 1e-8
+    assert np.abs(sfm.triangulate_nviews([P0, P1], [h0[5], h1[5]]) - ref[5]).max() < 1e-8
