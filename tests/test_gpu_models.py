@@ -180,6 +180,28 @@ def test_lightglue_golden(lg_eng, ci):
         assert np.array_equal(out["prune1"], g["prune1"])
 
 
+@pytest.mark.parametrize("ci", [1, 3, 5])
+def test_lightglue_golden_with_bf16x3_attention_experiment(ci, monkeypatch):
+    """The opt-in experiment (attention with fp32 products emulated on the bf16 matrix cores) has to
+    stay as exact as the default path: same reference goldens, same assertions (indices exact, scores 1e-4)."""
+    from icepy4d_amd.engine import Engine
+    monkeypatch.setenv("IM_ATTN_BF16X3", "1")      # read by the library when a workspace is reserved
+    e = Engine(0)
+    e.reserve(64, 64, 2, 1024)
+    monkeypatch.delenv("IM_ATTN_BF16X3")
+    g = load_golden(f"g2_lightglue_{ci}")
+    e.load_state_dict("lightglue", synthetic.lightglue_state_dict(0, str(g["variant"])))
+    f = synthetic.synthetic_features(int(g["seed"]), int(g["m"]), int(g["n"]))
+    wc, dc = float(g["width_confidence"]), float(g["depth_confidence"])
+    out = run_lightglue(e, f, depth_confidence=dc, width_confidence=wc)
+    assert out["stop"] == int(g["stop"])
+    assert np.array_equal(out["matches0"], g["matches0"]) and np.array_equal(out["matches1"], g["matches1"])
+    assert np.abs(out["matching_scores0"] - g["matching_scores0"]).max() < 1e-4
+    if wc > 0:
+        assert np.array_equal(out["prune0"], g["prune0"]) and np.array_equal(out["prune1"], g["prune1"])
+    e.close()
+
+
 def test_assign_from_sim_exact(lg_eng):
     """Stage-isolated: the oracle's own similarity matrix in, match indices bit-exact out."""
     from icepy4d_amd._lib import stream_ptr
