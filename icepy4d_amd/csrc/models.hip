@@ -541,7 +541,8 @@ int im_pack_record(im_ctx* ctx, const int32_t* d_n, const int32_t* d_matches0, c
 
 // Copies an internal buffer of the last forward to d_dst (stage-level parity tests). Names: "lg_x" (descriptors after the
 // last executed layer, [2][K][256]), "lg_cos" / "lg_sin" (rotary tables [2][K][32]), "sim" ([K][K] score matrix),
-// "md" (projected matching descriptors [2][K][256]). Synchronises the stream.
+// "md" (projected matching descriptors [2][K][256]), "sp_smap" / "sp_nms" (SuperPoint score map before / after simple_nms of
+// the last im_superpoint_forward, [n_images][H8][W8] densely packed for that call's size). Synchronises the stream.
 int im_debug_read(im_ctx* ctx, const char* name, float* d_dst, size_t nfloats, void* stream) {
     IM_CHECK_CTX(ctx);
     Workspace* ws = ctx->ws;
@@ -555,6 +556,8 @@ int im_debug_read(im_ctx* ctx, const char* name, float* d_dst, size_t nfloats, v
     else if (nm == "lg_sin") { src = ws->sn[ctx->dbg_cur]; avail = 2 * K * 32; }
     else if (nm == "sim") { src = ws->sim; avail = K * K; }
     else if (nm == "md") { src = ws->md; avail = 2 * K * 256; }
+    else if (nm == "sp_smap") { src = ws->smap; avail = (size_t)ctx->max_images * ((ctx->max_h / 8) * 8) * ((ctx->max_w / 8) * 8); }
+    else if (nm == "sp_nms") { src = ws->nms; avail = (size_t)ctx->max_images * ((ctx->max_h / 8) * 8) * ((ctx->max_w / 8) * 8); }
     else return ctx->fail(-61, "im_debug_read: unknown buffer '%s'", name);
     if (nfloats > avail) return ctx->fail(-62, "im_debug_read: %zu floats requested, %zu available", nfloats, avail);
     IM_HIP(ctx, hipMemcpyAsync(d_dst, src, nfloats * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));

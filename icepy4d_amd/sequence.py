@@ -118,7 +118,8 @@ def records_to_features(rec: np.ndarray, max_kpts: int, kpts0: np.ndarray, kpts1
 
 
 class SequenceMatcher:
-    """SuperPoint + LightGlue over a list of stereo pairs on one GPU, results kept on the device.
+    """SuperPoint + LightGlue (or SuperGlue, `matcher="superglue"`) over a list of stereo pairs on one GPU, results kept on
+    the device.
 
     A pair is ~200 kernel launches, none of which needs the host (counts, early stop and pruning are device state),
     so the whole pair is captured once into a HIP graph and replayed per epoch: the input pair is copied into a
@@ -127,11 +128,19 @@ class SequenceMatcher:
 
     def __init__(self, engine, height: int, width: int, max_keypoints: int = 4096, nms_radius: int = 4,
                  detection_threshold: float = 0.0005, remove_borders: int = 4, depth_confidence: float = 0.95,
-                 width_confidence: float = 0.99, filter_threshold: float = 0.1, use_graph: bool = True):
+                 width_confidence: float = 0.99, filter_threshold: float = 0.1, use_graph: bool = True,
+                 matcher: str = "lightglue", sinkhorn_iterations: int = 20, match_threshold: float = 0.3):
         self.e = engine
         self.h, self.w, self.k = height, width, max_keypoints
+        self.matcher = matcher
+        if matcher == "superglue":   # icepy4d's SuperGlue defaults (`matchers.py:854-867`)
+            nms_radius = 3 if nms_radius == 4 else nms_radius
+            detection_threshold = 0.001 if detection_threshold == 0.0005 else detection_threshold
+        elif matcher != "lightglue":
+            raise ValueError(f"unknown matcher {matcher!r}")
         self.sp = (nms_radius, detection_threshold, remove_borders)
         self.lg = dict(depth_confidence=depth_confidence, width_confidence=width_confidence, filter_threshold=filter_threshold)
+        self.sg = dict(sinkhorn_iterations=sinkhorn_iterations, match_threshold=match_threshold)
         engine.reserve(height, width, 2, max_keypoints)
         self.use_graph = use_graph
         self._graph = None
@@ -140,6 +149,10 @@ class SequenceMatcher:
 
     def _enqueue(self, pair_u8: torch.Tensor) -> None:
         e = self.e
+        if self.matcher == "superglue":
+            e.superpoint(pair_u8, self.sp[0], self.sp[1], self.sp[2], self.k, flavour=1)
+            e.superglue((self.h, self.w), (self.h, self.w), **self.sg)
+            return
         e.superpoint(pair_u8, self.sp[0], self.sp[1], self.sp[2], self.k)
         e.lightglue((self.w, self.h), (self.w, self.h), **self.lg)
 
@@ -190,7 +203,9 @@ class PairPipeline:
     on the legacy null stream (graph launches there serialise against every other stream)."""
 
     def __init__(self, make_engine, height: int, width: int, max_keypoints: int = 4096, n_streams: int = 2,
-                 use_graph: bool = True, **matcher_conf):
+                 use_graph: bool = True, pairs_per_launch: int = 1, **matcher_conf):
+        if pairs_per_launch != 1:
+            raise NotImplementedError("pairs_per_launch > 1")
         self.slots = []
         for _ in range(max(1, n_streams)):
             eng = make_engine()
@@ -210,6 +225,9 @@ class PairPipeline:
         self._next = (self._next + 1) % len(self.slots)
         with torch.cuda.stream(stream):
             sm.match_pair(pair_u8, epoch, table, row)
+
+    def flush(self) -> None:
+        """Enqueue whatever is still waiting for a full launch group (nothing with one pair per launch)."""
 
     def synchronize(self) -> None:
         for _, stream, _ in self.slots:

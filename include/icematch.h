@@ -91,7 +91,8 @@ int im_superglue_forward(im_ctx* ctx, const float* d_kpts, const float* d_scores
  * `main_dev.py:160-173`): int32 [8 + 2 * max_kpts] = {epoch, n0, n1, n_matches, stop, 0, 0, 0}, matches0, scores0 bits. */
 int im_pack_record(im_ctx* ctx, const int32_t* d_n, const int32_t* d_matches0, const float* d_mscores0,
                    const int32_t* d_info, int epoch, int32_t* d_record, void* stream);
-/* Copies an internal buffer of the last forward ("lg_x", "lg_cos", "lg_sin", "sim", "md") for stage-level parity tests. */
+/* Copies an internal buffer of the last forward ("lg_x", "lg_cos", "lg_sin", "sim", "md", "sp_smap", "sp_nms") for
+ * stage-level parity tests. */
 int im_debug_read(im_ctx* ctx, const char* name, float* d_dst, size_t nfloats, void* stream);
 
 /* ---- stage entry points (what the stage-isolated parity tests call; also usable on their own) ----------- */

@@ -1,0 +1,187 @@
+"""End-to-end parity report of the HIP path against the oracle: mismatch COUNTS per case, each mismatch traced to the oracle
+decision margin that explains it (tests/margins.py).   *** TEST INFRASTRUCTURE (imports oracle/) ***
+
+    python tests/parity_report.py --out gpurun_out/parity_wino.json            # Winograd convolutions (the default path)
+    IM_CONV_DIRECT=1 python tests/parity_report.py --out gpurun_out/parity_direct.json
+
+`run_case` is also what tests/test_gpu_parity.py asserts on (zero unexplained mismatches).
+
+The chain that is verified, per case:
+  A. extraction: device score map vs oracle score map (max abs error, the float tolerance eps_s := 4 x that, capped at 1e-5);
+     device keypoints vs oracle keypoints: every keypoint of the symmetric difference must be explained by an oracle decision
+     (NMS equality / threshold / top-k cut) with margin <= eps_s; keypoints present on both sides carry scores within 1e-5 and
+     descriptors within 1e-4;
+  B. extraction decisions alone: the oracle's integer stages (simple_nms, border/threshold/top-k) run on the DEVICE's score
+     map must reproduce the device keypoints exactly (ties as sets);
+  C. matching: the oracle's LightGlue run on the DEVICE's features (identical inputs) must give the device's matches0 / stop /
+     prune exactly, or each differing index explained by an arg-max gap / threshold margin <= 1e-4;
+  D. end to end (device vs oracle from pixels): identical when A found no difference and C none; otherwise reported as
+     coordinate-pair overlap (a flipped keypoint changes every descriptor through attention, so no margin applies).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import margins  # noqa: E402
+from icepy4d_amd import synthetic  # noqa: E402
+
+
+def _read(eng, name, numel):
+    from icepy4d_amd._lib import stream_ptr
+    buf = torch.empty(numel, device="cuda")
+    eng.ctx.call("im_debug_read", name.encode(), buf.data_ptr(), numel, stream_ptr())
+    return buf.cpu()
+
+
+def _tie_groups_equal(kp, sc, ref_kp, ref_sc):
+    if kp.shape != ref_kp.shape or not np.array_equal(sc, ref_sc):
+        return False
+    if np.array_equal(kp, ref_kp):
+        return True
+    for v in np.unique(sc[np.any(kp != ref_kp, axis=1)]):
+        idx = np.where(sc == v)[0]
+        if {tuple(p) for p in kp[idx]} != {tuple(p) for p in ref_kp[idx]}:
+            return False
+    return True
+
+
+def run_case(eng, img0, img1, sp_sd, lg_sd, max_k, lg_conf=None, radius=4, thr=0.0005, border=4, match=True):
+    """One stereo pair through the device path and the oracle; returns the report dict (see module docstring)."""
+    from oracle import ref_cpu as o
+    lg_conf = lg_conf or {}
+    h, w = img0.shape
+    assert img1.shape == img0.shape
+    H8, W8 = (h // 8) * 8, (w // 8) * 8
+    eng.reserve(h, w, 2, max_k)
+    K = eng.max_kpts
+    pair = torch.from_numpy(np.stack([img0, img1])).cuda()
+    eng.superpoint(pair, radius, thr, border, max_k)
+    torch.cuda.synchronize()
+    smap_d = _read(eng, "sp_smap", 2 * H8 * W8).view(2, H8, W8)
+    rep = {"shape": [h, w], "max_k": max_k, "images": []}
+    feats_d, feats_o = [], []
+    eps_all = 0.0
+    for b, img in enumerate((img0, img1)):
+        kp, desc, sc = eng.features_to_host(b)
+        with torch.inference_mode():
+            tr = {}
+            ref = o.superpoint_lg(o.frame_to_tensor(img), sp_sd, max_k, radius, thr, border, trace=tr)
+        smap_o, nms_o = tr["score_map"][0], tr["nms"][0]
+        err = float((smap_d[b] - smap_o).abs().max())
+        eps = min(max(4.0 * err, 1e-9), 1e-5)
+        eps_all = max(eps_all, eps)
+        ref_kp, ref_sc, ref_desc = ref["keypoints"].numpy(), ref["keypoint_scores"].numpy(), ref["descriptors"].numpy()
+        ex = margins.explain_keypoint_diffs(smap_o, nms_o, kp, ref_kp, radius, border, thr, max_k, eps)
+        ours = {tuple(p): i for i, p in enumerate(kp)}
+        common = [(ours[tuple(p)], j) for j, p in enumerate(ref_kp) if tuple(p) in ours]
+        ii, jj = (np.array(common).T if common else (np.zeros(0, int), np.zeros(0, int)))
+        # B: the oracle's integer stages on the device's score map
+        with torch.inference_mode():
+            nms_on_d = o.simple_nms(smap_d[b][None], radius)[0]
+            kp_b, sc_b = o.select_keypoints_lg(nms_on_d, border, thr, max_k)
+        stage_exact = _tie_groups_equal(kp, sc, kp_b.numpy(), sc_b.numpy())
+        order = margins.explain_order_diffs(kp, ref_kp, ref_sc, eps)
+        rep["images"].append({
+            "score_map_max_abs_err": err, "eps": eps, "n_keypoints": int(len(kp)), "n_keypoints_oracle": int(len(ref_kp)),
+            "keypoint_set_diff": ex["n_diff"], "diff_reasons": ex["reasons"], "unexplained": ex["unexplained"],
+            "same_order": bool(kp.shape == ref_kp.shape and np.array_equal(kp, ref_kp)),
+            "ranks_moved": order["n_moved"], "ranks_moved_exact_ties": order["n_exact_ties"], "ranks_moved_max_score_gap": order["max_gap"],
+            "ranks_moved_unexplained": order["unexplained"],
+            "score_max_abs_err_common": float(np.abs(sc[ii] - ref_sc[jj]).max()) if len(ii) else 0.0,
+            "desc_max_abs_err_common": float(np.abs(desc[ii] - ref_desc[jj]).max()) if len(ii) else 0.0,
+            "integer_stages_exact_on_device_map": bool(stage_exact)})
+        feats_d.append((kp, desc, sc))
+        feats_o.append(ref)
+    if not match:
+        return rep
+    eng.lightglue((w, h), (w, h), **lg_conf)
+    torch.cuda.synchronize()
+    (k0, d0, s0), (k1, d1, s1) = feats_d
+    out = eng.matches_to_host(len(k0), len(k1))
+    size = torch.tensor([w, h], dtype=torch.float)
+    with torch.inference_mode():
+        tr = {}
+        f0 = dict(keypoints=torch.from_numpy(k0), descriptors=torch.from_numpy(d0), image_size=size)
+        f1 = dict(keypoints=torch.from_numpy(k1), descriptors=torch.from_numpy(d1), image_size=size)
+        same = o.lightglue(f0, f1, lg_sd, trace=tr, **lg_conf)          # C: oracle matcher on the device's features
+        e2e = o.lightglue(feats_o[0], feats_o[1], lg_sd, **lg_conf)     # D: oracle from pixels
+    m0_same = same["matches0"].numpy()
+    pruned = len(tr["kept0"]) != len(k0) or len(tr["kept1"]) != len(k1)
+    if pruned:   # log_assignment is in the compact index space: compare in that space
+        kept0, kept1 = tr["kept0"].numpy(), tr["kept1"].numpy()
+        inv1 = -np.ones(len(k1) + 1, np.int64); inv1[kept1] = np.arange(len(kept1))
+        mo = inv1[out["matches0"][kept0]]; mr = inv1[m0_same[kept0]]
+        exm = margins.explain_match_diffs(tr["log_assignment"], mo, mr, float(lg_conf.get("filter_threshold", 0.1)), 1e-4)
+        outside = int(np.sum(np.delete(out["matches0"], kept0) != -1))
+        exm["matched_but_pruned_in_oracle"] = outside
+    else:
+        exm = margins.explain_match_diffs(tr["log_assignment"], out["matches0"], m0_same,
+                                          float(lg_conf.get("filter_threshold", 0.1)), 1e-4)
+    v = (out["matches0"] > -1) & (m0_same > -1)
+    rep["matching_same_features"] = {
+        "n0": int(len(k0)), "n1": int(len(k1)), "n_matches_device": int((out["matches0"] > -1).sum()),
+        "n_matches_oracle": int((m0_same > -1).sum()), "matches0_diff": exm["n_diff"], "diff_reasons": exm["reasons"],
+        "unexplained": exm["unexplained"], "stop_device": out["stop"], "stop_oracle": int(same["stop"]),
+        "prune0_equal": bool(np.array_equal(out["prune0"], same["prune0"].numpy())),
+        "prune1_equal": bool(np.array_equal(out["prune1"], same["prune1"].numpy())),
+        "mscore_max_abs_err": float(np.abs(out["matching_scores0"][v] - same["matching_scores0"].numpy()[v]).max()) if v.any() else 0.0}
+    ours = margins.match_pairs(k0, k1, out["matches0"])
+    theirs = margins.match_pairs(feats_o[0]["keypoints"].numpy(), feats_o[1]["keypoints"].numpy(), e2e["matches0"].numpy())
+    rep["end_to_end"] = {"pairs_device": len(ours), "pairs_oracle": len(theirs), "pairs_common": len(ours & theirs),
+                         "stop_device": out["stop"], "stop_oracle": int(e2e["stop"]),
+                         "identical": bool(ours == theirs and out["stop"] == int(e2e["stop"]))}
+    return rep
+
+
+def cases(full: bool):
+    from conftest import load_golden
+    g1a, g1b, g4, g5 = (load_golden(n) for n in ("g1_superpoint_a", "g1_superpoint_b", "g4_wrappers", "g5_assets"))
+    yield "g1_a (96x128, K=64)", g1a["image"], g1a["image"], 64
+    yield "g1_b (136x200, K=512)", g1b["image"], g1b["image"], 512
+    yield "g4 wrappers pair (200x304, K=256)", g4["image0"], g4["image1"], 256
+    yield "g5 assets pair = config 1 (800x1200, K=2048)", g5["gray0"], g5["gray1"], 2048
+    if full:
+        a, b = synthetic.translated_pair(0, 1080, 1920, 40, 8)
+        yield "config 2 translated pair (1080x1920, K=4096)", a, b, 4096
+        a, b = synthetic.stereo_pair(0, 1080, 1920)
+        yield "config 2 bench pair, epoch 0 (1080x1920, K=4096)", a, b, 4096
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "parity.json"))
+    ap.add_argument("--no-full", action="store_true")
+    args = ap.parse_args()
+    from icepy4d_amd.engine import Engine
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    sp_sd = synthetic.superpoint_state_dict(0)
+    lg_sd = synthetic.lightglue_state_dict(0, "passthrough")
+    eng = Engine(0)
+    eng.load_state_dict("superpoint", sp_sd)
+    eng.load_state_dict("lightglue", lg_sd)
+    report = {"conv": "direct" if os.environ.get("IM_CONV_DIRECT") == "1" else "winograd", "cases": {}}
+    for name, a, b, k in cases(not args.no_full):
+        t = time.time()
+        report["cases"][name] = run_case(eng, a, b, sp_sd, lg_sd, k)
+        report["cases"][name]["seconds"] = round(time.time() - t, 1)
+        print(name, json.dumps(report["cases"][name]), flush=True)
+    os.makedirs(os.path.dirname(args.out), exist_ok=True)
+    with open(args.out, "w") as fh:
+        json.dump(report, fh, indent=1)
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -19,11 +19,10 @@ def mutual_consistency(m0, m1):
     assert np.array_equal(m0[m1[j]], j)
 
 
-def test_config2_full_size_vs_oracle():
-    """1080 x 1920, 4096 keypoints, SuperPoint + LightGlue: keypoints, descriptors, match indices vs the CPU oracle."""
+def test_config2_full_size_determinism_and_geometry():
+    """1080 x 1920, 4096 keypoints, SuperPoint + LightGlue: two runs bit-identical, match tables mutually consistent, matches
+    follow the true translation. (Parity against the oracle at this size: test_gpu_parity.py, exact or margin-explained.)"""
     from icepy4d_amd.engine import Engine
-    from oracle import ref_cpu as o
-    torch.set_num_threads(min(32, torch.get_num_threads()))
     lg_sd = synthetic.lightglue_state_dict(0, "passthrough")
     img0, img1 = synthetic.translated_pair(0, 1080, 1920, 40, 8)
     e = Engine(0)
@@ -44,20 +43,11 @@ def test_config2_full_size_vs_oracle():
         assert np.array_equal(x, y)                      # bit-identical across runs
     assert np.array_equal(a[6]["matches0"], b[6]["matches0"]) and np.array_equal(a[6]["matching_scores0"], b[6]["matching_scores0"])
     k0, d0, s0, k1, d1, s1, out = a
+    assert k0.shape == (4096, 2)
     mutual_consistency(out["matches0"], out["matches1"])
-    F0, F1, m0, mconf, ref = o.match_images_lightglue(img0, img1, SP_SD, lg_sd, max_keypoints=4096)
-    assert k0.shape == F0[0].shape == (4096, 2) and out["stop"] == ref["stop"]
-    idx = {tuple(p): i for i, p in enumerate(k0)}
-    common = [(idx[tuple(p)], j) for j, p in enumerate(F0[0]) if tuple(p) in idx]
-    assert len(common) >= 0.97 * 4096, len(common)
-    ii, jj = np.array(common).T
-    assert np.abs(d0[ii] - F0[1].T[jj]).max() < 1e-4
-    assert np.abs(s0[ii] - F0[2][jj]).max() < 1e-5
-    ours = {(tuple(k0[i]), tuple(k1[j])) for i, j in enumerate(out["matches0"]) if j > -1}
-    theirs = {(tuple(F0[0][i]), tuple(F1[0][j])) for i, j in enumerate(m0) if j > -1}
-    assert len(theirs) > 500
-    assert len(ours & theirs) >= 0.95 * len(theirs), (len(ours & theirs), len(theirs), len(ours))
-    d = np.array([np.array(q) - np.array(p) for p, q in ours])
+    v = out["matches0"] > -1
+    assert v.sum() > 500
+    d = k1[out["matches0"][v]] - k0[v]
     assert np.mean(np.all(np.abs(d - np.array([40, 8])) < 1.5, 1)) > 0.7   # matches follow the true translation
     e.close()
 

@@ -286,3 +286,68 @@ def test_sfm_relative_orientation_and_triangulation():
     ref = np.array([ref_nviews([P0, P1], [a, b]) for a, b in zip(h0, h1)])
     assert np.abs(Xt - ref).max() < 1e-8 and np.abs(Xt[:, :3] - X).max() < 1e-8
     assert np.abs(sfm.triangulate_nviews([P0, P1], [h0[5], h1[5]]) - ref[5]).max() < 1e-8
+
+
+def test_bench_gpus2_as_typed_spawns_its_ranks_dry_run():
+    """`python bench.py --gpus 2 ...` with no launcher around it: the parent starts one process per rank through
+    torch.distributed.run before anything touches a GPU and relays rank 0's JSON line. --dry-run fabricates the records, so
+    spawn, rendezvous (gloo), epoch sharding, the table all-gather and the JSON contract are exercised on a CPU-only machine."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--dry-run"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["warmup"] == 2 and d["dry_run"] is True and d["scaling"] == "weak"
+    for k in ("metric", "value", "unit", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    # a mismatch between --gpus and the launcher's world size is an error, not a silent single-rank run
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"],
+                       env=dict(env, WORLD_SIZE="1", RANK="0"), capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0
+
+
+def test_margin_extractor_explains_perturbed_decisions():
+    """tests/margins.py on the CPU: perturb the oracle's score map by +-d, redo the oracle's integer stages on the perturbed
+    map, and every keypoint that changed must be traced to an oracle decision (NMS equality / threshold / top-k cut) with margin
+    <= 2d; an unrelated keypoint swap is NOT explained. Same for match indices against arg-max gaps."""
+    import margins
+    from icepy4d_amd import synthetic
+    from oracle import ref_cpu as o
+    sd = synthetic.superpoint_state_dict(0)
+    img = synthetic.band_limited_noise(np.random.default_rng(3), 240, 320)
+    with torch.inference_mode():
+        tr = {}
+        ref = o.superpoint_lg(o.frame_to_tensor(img), sd, 300, trace=tr)
+    S, N = tr["score_map"][0], tr["nms"][0]
+    ref_kp = ref["keypoints"].numpy()
+    n_diff = 0
+    for seed, d in enumerate((1e-5, 1e-4, 1e-4)):
+        g = torch.Generator().manual_seed(seed)
+        Sp = S + (torch.rand(S.shape, generator=g) * 2 - 1) * d
+        kp, _ = o.select_keypoints_lg(o.simple_nms(Sp[None], 4)[0], 4, 0.0005, 300)
+        ex = margins.explain_keypoint_diffs(S, N, kp.numpy(), ref_kp, 4, 4, 0.0005, 300, 2 * d)
+        assert ex["unexplained"] == [], ex
+        n_diff += ex["n_diff"]
+    assert n_diff > 0                                              # the perturbation did flip decisions
+    # a keypoint replaced by a far-away non-candidate pixel has no explaining margin at the float tolerance
+    fake = ref_kp.copy()
+    fake[0] = [7.0, 9.0] if (7.0, 9.0) not in {tuple(p) for p in ref_kp} else [9.0, 7.0]
+    ex = margins.explain_keypoint_diffs(S, N, fake, ref_kp, 4, 4, 0.0005, 300, 1e-7)
+    assert ex["n_diff"] == 2 and len(ex["unexplained"]) >= 1
+    # order: swapping two keypoints whose scores differ by more than eps is unexplained, equal scores are explained
+    sc = ref["keypoint_scores"].numpy()
+    sw = ref_kp.copy()
+    sw[[0, 200]] = sw[[200, 0]]
+    assert margins.explain_order_diffs(sw, ref_kp, sc, 1e-7)["unexplained"] != []
+    assert margins.explain_order_diffs(ref_kp, ref_kp, sc, 1e-7)["n_moved"] == 0
+    # matches: a changed arg-max is explained only when the row / column gap is within eps
+    la = torch.full((4, 4), -5.0)
+    la[0, 0], la[0, 1] = -0.5, -0.5 - 5e-5
+    la[1, 2], la[2, 1] = -0.3, -0.2
+    m_ref = np.array([0, 2, 1])
+    assert margins.explain_match_diffs(la, np.array([1, 2, 1]), m_ref, 0.1, 1e-4)["unexplained"] == []
+    assert margins.explain_match_diffs(la, np.array([0, 0, 1]), m_ref, 0.1, 1e-4)["unexplained"] != []
