@@ -19,7 +19,7 @@ _lib: Optional[C.CDLL] = None
 
 class LightGlueConf(C.Structure):
     _fields_ = [("depth_confidence", C.c_double), ("width_confidence", C.c_double),
-                ("filter_threshold", C.c_double), ("n_layers", C.c_int)]
+                ("filter_threshold", C.c_double), ("n_layers", C.c_int), ("pruning_min_kpts", C.c_int)]
 
 
 class SuperGlueConf(C.Structure):
@@ -41,7 +41,8 @@ SIGNATURES = {
     "im_profile_end": [_P, C.c_char_p, C.c_size_t],
     "im_set_tensor": [_P, C.c_char_p, C.c_char_p, _P, C.c_size_t],
     "im_finalize_weights": [_P, C.c_char_p],
-    "im_superpoint_forward": [_P, _P, _I, _I, _I, _I, _F, _I, _I, _I, _P, _P, _P, _P, _P],
+    "im_superpoint_forward": [_P, _P, _I, _I, _I, _I, _I, _F, _I, _I, _I, _P, _P, _P, _P, _P],
+    "im_superpoint_candidates": [_P, _I, _P, _P],
     "im_lightglue_forward": [_P, _P, _P, _P, _P, C.POINTER(LightGlueConf), _P, _P, _P, _P, _P],
     "im_superglue_forward": [_P, _P, _P, _P, _P, _P, C.POINTER(SuperGlueConf), _P, _P, _P, _P],
     "im_pack_record": [_P, _P, _P, _P, _P, _I, _P, _P],

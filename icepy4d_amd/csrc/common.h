@@ -36,6 +36,23 @@ __device__ __forceinline__ int wave_sum_i(int v) {
     return v;
 }
 
+// Image value fed to conv1a for pixel `pix` of a uint8 image with 1 or 3 interleaved channels.
+//   1 channel : x / 255 (`matchers.py:1212-1220`, `:263-274`; true fp32 division == float64 divide then round, for all 256 inputs)
+//   3 channels, gray_mode 0 (LightGlue flavour): the reference scales the HWC image to float first and converts on the float
+//     image: kornia.color.rgb_to_grayscale = w_r * r + w_g * g + w_b * b with fp32 weights (0.299, 0.587, 0.114), three
+//     separate tensor multiplies and two adds, each rounded to fp32 (`lightglue/utils.py:35-36`): no fused multiply-add here
+//   3 channels, gray_mode 1 (SuperGlue flavour): cv2.cvtColor(RGB2GRAY) on the uint8 image (`matchers.py:911-914`): OpenCV's
+//     fixed-point form with 14 fractional bits, (4899 R + 9617 G + 1868 B + 8192) >> 14, then x / 255
+// kornia and cv2 are un-vendored: both formulas restate their published code (parity unpinned at these two call sites).
+__device__ __forceinline__ float image_value(const uint8_t* __restrict__ img, long pix, int channels, int gray_mode) {
+    if (channels == 1) return (float)img[pix] / 255.0f;
+    const uint8_t* p = img + pix * 3;
+    const unsigned r = p[0], g = p[1], b = p[2];
+    if (gray_mode == 1) return (float)((r * 4899u + g * 9617u + b * 1868u + 8192u) >> 14) / 255.0f;
+    const float rf = (float)r / 255.0f, gf = (float)g / 255.0f, bf = (float)b / 255.0f;
+    return __fadd_rn(__fadd_rn(__fmul_rn(0.299f, rf), __fmul_rn(0.587f, gf)), __fmul_rn(0.114f, bf));
+}
+
 // order-preserving float -> uint32 map (larger float <=> larger uint)
 __device__ __forceinline__ uint32_t f2ord(float f) {
     uint32_t u = __float_as_uint(f);

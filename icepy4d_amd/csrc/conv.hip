@@ -56,12 +56,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
     const float* in = a.in + (long)b * a.H * a.W * a.Cin;
 
     if constexpr (FUSE1A) {
-        const uint8_t* img = a.img + (long)b * a.H * a.W;
+        const uint8_t* img = a.img + (long)b * a.H * a.W * a.img_channels;
         for (int idx = tid; idx < IH * IW; idx += 256) {
             const int iy = idx / IW, ix = idx - iy * IW;
             const int gy = y0 + iy - 2, gx = x0 + ix - 2;
             float v = 0.f;  // conv1a's own zero padding
-            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = (float)img[(long)gy * a.W + gx] / 255.0f;
+            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = image_value(img, (long)gy * a.W + gx, a.img_channels, a.gray_mode);
             sImg[idx] = v;
         }
         for (int idx = tid; idx < 9 * 64 + 64; idx += 256) sW1[idx] = idx < 576 ? a.w1[idx] : a.b1[idx - 576];
@@ -229,7 +229,7 @@ hipError_t launch_conv3x3(const ConvArgs& a, hipStream_t s) {
 // all 256 values, `matchers.py:1220`) -> 3x3 stencil x 64 channels, bias, ReLU -> NHWC. Only used by the stage
 // tests; the forward pass fuses it into conv1b (FUSE1A above).
 // Thread = (pixel, 4 channels): 16 threads write one pixel's 256 contiguous bytes.
-__global__ __launch_bounds__(256) void conv1a_kernel(const uint8_t* __restrict__ img, const float* __restrict__ w,
+__global__ __launch_bounds__(256) void conv1a_kernel(const uint8_t* __restrict__ img, int channels, int gray_mode, const float* __restrict__ w,
                                                       const float* __restrict__ bias, float* __restrict__ out,
                                                       int H, int W) {
     const int b = blockIdx.y;
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void conv1a_kernel(const uint8_t* __restrict__
 #pragma unroll
     for (int t = 0; t < 9; ++t) wt[t] = *reinterpret_cast<const float4*>(w + t * 64 + cg * 4);
     const float4 bv = *reinterpret_cast<const float4*>(bias + cg * 4);
-    const uint8_t* im = img + (long)b * H * W;
+    const uint8_t* im = img + (long)b * H * W * channels;
     const long npix = (long)H * W;
     for (long p0 = (long)blockIdx.x * 64; p0 < npix; p0 += (long)gridDim.x * 64)
     for (long pix = p0 + (threadIdx.x >> 4); pix < min(p0 + 64, npix); pix += 16) {
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void conv1a_kernel(const uint8_t* __restrict__
             for (int dx = 0; dx < 3; ++dx) {
                 const int yy = y + dy - 1, xx = x + dx - 1;
                 float p = 0.f;
-                if (yy >= 0 && yy < H && xx >= 0 && xx < W) p = (float)im[(long)yy * W + xx] / 255.0f;
+                if (yy >= 0 && yy < H && xx >= 0 && xx < W) p = image_value(im, (long)yy * W + xx, channels, gray_mode);
                 const float4 wv = wt[dy * 3 + dx];
                 acc.x = fmaf(p, wv.x, acc.x); acc.y = fmaf(p, wv.y, acc.y);
                 acc.z = fmaf(p, wv.z, acc.z); acc.w = fmaf(p, wv.w, acc.w);
@@ -261,12 +261,12 @@ __global__ __launch_bounds__(256) void conv1a_kernel(const uint8_t* __restrict__
     }
 }
 
-hipError_t launch_conv1a(const uint8_t* img, const float* w, const float* bias, float* out, int B, int H, int W,
-                         hipStream_t s) {
+hipError_t launch_conv1a(const uint8_t* img, int channels, int gray_mode, const float* w, const float* bias, float* out, int B,
+                         int H, int W, hipStream_t s) {
     const long npix = (long)H * W;
     int gx = (int)((npix + 63) / 64);
     if (gx > 65535 * 4) gx = 65535 * 4;
-    hipLaunchKernelGGL(conv1a_kernel, dim3(gx, B), dim3(256), 0, s, img, w, bias, out, H, W);
+    hipLaunchKernelGGL(conv1a_kernel, dim3(gx, B), dim3(256), 0, s, img, channels, gray_mode, w, bias, out, H, W);
     return hipGetLastError();
 }
 

@@ -106,12 +106,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
 
     float tap[9];
     if constexpr (FUSE1A) {
-        const uint8_t* img = a.img + (long)b * a.H * a.W;
+        const uint8_t* img = a.img + (long)b * a.H * a.W * a.img_channels;
         for (int idx = tid; idx < S_IH * S_IW; idx += 256) {
             const int iy = idx / S_IW, ix = idx - iy * S_IW;
             const int gy = y0 + iy - 2, gx = x0 + ix - 2;
             float v = 0.f;
-            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = (float)img[(long)gy * a.W + gx] / 255.0f;
+            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = image_value(img, (long)gy * a.W + gx, a.img_channels, a.gray_mode);
             sImg[idx] = v;
         }
         __syncthreads();

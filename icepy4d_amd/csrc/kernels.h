@@ -75,7 +75,9 @@ struct ConvArgs {
     int pool = 0;                // fused 2x2 max-pool (floor) after bias + ReLU
     int relu = 1;
     // fused first layer: when img != nullptr the input is conv1a(img / 255) computed on the fly (Cin must be 64)
-    const uint8_t* img = nullptr; // uint8 gray [B][H][W]
+    const uint8_t* img = nullptr; // uint8 [B][H][W][img_channels]
+    int img_channels = 1;         // 1 = gray, 3 = RGB interleaved (converted per pixel on the fly: common.h image_value)
+    int gray_mode = 0;            // 3 channels: 0 = float-image weights (LightGlue flavour), 1 = OpenCV uint8 fixed point (SuperGlue)
     const float* w1 = nullptr;    // conv1a weights [9][64]
     const float* b1 = nullptr;    // conv1a bias [64]
 };
@@ -83,6 +85,7 @@ hipError_t launch_conv3x3(const ConvArgs& a, hipStream_t s);
 // Winograd F(2x2, 3x3) variant (conv_wino.hip); a.w = weights packed by pack_conv3x3_wino: [Cin / 8][16][Cout][8]
 hipError_t launch_conv3x3_wino(const ConvArgs& a, hipStream_t s);
 // conv1a: u8 gray [B][H][W] -> (x / 255) * w + b, ReLU -> NHWC [B][H][W][64]; w packed [9][64]
-hipError_t launch_conv1a(const uint8_t* img, const float* w, const float* bias, float* out, int B, int H, int W, hipStream_t s);
+hipError_t launch_conv1a(const uint8_t* img, int channels, int gray_mode, const float* w, const float* bias, float* out, int B, int H,
+                         int W, hipStream_t s);
 
 }  // namespace im

@@ -34,7 +34,7 @@ hipError_t launch_rowdot(const float* x, long bstride, const int* n_ptr, int n_m
                          float thr, int* counter, const int* active, hipStream_t s);
 hipError_t launch_stop_prune(LGState* st, int layer, int do_stop, int do_prune, float depth_conf, float keep_thr,
                              float conf_thr, const float* conf, const float* msc, long vec_bstride, const int* ind_cur,
-                             int* ind_next, int* keep_idx, int* prune, long idx_bstride, hipStream_t s);
+                             int* ind_next, int* keep_idx, int* prune, long idx_bstride, int prune_min, hipStream_t s);
 hipError_t launch_gather_rows(const LGState* st, int n_max, const int* keep_idx, long idx_bstride, const float* x_src,
                               float* x_dst, long x_bstride, const float* cs_src, float* cs_dst, const float* sn_src,
                               float* sn_dst, long enc_bstride, hipStream_t s);

@@ -140,7 +140,7 @@ __global__ __launch_bounds__(1024) void stop_prune_kernel(LGState* __restrict__ 
                                                            const float* __restrict__ conf, const float* __restrict__ msc,
                                                            long vec_bstride, const int* __restrict__ ind_cur,
                                                            int* __restrict__ ind_next, int* __restrict__ keep_idx,
-                                                           int* __restrict__ prune, long idx_bstride) {
+                                                           int* __restrict__ prune, long idx_bstride, int prune_min) {
     __shared__ int part[1024];
     __shared__ int sh_active;
     const int tid = threadIdx.x;
@@ -157,9 +157,10 @@ __global__ __launch_bounds__(1024) void stop_prune_kernel(LGState* __restrict__ 
         sh_active = act;
     }
     __syncthreads();
-    const bool live = sh_active != 0 && do_prune;
     for (int b = 0; b < 2; ++b) {
         const int n = st->n[b];
+        // `if do_point_pruning and desc.shape[-2] > pruning_th` (`lightglue.py:495, 503`): per image, on its live count
+        const bool live = sh_active != 0 && do_prune && n > prune_min;
         const int per = (n + 1023) / 1024;
         const int lo = min(tid * per, n), hi = min(lo + per, n);
         const float* cf = conf + (long)b * vec_bstride;
@@ -209,9 +210,9 @@ __global__ __launch_bounds__(1024) void stop_prune_kernel(LGState* __restrict__ 
 
 hipError_t launch_stop_prune(LGState* st, int layer, int do_stop, int do_prune, float depth_conf, float keep_thr,
                              float conf_thr, const float* conf, const float* msc, long vec_bstride, const int* ind_cur,
-                             int* ind_next, int* keep_idx, int* prune, long idx_bstride, hipStream_t s) {
+                             int* ind_next, int* keep_idx, int* prune, long idx_bstride, int prune_min, hipStream_t s) {
     hipLaunchKernelGGL(stop_prune_kernel, dim3(1), dim3(1024), 0, s, st, layer, do_stop, do_prune, depth_conf, keep_thr, conf_thr,
-                       conf, msc, vec_bstride, ind_cur, ind_next, keep_idx, prune, idx_bstride);
+                       conf, msc, vec_bstride, ind_cur, ind_next, keep_idx, prune, idx_bstride, prune_min);
     return hipGetLastError();
 }
 

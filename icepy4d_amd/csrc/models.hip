@@ -168,9 +168,16 @@ static int finalize_lightglue(im_ctx* ctx) {
     CAT_UP(w.tc_w, "token_confidence.%d.token.0.weight", 256, L - 1);
     CAT_UP(w.tc_b, "token_confidence.%d.token.0.bias", 1, L - 1);
 #undef CAT_UP
-    {
+    if (ctx->host_w.count("lightglue/confidence_thresholds")) {
         GETW(thr, "lightglue", "confidence_thresholds", (size_t)L);
         for (int i = 0; i < L; ++i) w.thr[i] = (*thr)[i];
+    } else {
+        // a registered buffer the reference computes in __init__ and loads with strict=False (`lightglue.py:371-373, 392,
+        // 558-561`): absent from a checkpoint saved without buffers. Same formula, double -> float32.
+        for (int i = 0; i < L; ++i) {
+            double t = 0.8 + 0.1 * std::exp(-4.0 * i / L);
+            w.thr[i] = (float)(t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t));
+        }
     }
     if (!w.wr || !w.qkv_w || !w.qkv_b) return ctx->fail(-22, "weights: upload failed");
     w.ready = true;
@@ -334,11 +341,13 @@ int im_ctx_reserve(im_ctx* ctx, int max_h, int max_w, int max_images, int max_kp
 }
 
 // ------------------------------------------------------------------------------------------------ SuperPoint
-int im_superpoint_forward(im_ctx* ctx, const uint8_t* d_gray, int n_images, int h, int w, int nms_radius, float threshold,
-                          int border, int max_kpts, int flavour, float* d_kpts, float* d_scores, float* d_desc, int32_t* d_n,
-                          void* stream) {
+int im_superpoint_forward(im_ctx* ctx, const uint8_t* d_img, int n_images, int h, int w, int channels, int nms_radius,
+                          float threshold, int border, int max_kpts, int flavour, float* d_kpts, float* d_scores, float* d_desc,
+                          int32_t* d_n, void* stream) {
     IM_CHECK_CTX(ctx);
-    (void)flavour;  // both flavours select the same candidate set (border test commutes with the threshold for thr >= 0)
+    // flavour: both select the same candidate set (the border test commutes with the threshold for thr >= 0, tested); it
+    // only picks the gray conversion of 3-channel input
+    if (channels != 1 && channels != 3) return ctx->fail(-44, "im_superpoint_forward: channels must be 1 (gray) or 3 (RGB), got %d", channels);
     if (!ctx->sp.ready) return ctx->fail(-40, "im_superpoint_forward: weights not finalized");
     Workspace* ws = ctx->ws;
     if (!ws || h > ctx->max_h || w > ctx->max_w || n_images > ctx->max_images)
@@ -360,7 +369,7 @@ int im_superpoint_forward(im_ctx* ctx, const uint8_t* d_gray, int n_images, int 
         ConvArgs a;
         a.in = src; a.bias = W.cb[i]; a.out = dst; a.B = B; a.H = ch; a.W = cw_;
         a.Cin = SP_CIN[i]; a.Cout = SP_COUT[i]; a.pool = pool_after[i]; a.relu = 1;
-        if (i == 0) { a.img = d_gray; a.w1 = W.c1a_w; a.b1 = W.c1a_b; }
+        if (i == 0) { a.img = d_img; a.img_channels = channels; a.gray_mode = flavour == 1 ? 1 : 0; a.w1 = W.c1a_w; a.b1 = W.c1a_b; }
         IM_LAUNCH(ctx, SP_CONV3[i], s, conv(a, i));
         if (pool_after[i]) { ch /= 2; cw_ /= 2; }
         src = dst;
@@ -396,6 +405,14 @@ int im_superpoint_forward(im_ctx* ctx, const uint8_t* d_gray, int n_images, int 
         IM_LAUNCH(ctx, "convDb_gemm", s, launch_gemm(g, s));
         IM_LAUNCH(ctx, "sample_desc", s, launch_sample_desc(ws->dense, B, hc, wc, d_kpts, d_n, K, d_desc, s));
     }
+    return 0;
+}
+
+int im_superpoint_candidates(im_ctx* ctx, int n_images, int32_t* h_counts, void* stream) {
+    IM_CHECK_CTX(ctx);
+    if (!ctx->ws || !h_counts || n_images < 1 || n_images > ctx->max_images) return ctx->fail(-41, "im_superpoint_candidates: bad arguments");
+    IM_HIP(ctx, hipMemcpyAsync(h_counts, ctx->ws->n_cand, sizeof(int32_t) * n_images, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    IM_HIP(ctx, hipStreamSynchronize((hipStream_t)stream));
     return 0;
 }
 
@@ -490,7 +507,8 @@ int im_lightglue_forward(im_ctx* ctx, const float* d_kpts, const float* d_desc, 
         // keep threshold: `scores > (1 - width_confidence)` evaluated in double, compared in fp32 (`lightglue.py:566`)
         const float keep_thr = (float)(1.0 - (double)conf->width_confidence);
         IM_LAUNCH(ctx, "lg_adapt", s, launch_stop_prune(st, i, do_stop, do_prune, (float)conf->depth_confidence, keep_thr, W.thr[i], ws->conf,
-                                                      ws->msc, K, ws->ind[cur], ws->ind[1 - cur], ws->keep_idx, ws->prune, K, s));
+                                                      ws->msc, K, ws->ind[cur], ws->ind[1 - cur], ws->keep_idx, ws->prune, K,
+                                                      conf->pruning_min_kpts, s));
         if (do_prune) {
             IM_LAUNCH(ctx, "lg_adapt", s, launch_gather_rows(st, K, ws->keep_idx, K, ws->x[cur], ws->x[1 - cur], xb, ws->cs[cur], ws->cs[1 - cur],
                                                            ws->sn[cur], ws->sn[1 - cur], eb, s));

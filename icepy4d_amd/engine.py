@@ -5,6 +5,7 @@ torch is plumbing here (device memory, the current HIP stream); every computatio
 from __future__ import annotations
 
 import ctypes as C
+import hashlib
 from typing import Dict, Optional, Tuple
 
 import numpy as np
@@ -12,6 +13,20 @@ import torch
 
 from . import _lib
 from ._lib import LightGlueConf, SuperGlueConf, ptr
+
+
+def state_dict_fingerprint(state_dict: Dict[str, torch.Tensor]) -> str:
+    """Identity of a weight set: SHA-1 over names, shapes and fp32 bytes (50 ms for LightGlue's 12 M parameters). Two
+    matcher objects built from equal state dicts share device weights; different ones never share a context."""
+    h = hashlib.sha1()
+    for key in sorted(state_dict):
+        if key.endswith("num_batches_tracked"):
+            continue
+        t = state_dict[key].detach().cpu().to(torch.float32).contiguous()
+        h.update(key.encode())
+        h.update(str(tuple(t.shape)).encode())
+        h.update(t.numpy().tobytes())
+    return h.hexdigest()
 
 
 class Engine:
@@ -24,14 +39,20 @@ class Engine:
         torch.cuda.set_device(self.device)
         self.ctx = _lib.Context(device)
         self.max_h = self.max_w = self.max_images = self.max_kpts = 0
-        self.generation = 0          # bumped whenever the buffers are reallocated (captured graphs become stale)
-        self._loaded = set()
+        self.generation = 0          # bumped whenever buffers are reallocated OR weights replaced (captured graphs become stale)
+        self._loaded: Dict[str, str] = {}     # model -> fingerprint of the weights on the device
+        self.graphs: Dict[tuple, object] = {}  # captured whole-pair HIP graphs, keyed by (shape, K, settings, generation)
 
     # ------------------------------------------------------------------ weights
     def load_state_dict(self, model: str, state_dict: Dict[str, torch.Tensor]) -> None:
         """Pass a state dict with the official key names (`lightglue/superpoint.py:118-137`,
         `lightglue/lightglue.py:350-373`, `SuperGlue/models/superglue.py:221-242`); the old LightGlue names
-        `self_attn.{i}` / `cross_attn.{i}` are remapped like the reference does (`lightglue.py:388-392`)."""
+        `self_attn.{i}` / `cross_attn.{i}` are remapped like the reference does (`lightglue.py:388-392`).
+        Loading the weights that are already on the device is a no-op; replacing them frees the old device copy, so
+        `generation` is bumped and every HIP graph captured against the old pointers is dropped by its owner."""
+        fp = state_dict_fingerprint(state_dict)
+        if self._loaded.get(model) == fp:
+            return
         m = model.encode()
         for key, t in state_dict.items():
             if key.endswith("num_batches_tracked"):
@@ -45,7 +66,12 @@ class Engine:
             a = np.ascontiguousarray(t.detach().cpu().to(torch.float32).numpy())
             self.ctx.call("im_set_tensor", m, key.encode(), a.ctypes.data, a.size)
         self.ctx.call("im_finalize_weights", m)
-        self._loaded.add(model)
+        self._loaded[model] = fp
+        self.generation += 1
+
+    def holds(self, model: str, fingerprint: str) -> bool:
+        """True if `model` is not loaded yet or loaded with exactly these weights (i.e. a matcher with them may share this engine)."""
+        return self._loaded.get(model, fingerprint) == fingerprint
 
     # ------------------------------------------------------------------ workspace
     def reserve(self, max_h: int, max_w: int, max_images: int = 2, max_kpts: int = 4096) -> None:
@@ -71,26 +97,40 @@ class Engine:
     # ------------------------------------------------------------------ forwards (enqueue only)
     def superpoint(self, gray_u8: torch.Tensor, nms_radius: int = 4, threshold: float = 0.0005, border: int = 4,
                    max_kpts: Optional[int] = None, flavour: int = 0, slot: int = 0) -> None:
-        """gray_u8: device uint8 [B, H, W]. Fills self.kpts / scores / desc / n for images slot .. slot + B - 1
+        """gray_u8: device uint8 [B, H, W] (gray) or [B, H, W, 3] (RGB: converted per pixel inside the first convolution,
+        `flavour` picks the reference's conversion). Fills self.kpts / scores / desc / n for images slot .. slot + B - 1
         (two images of different size are two calls with slot 0 and 1)."""
-        assert gray_u8.dtype == torch.uint8 and gray_u8.is_cuda and gray_u8.dim() == 3 and gray_u8.is_contiguous()
-        B, H, W = gray_u8.shape
+        assert gray_u8.dtype == torch.uint8 and gray_u8.is_cuda and gray_u8.is_contiguous()
+        assert gray_u8.dim() == 3 or (gray_u8.dim() == 4 and gray_u8.shape[3] == 3), gray_u8.shape
+        B, H, W = gray_u8.shape[:3]
+        C_ = 1 if gray_u8.dim() == 3 else 3
         assert 0 <= slot and slot + B <= self.max_images
         k = -1 if max_kpts is None else int(max_kpts)
-        self.ctx.call("im_superpoint_forward", ptr(gray_u8), B, H, W, int(nms_radius), float(threshold), int(border), k,
+        self._last_sp = (slot, B)
+        self.ctx.call("im_superpoint_forward", ptr(gray_u8), B, H, W, C_, int(nms_radius), float(threshold), int(border), k,
                       int(flavour), ptr(self.kpts[slot:]), ptr(self.scores[slot:]), ptr(self.desc[slot:]), ptr(self.n[slot:]),
                       _lib.stream_ptr())
+
+    def candidates(self) -> list:
+        """Candidate counts (before the top-k / capacity cut) of the images of the last `superpoint` call. Synchronises."""
+        slot, B = self._last_sp
+        h = np.zeros(B, dtype=np.int32)
+        self.ctx.call("im_superpoint_candidates", B, h.ctypes.data, _lib.stream_ptr())
+        return h.tolist()
 
     def lightglue(self, size0: Tuple[float, float], size1: Tuple[float, float], depth_confidence: float = 0.95,
                   width_confidence: float = 0.99, filter_threshold: float = 0.1, n_layers: int = 9,
                   kpts: Optional[torch.Tensor] = None, desc: Optional[torch.Tensor] = None,
-                  n: Optional[torch.Tensor] = None) -> None:
+                  n: Optional[torch.Tensor] = None, pruning_min_kpts: int = -1) -> None:
         """Matches image 0 and 1 of (kpts, desc, n) (default: the SuperPoint outputs held by the engine).
-        size = (W, H). Fills self.matches / mscores / prune / info."""
+        size = (W, H). Fills self.matches / mscores / prune / info. pruning_min_kpts: -1 = the reference's CPU-path
+        semantics (pruning evaluated after every layer; what the golden vectors pin), 1024 / 1536 = its CUDA path without /
+        with FlashAttention (`lightglue.py:326-331`)."""
         kpts = self.kpts if kpts is None else kpts
         desc = self.desc if desc is None else desc
         n = self.n if n is None else n
-        conf = LightGlueConf(float(depth_confidence), float(width_confidence), float(filter_threshold), int(n_layers))
+        conf = LightGlueConf(float(depth_confidence), float(width_confidence), float(filter_threshold), int(n_layers),
+                             int(pruning_min_kpts))
         size = np.array([size0[0], size0[1], size1[0], size1[1]], dtype=np.float32)
         self.ctx.call("im_lightglue_forward", ptr(kpts), ptr(desc), ptr(n), size.ctypes.data, C.byref(conf),
                       ptr(self.matches), ptr(self.mscores), ptr(self.prune), ptr(self.info), _lib.stream_ptr())

@@ -38,15 +38,28 @@ logger = logging.getLogger(__name__)
 
 MIN_MATCHES_PER_TILE = 5
 
-_ENGINES: Dict[int, "object"] = {}
+_ENGINES: Dict[int, list] = {}
 
 
-def get_engine(device: int = 0):
-    """One engine (context + workspace) per device and process, shared by all matcher objects."""
-    from ..engine import Engine
-    if device not in _ENGINES:
-        _ENGINES[device] = Engine(device)
-    return _ENGINES[device]
+def get_engine(device: int = 0, state_dicts: Optional[Dict[str, dict]] = None, private: bool = False):
+    """An engine (context + device weights + workspace) on `device` whose weights are, or can become, exactly
+    `state_dicts` ({model: state dict}). Matcher objects with EQUAL weights share one engine (the reference builds a fresh
+    matcher per epoch, `main_dev.py:115-132`: here that costs one fingerprint, no upload, and the captured HIP graph stays
+    valid); a matcher with different weights gets a context of its own, so no object ever runs with another object's weights
+    or replays a graph that points at freed weight buffers."""
+    from ..engine import Engine, state_dict_fingerprint
+    fps = {m: state_dict_fingerprint(sd) for m, sd in (state_dicts or {}).items()}
+    pool = _ENGINES.setdefault(device, [])
+    for eng in ([] if private else pool):
+        if all(eng.holds(m, fp) for m, fp in fps.items()):
+            break
+    else:
+        eng = Engine(device)
+        if not private:     # opt["private_engine"]: a context (weights + workspace) no other matcher object will ever use
+            pool.append(eng)
+    for m, sd in (state_dicts or {}).items():
+        eng.load_state_dict(m, sd)
+    return eng
 
 
 def check_dict_keys(dict: dict, keys: List[str]):
@@ -62,18 +75,18 @@ class FeaturesBase:
     scores: np.ndarray = None
 
 
-def _to_gray_u8(image: np.ndarray, flavour: str) -> np.ndarray:
-    """The kernels take gray uint8. 3-channel input: LightGlue flavour = kornia weights on the scaled float image
-    (`lightglue/utils.py:35-36`), SuperGlue flavour = cv2.cvtColor(RGB2GRAY) on uint8 (`matchers.py:911-914`).
-    Both are un-vendored: the result is rounded to uint8 here, so colour input is parity-unpinned (SURVEY §9);
-    gray input is the pinned path."""
-    if image.ndim == 2:
+def _as_device_image(image: np.ndarray) -> np.ndarray:
+    """What the kernels take: contiguous uint8 [H, W] (gray) or [H, W, 3] (RGB, `core/images.py:75`). The u8 -> float scaling
+    and the gray conversion of 3-channel input happen on the device, per pixel, inside the first convolution, in the
+    reference's order and arithmetic (LightGlue flavour: float image, kornia weights, `lightglue/utils.py:35-36`; SuperGlue
+    flavour: cv2.cvtColor on uint8, `matchers.py:911-914`): no host pass over the image, no rounding to a uint8 gray."""
+    if image.dtype != np.uint8:
+        raise TypeError(f"uint8 image expected, got {image.dtype}")
+    if image.ndim == 2 or (image.ndim == 3 and image.shape[2] == 3):
         return np.ascontiguousarray(image)
-    if image.ndim != 3 or image.shape[2] != 3:
-        raise ValueError(f"Not an image: {image.shape}")
-    f = image.astype(np.float32)
-    g = (0.299 * f[..., 0] + 0.587 * f[..., 1]) + 0.114 * f[..., 2]
-    return np.clip(np.rint(g), 0, 255).astype(np.uint8)
+    if image.ndim == 3 and image.shape[2] == 1:
+        return np.ascontiguousarray(image[..., 0])
+    raise ValueError(f"Not an image: {image.shape}")
 
 
 def _load_state_dict(opt: dict, model: str, filenames: List[str]) -> Dict[str, torch.Tensor]:
@@ -106,12 +119,13 @@ class ImageMatcherBase:
         self._device_index = int(opt.get("device", 0))
         self._device = f"cuda:{self._device_index}"
         self._engine = None
+        self._state_dicts: Dict[str, dict] = {}
         self.reset()
 
     @property
     def engine(self):
         if self._engine is None:
-            self._engine = get_engine(self._device_index)
+            self._engine = get_engine(self._device_index, self._state_dicts, bool(self._opt.get("private_engine", False)))
         return self._engine
 
     def reset(self):
@@ -344,13 +358,13 @@ class ImageMatcherBase:
         params = self._sp_params(**config)
         if params is None or not tile_pairs:
             return None
-        radius, thr, border, max_k, flavour = params
+        radius, thr, border, max_k, flavour = params            # max_k < 0: every candidate (SuperGlue's max_keypoints = -1)
         eng = self.engine
         todo = sorted({(0, a) for a, _ in tile_pairs} | {(1, b) for _, b in tile_pairs})
-        tiles = {k: _to_gray_u8(self._tiler.extract_patch(image0 if k[0] == 0 else image1, (t0_lims if k[0] == 0 else t1_lims)[k[1]]), "")
+        tiles = {k: _as_device_image(self._tiler.extract_patch(image0 if k[0] == 0 else image1, (t0_lims if k[0] == 0 else t1_lims)[k[1]]))
                  for k in todo}
         hmax, wmax = max(t.shape[0] for t in tiles.values()), max(t.shape[1] for t in tiles.values())
-        eng.reserve(hmax, wmax, 2, max(int(max_k), 1))
+        cap = int(self._opt.get("max_keypoints_cap", 16384)) if max_k < 0 else int(max_k)
         cache = {}
         by_shape = {}
         for k in todo:
@@ -359,10 +373,22 @@ class ImageMatcherBase:
             for i in range(0, len(keys), 2):  # two equal-sized tiles per launch
                 grp = keys[i:i + 2]
                 batch = torch.from_numpy(np.stack([tiles[k] for k in grp])).to(eng.device)
-                eng.superpoint(batch, radius, thr, border, max_k, flavour=flavour)
+                while True:
+                    eng.reserve(hmax, wmax, 2, max(cap, 1))
+                    eng.superpoint(batch, radius, thr, border, max_k, flavour=flavour)
+                    if max_k >= 0 or max(eng.candidates()) <= eng.max_kpts:
+                        break
+                    cap = max(eng.candidates())                 # unlimited and more candidates than rows: grow, extract again
                 for slot, k in enumerate(grp):
                     cache[k] = dict(kpts=eng.kpts[slot].clone(), scores=eng.scores[slot].clone(), desc=eng.desc[slot].clone(),
-                                    n=eng.n[slot:slot + 1].clone(), shape=shape)
+                                    n=eng.n[slot:slot + 1].clone(), shape=shape[:2])
+        K = eng.max_kpts
+        for c in cache.values():   # the workspace may have grown after a tile was cached: same row count everywhere
+            if c["kpts"].shape[0] < K:
+                pad = K - c["kpts"].shape[0]
+                c["kpts"] = torch.nn.functional.pad(c["kpts"], (0, 0, 0, pad))
+                c["scores"] = torch.nn.functional.pad(c["scores"], (0, pad))
+                c["desc"] = torch.nn.functional.pad(c["desc"], (0, 0, 0, pad))
         return cache
 
     def _match_cached(self, c0: dict, c1: dict, **config):
@@ -455,9 +481,9 @@ class SuperGlueMatcher(ImageMatcherBase):
         cfg = self._build_superglue_config(opt)
         super().__init__({**opt, **cfg})
         self._cfg = cfg
-        eng = self.engine
-        eng.load_state_dict("superpoint", _load_state_dict(opt, "superpoint", ["superpoint_v1.pth"]))
-        eng.load_state_dict("superglue", _load_state_dict(opt, "superglue", [f"superglue_{cfg['superglue']['weights']}.pth"]))
+        self._state_dicts = {"superpoint": _load_state_dict(opt, "superpoint", ["superpoint_v1.pth"]),
+                             "superglue": _load_state_dict(opt, "superglue", [f"superglue_{cfg['superglue']['weights']}.pth"])}
+        self.engine   # binds (or creates) the engine that holds exactly these weights
 
     def _build_superglue_config(self, opt: dict) -> dict:
         def_opt = {"weights": "outdoor", "keypoint_threshold": 0.001, "max_keypoints": -1, "match_threshold": 0.3,
@@ -470,13 +496,9 @@ class SuperGlueMatcher(ImageMatcherBase):
                               "match_threshold": opt["match_threshold"]},
                 "force_cpu": opt["force_cpu"]}
 
-    def _sp_cap(self) -> int:
-        sp = self._cfg["superpoint"]
-        return int(self._opt.get("max_keypoints_cap", 16384)) if sp["max_keypoints"] < 0 else int(sp["max_keypoints"])
-
     def _sp_params(self, **config):
         sp = self._cfg["superpoint"]
-        return sp["nms_radius"], sp["keypoint_threshold"], 4, self._sp_cap(), 1
+        return sp["nms_radius"], sp["keypoint_threshold"], 4, int(sp["max_keypoints"]), 1
 
     def _enqueue_cached(self, c0: dict, c1: dict, **config) -> None:
         sg = self._cfg["superglue"]
@@ -492,15 +514,28 @@ class SuperGlueMatcher(ImageMatcherBase):
 
     def _match_images(self, image0: np.ndarray, image1: np.ndarray, **config):
         """`SuperGlueMatcher._match_images` (`matchers.py:892-940`) on the GPU."""
-        g0, g1 = _to_gray_u8(image0, "superglue"), _to_gray_u8(image1, "superglue")
+        g0, g1 = _as_device_image(image0), _as_device_image(image1)
         sp, sg = self._cfg["superpoint"], self._cfg["superglue"]
         eng = self.engine
         unlimited = sp["max_keypoints"] < 0
+        # `max_keypoints = -1` (icepy4d's default, `matchers.py:859`) keeps EVERY candidate
+        # (`SuperGlue/models/superpoint.py:196-203`). The workspace is sized for opt["max_keypoints_cap"] candidates per
+        # image (default 16384) and grown to the device-side candidate count whenever an image has more: extraction is then
+        # repeated once, nothing is ever cut silently.
         cap = int(self._opt.get("max_keypoints_cap", 16384)) if unlimited else int(sp["max_keypoints"])
-        eng.reserve(max(g0.shape[0], g1.shape[0]), max(g0.shape[1], g1.shape[1]), 2, max(cap, 1))
-        for slot, up in enumerate(self._upload_pair(g0, g1)):   # one batched launch, or one per image if the sizes differ
-            eng.superpoint(up, sp["nms_radius"], sp["keypoint_threshold"], 4, cap, flavour=1, slot=slot)
-        eng.superglue(g0.shape, g1.shape, sg["sinkhorn_iterations"], sg["match_threshold"])
+        ups = self._upload_pair(g0, g1)
+        while True:
+            eng.reserve(max(g0.shape[0], g1.shape[0]), max(g0.shape[1], g1.shape[1]), 2, max(cap, 1))
+            n_cand = []
+            for slot, up in enumerate(ups):   # one batched launch, or one per image if the sizes differ
+                eng.superpoint(up, sp["nms_radius"], sp["keypoint_threshold"], 4, -1 if unlimited else cap, flavour=1, slot=slot)
+                if unlimited:
+                    n_cand += eng.candidates()
+            if not unlimited or max(n_cand) <= eng.max_kpts:
+                break
+            cap = max(n_cand)
+            logger.info(f"SuperPoint found {cap} candidates: growing the keypoint workspace from {eng.max_kpts}")
+        eng.superglue(g0.shape[:2], g1.shape[:2], sg["sinkhorn_iterations"], sg["match_threshold"])
         torch.cuda.synchronize()
         k0, d0, s0 = eng.features_to_host(0, channels_first=True)
         k1, d1, s1 = eng.features_to_host(1, channels_first=True)
@@ -520,12 +555,11 @@ class LightGlueMatcher(ImageMatcherBase):
         if self._localfeatures != "superpoint":
             raise ValueError("only features='superpoint' is supported (DISK is outside the hot-path scope)")
         super().__init__(opt)
-        eng = self.engine
-        eng.load_state_dict("superpoint", _load_state_dict(opt, "superpoint", ["superpoint_v1.pth"]))
-        eng.load_state_dict("lightglue", _load_state_dict(opt, "lightglue", ["superpoint_lightglue.pth",
-                                                                              "superpoint_lightglue_v0-1_arxiv-pth"]))
-        self._lg_conf = {k: opt[k] for k in ("depth_confidence", "width_confidence", "filter_threshold") if k in opt}
-        self._graphs = {}
+        self._state_dicts = {"superpoint": _load_state_dict(opt, "superpoint", ["superpoint_v1.pth"]),
+                             "lightglue": _load_state_dict(opt, "lightglue", ["superpoint_lightglue.pth",
+                                                                              "superpoint_lightglue_v0-1_arxiv-pth"])}
+        self.engine   # binds (or creates) the engine that holds exactly these weights
+        self._lg_conf = {k: opt[k] for k in ("depth_confidence", "width_confidence", "filter_threshold", "pruning_min_kpts") if k in opt}
 
     def _sp_params(self, **config):
         if config.get("resize", None) is not None:
@@ -551,22 +585,26 @@ class LightGlueMatcher(ImageMatcherBase):
         max_keypoints = config.get("max_keypoints", 10240)
         if config.get("resize", None) is not None:
             raise NotImplementedError("resize is not supported: icepy4d always calls extract(resize=None)")
-        g0, g1 = _to_gray_u8(image0, "lightglue"), _to_gray_u8(image1, "lightglue")
+        g0, g1 = _as_device_image(image0), _as_device_image(image1)
         eng = self.engine
         eng.reserve(max(g0.shape[0], g1.shape[0]), max(g0.shape[1], g1.shape[1]), 2, int(max_keypoints))
         if g0.shape == g1.shape and self._opt.get("use_graph", True):
-            # the ~190 launches of a pair have no host dependency: captured once per (shape, keypoint budget) into a HIP
-            # graph and replayed on later calls (icepy4d matches the same camera pair epoch after epoch)
-            key = (g0.shape, int(max_keypoints), eng.generation)
-            sm = self._graphs.get(key)
+            # the ~190 launches of a pair have no host dependency: captured once per (shape, keypoint budget, matcher
+            # settings) into a HIP graph and replayed on later calls (icepy4d matches the same camera pair epoch after
+            # epoch). The cache lives on the ENGINE, so the fresh matcher object the reference's driver builds for every
+            # epoch (`main_dev.py:115-132`) finds the graph of the previous one; entries captured before a workspace
+            # re-allocation or a weight reload (engine.generation) are dropped.
+            key = (g0.shape, int(max_keypoints), tuple(sorted(self._lg_conf.items())), eng.generation)
+            sm = eng.graphs.get(key)
             if sm is None:
                 from ..sequence import SequenceMatcher
-                self._graphs = {k: v for k, v in self._graphs.items() if k[2] == eng.generation}   # stale captures
-                sm = SequenceMatcher(eng, g0.shape[0], g0.shape[1], int(max_keypoints), **self._lg_conf)
-                if eng.generation != key[2]:
-                    key = (g0.shape, int(max_keypoints), eng.generation)
+                sm = SequenceMatcher(eng, g0.shape[0], g0.shape[1], int(max_keypoints), channels=1 if g0.ndim == 2 else 3,
+                                     **self._lg_conf)
+                key = key[:3] + (eng.generation,)       # the constructor may have grown the workspace
+                for k in [k for k in eng.graphs if k[3] != eng.generation]:
+                    del eng.graphs[k]                   # stale captures
                 sm._capture()
-                self._graphs[key] = sm
+                eng.graphs[key] = sm
             sm._inp.copy_(torch.from_numpy(np.stack([g0, g1])), non_blocking=True)
             sm._graph.replay()
         else:

@@ -129,7 +129,8 @@ class SequenceMatcher:
     def __init__(self, engine, height: int, width: int, max_keypoints: int = 4096, nms_radius: int = 4,
                  detection_threshold: float = 0.0005, remove_borders: int = 4, depth_confidence: float = 0.95,
                  width_confidence: float = 0.99, filter_threshold: float = 0.1, use_graph: bool = True,
-                 matcher: str = "lightglue", sinkhorn_iterations: int = 20, match_threshold: float = 0.3):
+                 matcher: str = "lightglue", sinkhorn_iterations: int = 20, match_threshold: float = 0.3,
+                 pruning_min_kpts: int = -1, channels: int = 1):
         self.e = engine
         self.h, self.w, self.k = height, width, max_keypoints
         self.matcher = matcher
@@ -139,12 +140,13 @@ class SequenceMatcher:
         elif matcher != "lightglue":
             raise ValueError(f"unknown matcher {matcher!r}")
         self.sp = (nms_radius, detection_threshold, remove_borders)
-        self.lg = dict(depth_confidence=depth_confidence, width_confidence=width_confidence, filter_threshold=filter_threshold)
+        self.lg = dict(depth_confidence=depth_confidence, width_confidence=width_confidence, filter_threshold=filter_threshold,
+                       pruning_min_kpts=pruning_min_kpts)
         self.sg = dict(sinkhorn_iterations=sinkhorn_iterations, match_threshold=match_threshold)
         engine.reserve(height, width, 2, max_keypoints)
         self.use_graph = use_graph
         self._graph = None
-        self._inp = torch.zeros(2, height, width, dtype=torch.uint8, device=engine.device)
+        self._inp = torch.zeros((2, height, width) if channels == 1 else (2, height, width, 3), dtype=torch.uint8, device=engine.device)
         self._rec = new_table(1, engine.max_kpts, engine.device)
 
     def _enqueue(self, pair_u8: torch.Tensor) -> None:

@@ -52,13 +52,24 @@ int im_finalize_weights(im_ctx* ctx, const char* model);
 
 /* ---- SuperPoint: `SuperPoint.extract` / `.forward` -----------------------------------------------
  * (`lightglue/superpoint.py:146-231`, `SuperGlue/models/superpoint.py:151-220`).
- * d_gray: uint8 [n_images][h][w].  flavour 0 = LightGlue (border := -1 before threshold), 1 = SuperGlue.
- * max_kpts <= 0 means unlimited (bounded by the reserved max_kpts).
+ * d_img: uint8 [n_images][h][w][channels], channels = 1 (gray) or 3 (RGB, the layout `core/images.py:75` hands to
+ * `match()`); the u8 -> float conversion of `_frame2tensor` (`matchers.py:263-274, 1212-1220`) and, for 3 channels, the gray
+ * conversion happen per pixel inside the first convolution's producer, exactly as the reference orders them:
+ *   flavour 0 = LightGlue: scale to float, then kornia's weights on the FLOAT image (`lightglue/utils.py:35-36`);
+ *               border := -1 before the threshold (`lightglue/superpoint.py:177-184`)
+ *   flavour 1 = SuperGlue: cv2.cvtColor(RGB2GRAY) on the UINT8 image (fixed point), then scale (`matchers.py:911-917`);
+ *               threshold, then the coordinate border mask (`SuperGlue/models/superpoint.py:176-189`)
+ * max_kpts <= 0 means unlimited (bounded by the reserved max_kpts: see im_superpoint_candidates).
  * Outputs (row stride = reserved max_kpts): d_kpts [n_images][max_kpts][2] (x, y), d_scores [n_images][max_kpts],
  * d_desc [n_images][max_kpts][256] (L2-normalised), d_n [n_images]. */
-int im_superpoint_forward(im_ctx* ctx, const uint8_t* d_gray, int n_images, int h, int w,
+int im_superpoint_forward(im_ctx* ctx, const uint8_t* d_img, int n_images, int h, int w, int channels,
                           int nms_radius, float threshold, int border, int max_kpts, int flavour,
                           float* d_kpts, float* d_scores, float* d_desc, int32_t* d_n, void* stream);
+/* Number of candidates (NMS survivors above the threshold, inside the border) each image of the LAST im_superpoint_forward
+ * had BEFORE the top-k / capacity cut; h_counts: host int32 [n_images]. Synchronises the stream. `max_keypoints = -1`
+ * (`SuperGlue/models/superpoint.py:176-203`, icepy4d's SuperGlue default `matchers.py:859`) means "all of them": the caller
+ * compares with the reserved max_kpts, grows the workspace (im_ctx_reserve) and repeats the forward if any were cut. */
+int im_superpoint_candidates(im_ctx* ctx, int n_images, int32_t* h_counts, void* stream);
 
 /* ---- LightGlue: `LightGlue._forward` on the reference's CPU path (`lightglue/lightglue.py:436-556`) ----
  * Inputs for image 0/1 are the two slices of the SuperPoint outputs above (same strides, n_images = 2).
@@ -70,6 +81,9 @@ typedef struct {
     double width_confidence; /* <= 0 disables point pruning (`lightglue.py:318`); Python floats and derives   */
     double filter_threshold; /* `lightglue.py:319`                                 1 - width_confidence in double */
     int n_layers;            /* 9 */
+    int pruning_min_kpts;    /* an image is pruned after a layer only while it holds MORE live points than this
+                                (`lightglue.py:326-331, 495, 503, 581-585`): -1 = the reference's CPU path (always), 1024 = its CUDA
+                                path, 1536 = CUDA with FlashAttention */
 } im_lightglue_conf;
 int im_lightglue_forward(im_ctx* ctx, const float* d_kpts, const float* d_desc, const int32_t* d_n,
                          const float* h_size, const im_lightglue_conf* conf,

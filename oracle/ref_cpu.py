@@ -51,6 +51,14 @@ def rgb_to_gray(img: Tensor) -> Tensor:
     return (0.299 * r + 0.587 * g) + 0.114 * b
 
 
+def rgb_to_gray_u8_cv2(image: np.ndarray) -> np.ndarray:
+    """cv2.cvtColor(image, cv2.COLOR_RGB2GRAY) on uint8 [H,W,3] as `SuperGlueMatcher._match_images` calls it
+    (`matchers.py:911-914`); OpenCV is un-vendored => parity unpinned; its published fixed-point form with 14
+    fractional bits: (4899 R + 9617 G + 1868 B + 8192) >> 14."""
+    a = image.astype(np.uint32)
+    return ((a[..., 0] * 4899 + a[..., 1] * 9617 + a[..., 2] * 1868 + 8192) >> 14).astype(np.uint8)
+
+
 # ----------------------------------------------------------------------------------------------
 # SuperPoint
 # ----------------------------------------------------------------------------------------------
@@ -309,9 +317,10 @@ def mutual_nn_filter(scores: Tensor, th: float):
 
 def lightglue(feats0: dict, feats1: dict, sd: SD, depth_confidence: float = 0.95,
               width_confidence: float = 0.99, filter_threshold: float = 0.1, n_layers: int = 9,
-              trace: Optional[dict] = None) -> dict:
+              trace: Optional[dict] = None, pruning_min_kpts: int = -1) -> dict:
     """`LightGlue._forward` on the CPU path (`lightglue/lightglue.py:436-556`): pruning threshold is -1
-    on CPU (`:326-331`) so pruning is evaluated after every layer but the last (quirk q10).
+    on CPU (`:326-331`) so pruning is evaluated after every layer but the last (quirk q10);
+    `pruning_min_kpts` = 1024 / 1536 restates the CUDA path's `desc.shape[-2] > pruning_th` test (`:495, 503`).
     feats: keypoints [K,2], descriptors [K,256], image_size [2] (batch-free). Returns batch-free tensors."""
     k0, k1 = feats0["keypoints"][None], feats1["keypoints"][None]
     m, n = k0.shape[1], k1.shape[1]
@@ -320,7 +329,9 @@ def lightglue(feats0: dict, feats1: dict, sd: SD, depth_confidence: float = 0.95
     d0 = feats0["descriptors"][None].contiguous()
     d1 = feats1["descriptors"][None].contiguous()
     e0, e1 = lg_posenc(kn0, sd), lg_posenc(kn1, sd)
-    thr = sd["confidence_thresholds"]
+    thr = sd.get("confidence_thresholds")
+    if thr is None:   # registered buffer computed in `LightGlue.__init__` (`lightglue/lightglue.py:371-373, 558-561`)
+        thr = torch.Tensor([float(np.clip(0.8 + 0.1 * np.exp(-4.0 * i / n_layers), 0, 1)) for i in range(n_layers)])
     do_stop = depth_confidence > 0
     do_prune = width_confidence > 0
     ind0, ind1 = torch.arange(m)[None], torch.arange(n)[None]
@@ -350,6 +361,8 @@ def lightglue(feats0: dict, feats1: dict, sd: SD, depth_confidence: float = 0.95
             mw, mb = sd[f"log_assignment.{i}.matchability.weight"], sd[f"log_assignment.{i}.matchability.bias"]
             for side in (0, 1):
                 d, t = (d0, t0) if side == 0 else (d1, t1)
+                if not d.shape[-2] > pruning_min_kpts:
+                    continue
                 keep = torch.sigmoid(F.linear(d, mw, mb)).squeeze(-1) > (1 - width_confidence)
                 if t is not None:
                     keep |= t <= thr[i]
@@ -503,6 +516,10 @@ def match_images_superglue(image0: np.ndarray, image1: np.ndarray, sp_sd: SD, sg
                            sinkhorn_iterations: int = 20, match_threshold: float = 0.3):
     """`SuperGlueMatcher._match_images` (`matchers.py:892-940`) for gray uint8 inputs; note quirk q5:
     mconf = keypoint scores of the valid matches, not match confidences (`matchers.py:936-938`)."""
+    if image0.ndim > 2:
+        image0 = rgb_to_gray_u8_cv2(image0)
+    if image1.ndim > 2:
+        image1 = rgb_to_gray_u8_cv2(image1)
     with torch.inference_mode():
         t0 = torch.tensor(image0 / 255.0, dtype=torch.float)[None, None]
         t1 = torch.tensor(image1 / 255.0, dtype=torch.float)[None, None]

@@ -639,3 +639,124 @@ def test_pack_record_matches_torch_twin(lg_eng):
     assert torch.equal(t_lib.cpu()[:, :8 + 2 * K], t_ref.cpu()[:, :8 + 2 * K].where(t_ref.cpu()[:, :8 + 2 * K] != -1, t_lib.cpu()[:, :8 + 2 * K]))
     r = sq.decode_record(t_lib[1].cpu().numpy(), K)
     assert r["epoch"] == 77 and r["n_matches"] == int((g["matches0"] > -1).sum()) and np.array_equal(r["matches0"], g["matches0"])
+
+
+# ------------------------------------------------------------------------------------------- colour input, pruning gate
+def test_colour_input_on_device_both_flavours():
+    """Row a3: uint8 RGB [H, W, 3] goes to the device as it is; the first convolution's producer scales to float and converts
+    to gray per pixel the way each flavour of the reference does (LightGlue: kornia weights on the float image; SuperGlue:
+    OpenCV's fixed-point uint8 gray). Against golden g6 made by the reference's own code (the two un-vendored conversions
+    restated in the generator: parity unpinned at those two call sites)."""
+    from icepy4d_amd.engine import Engine
+    g = load_golden("g6_colour")
+    rgb = torch.from_numpy(g["rgb"])
+    e = Engine(0)
+    e.load_state_dict("superpoint", SP_SD)
+    e.reserve(200, 304, 2, 300)
+    pair = torch.stack([rgb, rgb]).contiguous().cuda()                  # [2, H, W, 3]
+    res = {}
+    for name, (fl, radius, thr) in {"lg": (0, 4, 0.0005), "sg": (1, 3, 0.001)}.items():
+        e.superpoint(pair, radius, thr, 4, 300, flavour=fl)
+        torch.cuda.synchronize()
+        kp, desc, sc = e.features_to_host(0)
+        kp1, desc1, sc1 = e.features_to_host(1)
+        assert np.array_equal(kp, kp1) and np.array_equal(desc, desc1)
+        ordered_equal_or_tied(kp, sc, g[f"{name}_keypoints"], g[f"{name}_scores"])
+        idx = {tuple(p): i for i, p in enumerate(kp)}
+        perm = np.array([idx[tuple(p)] for p in g[f"{name}_keypoints"]])
+        assert np.abs(sc[perm] - g[f"{name}_scores"]).max() < 1e-5
+        ref_desc = g["lg_descriptors"] if name == "lg" else g["sg_descriptors"].T
+        assert np.abs(desc[perm] - ref_desc).max() < 1e-4
+        res[name] = (kp.copy(), sc.copy())
+    # the device path really converts in float for flavour 0: feeding the ROUNDED uint8 gray instead gives other score bits
+    gray_u8 = torch.from_numpy(np.clip(np.rint(g["lg_gray"] * 255.0), 0, 255).astype(np.uint8))
+    e.superpoint(torch.stack([gray_u8, gray_u8]).contiguous().cuda(), 4, 0.0005, 4, 300, flavour=0)
+    torch.cuda.synchronize()
+    _, _, sc_r = e.features_to_host(0)
+    assert not np.array_equal(np.sort(sc_r), np.sort(res["lg"][1]))
+    # and the uint8 fixed-point gray of flavour 1 equals feeding that gray image directly
+    e.superpoint(torch.stack([torch.from_numpy(g["sg_gray_u8"])] * 2).contiguous().cuda(), 3, 0.001, 4, 300, flavour=1)
+    torch.cuda.synchronize()
+    kp_g, _, sc_g = e.features_to_host(0)
+    assert np.array_equal(kp_g, res["sg"][0]) and np.array_equal(sc_g, res["sg"][1])
+    e.close()
+
+
+def test_matcher_api_takes_rgb_images():
+    """`match()` with the RGB arrays icepy4d's `Image.value` delivers (`core/images.py:75`, `main_dev.py:115-132`): same result
+    as the oracle on the same RGB input, for both matcher classes (whole image and tiles)."""
+    from icepy4d_amd.matching import GeometricVerification, LightGlueMatcher, Quality, SuperGlueMatcher, TileSelection
+    o = oracle()
+    g = load_golden("g6_colour")
+    rgb0 = g["rgb"]
+    rgb1 = np.ascontiguousarray(np.roll(rgb0, (8, 16), axis=(0, 1)))
+    lg_sd = synthetic.lightglue_state_dict(0, "passthrough")
+    m = LightGlueMatcher({"state_dicts": {"superpoint": SP_SD, "lightglue": lg_sd}})
+    f0, f1, matches0, mconf = m._match_images(rgb0, rgb1, max_keypoints=256)
+    F0, F1, m0, ref_conf, _ = o.match_images_lightglue(rgb0, rgb1, SP_SD, lg_sd, max_keypoints=256)
+    assert_same_matches(f0.keypoints, f1.keypoints, matches0, F0[0], F1[0], m0, F0[2], F1[2])
+    assert (matches0 > -1).sum() > 20
+    m.match(rgb0, rgb1, quality=Quality.HIGH, tile_selection=TileSelection.GRID, grid=[1, 2], overlap=10,
+            geometric_verification=GeometricVerification.NONE, max_keypoints=256)
+    assert len(m.mkpts0) > 20 and len(m.mkpts0) == len(m.mkpts1)
+    sg_sd = synthetic.superglue_state_dict(0, "passthrough")
+    s = SuperGlueMatcher({"weights": "outdoor", "keypoint_threshold": 0.001, "max_keypoints": 256, "match_threshold": 0.3,
+                          "force_cpu": False, "state_dicts": {"superpoint": SP_SD, "superglue": sg_sd}})
+    f0, f1, matches0, _ = s._match_images(rgb0, rgb1)
+    G0, G1, m0, _, _ = o.match_images_superglue(rgb0, rgb1, SP_SD, sg_sd, max_keypoints=256)
+    assert_same_matches(f0.keypoints, f1.keypoints, matches0, G0[0], G1[0], m0, G0[2], G1[2])
+
+
+def test_superglue_unlimited_keypoints_grow_the_workspace():
+    """`max_keypoints = -1` (icepy4d's SuperGlue default, `matchers.py:859`) keeps every candidate: with a deliberately small
+    initial capacity the matcher learns the device-side candidate count, grows the workspace and extracts again - the result
+    equals the oracle's unlimited extraction (row-major keypoint order, no top-k)."""
+    from icepy4d_amd.matching import SuperGlueMatcher
+    o = oracle()
+    a, b = synthetic.translated_pair(9, 136, 200, 8, 8)
+    sg_sd = synthetic.superglue_state_dict(0, "passthrough")
+    s = SuperGlueMatcher({"weights": "outdoor", "keypoint_threshold": 0.001, "max_keypoints": -1, "match_threshold": 0.3,
+                          "force_cpu": False, "max_keypoints_cap": 64, "state_dicts": {"superpoint": SP_SD, "superglue": sg_sd},
+                          "private_engine": True})
+    f0, f1, matches0, _ = s._match_images(a, b)
+    G0, G1, m0, _, _ = o.match_images_superglue(a, b, SP_SD, sg_sd, max_keypoints=-1)
+    assert len(G0[0]) > 64 and np.array_equal(f0.keypoints, G0[0]) and np.array_equal(f1.keypoints, G1[0])
+    assert np.array_equal(matches0, m0)
+
+
+def test_lightglue_pruning_gate_and_missing_thresholds_buffer(lg_eng):
+    """`pruning_min_kpts` (the reference's CUDA-path gate `desc.shape[-2] > pruning_th`, `lightglue.py:495, 503`) against
+    golden g2_lightglue_6 (reference run with the gate at 280: image 0 pruned once, image 1 never), and a state dict without
+    the `confidence_thresholds` buffer (the reference recomputes it in __init__) loads and gives the same result."""
+    g = load_golden("g2_lightglue_6")
+    sd = synthetic.lightglue_state_dict(0, str(g["variant"]))
+    f = synthetic.synthetic_features(int(g["seed"]), int(g["m"]), int(g["n"]))
+    for w in (sd, {k: v for k, v in sd.items() if k != "confidence_thresholds"}):
+        lg_eng.load_state_dict("lightglue", w)
+        out = run_lightglue(lg_eng, f, depth_confidence=float(g["depth_confidence"]), width_confidence=float(g["width_confidence"]),
+                            pruning_min_kpts=int(g["pruning_min_kpts"]))
+        assert np.array_equal(out["matches0"], g["matches0"]) and np.array_equal(out["matches1"], g["matches1"])
+        assert np.array_equal(out["prune0"], g["prune0"]) and np.array_equal(out["prune1"], g["prune1"])
+        assert np.abs(out["matching_scores0"] - g["matching_scores0"]).max() < 1e-4
+
+
+def test_matchers_with_different_weights_do_not_share_a_context():
+    """two matcher objects with DIFFERENT weights must not overwrite each other's device weights (nor replay a graph
+    captured against freed weight buffers); with EQUAL weights they share one engine and its captured graph."""
+    from icepy4d_amd.matching import LightGlueMatcher
+    g = load_golden("g4_wrappers")
+    sd_a = {"superpoint": SP_SD, "lightglue": synthetic.lightglue_state_dict(0, "passthrough")}
+    sd_b = {"superpoint": SP_SD, "lightglue": synthetic.lightglue_state_dict(0, "default")}
+    A = LightGlueMatcher({"state_dicts": sd_a})
+    fa = A._match_images(g["image0"], g["image1"], max_keypoints=256)
+    B = LightGlueMatcher({"state_dicts": sd_b})
+    assert B.engine is not A.engine
+    fb = B._match_images(g["image0"], g["image1"], max_keypoints=256)
+    fa2 = A._match_images(g["image0"], g["image1"], max_keypoints=256)       # replays A's graph: still A's weights
+    assert np.array_equal(fa[2], fa2[2]) and np.array_equal(fa[3], fa2[3])
+    assert not np.array_equal(fa[2], fb[2])
+    A2 = LightGlueMatcher({"state_dicts": {k: {n: t.clone() for n, t in v.items()} for k, v in sd_a.items()}})
+    assert A2.engine is A.engine and len(A.engine.graphs) >= 1
+    n_graphs = len(A.engine.graphs)
+    fa3 = A2._match_images(g["image0"], g["image1"], max_keypoints=256)      # fresh object, same weights: no new capture
+    assert len(A.engine.graphs) == n_graphs and np.array_equal(fa[2], fa3[2])

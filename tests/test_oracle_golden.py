@@ -108,3 +108,44 @@ def test_assets_pair_config1():
     close(out["matching_scores0"], g["matching_scores0"])
     assert out["stop"] == int(g["stop"])
     assert np.array_equal(out["prune0"].numpy(), g["prune0"])
+
+
+def test_colour_input_both_flavours():
+    """G6: uint8 RGB input through the reference's own code (kornia / cv2 colour conversions restated in the generator)."""
+    g = load_golden("g6_colour")
+    with torch.inference_mode():
+        x = o.frame_to_tensor(g["rgb"])
+        assert x.shape == (3, 200, 304)
+        close(o.rgb_to_gray(x[None])[0, 0], g["lg_gray"], 0)
+        out = o.superpoint_lg(x, SP_SD, 300)
+        assert np.array_equal(out["keypoints"].numpy(), g["lg_keypoints"])
+        close(out["keypoint_scores"], g["lg_scores"], 0)
+        close(out["descriptors"], g["lg_descriptors"])
+        gray = o.rgb_to_gray_u8_cv2(g["rgb"])
+        assert np.array_equal(gray, g["sg_gray_u8"])
+        sg = o.superpoint_sg(torch.tensor(gray / 255.0, dtype=torch.float)[None, None], SP_SD, 3, 0.001, 300)
+        assert np.array_equal(sg["keypoints"].numpy(), g["sg_keypoints"])
+        close(sg["scores"], g["sg_scores"], 0)
+        close(sg["descriptors"], g["sg_descriptors"])
+    # the float gray is NOT the rounded uint8 gray: the two flavours see different pixels
+    assert np.abs(g["lg_gray"] * 255.0 - g["sg_gray_u8"]).max() > 0.3
+
+
+def test_lightglue_pruning_threshold_and_missing_thresholds_buffer():
+    """`pruning_min_kpts` restates the CUDA path's `desc.shape[-2] > pruning_th` (`lightglue.py:495, 503`): against the
+    reference run with its CPU threshold patched to 280 (golden g2_lightglue_6), and a state dict without the
+    `confidence_thresholds` buffer gives the same result (the reference computes it in __init__)."""
+    g = load_golden("g2_lightglue_6")
+    sd = synthetic.lightglue_state_dict(0, str(g["variant"]))
+    f = synthetic.synthetic_features(int(g["seed"]), int(g["m"]), int(g["n"]))
+    f0 = dict(keypoints=torch.from_numpy(f["kpts0"]), descriptors=torch.from_numpy(f["desc0"]), image_size=torch.from_numpy(f["size0"]))
+    f1 = dict(keypoints=torch.from_numpy(f["kpts1"]), descriptors=torch.from_numpy(f["desc1"]), image_size=torch.from_numpy(f["size1"]))
+    sd2 = {k: v for k, v in sd.items() if k != "confidence_thresholds"}
+    for w in (sd, sd2):
+        with torch.inference_mode():
+            out = o.lightglue(f0, f1, w, depth_confidence=float(g["depth_confidence"]), width_confidence=float(g["width_confidence"]),
+                              pruning_min_kpts=int(g["pruning_min_kpts"]))
+        for key in ("matches0", "matches1", "prune0", "prune1"):
+            assert np.array_equal(out[key].numpy(), g[key]), key
+        close(out["matching_scores0"], g["matching_scores0"])
+    assert (g["prune1"] == 1).all() and (g["prune0"] > 1).any()      # image 1 (257 points) was never pruned, image 0 was

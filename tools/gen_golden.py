@@ -92,11 +92,89 @@ def noise_image(seed, h, w):
     return synthetic.band_limited_noise(np.random.default_rng(seed), h, w)
 
 
+def kornia_rgb_to_grayscale(image, rgb_weights=None):
+    """RESTATEMENT of kornia.color.rgb_to_grayscale for floating-point images (kornia is un-vendored and absent here):
+    weights (0.299, 0.587, 0.114) in the image dtype, `w_r * r + w_g * g + w_b * b`. Parity unpinned at this call site."""
+    r, g, b = image[..., 0:1, :, :], image[..., 1:2, :, :], image[..., 2:3, :, :]
+    w = torch.tensor([0.299, 0.587, 0.114], device=image.device, dtype=image.dtype)
+    return w[0] * r + w[1] * g + w[2] * b
+
+
+def cv2_cvtcolor_rgb2gray(image, code=None):
+    """RESTATEMENT of cv2.cvtColor(img, cv2.COLOR_RGB2GRAY) for uint8 (OpenCV is un-vendored and absent here): fixed point
+    with 14 fractional bits, (4899 R + 9617 G + 1868 B + 8192) >> 14. Parity unpinned at this call site."""
+    a = image.astype(np.uint32)
+    return ((a[..., 0] * 4899 + a[..., 1] * 9617 + a[..., 2] * 1868 + 8192) >> 14).astype(np.uint8)
+
+
+def gen_colour(sp_sd):
+    """G6: 3-channel uint8 input (what `core/images.py:75` hands to `match()`) through the reference's own code paths:
+    LightGlue flavour = `_frame2tensor` + `SuperPoint.extract` (`matchers.py:1212-1220`, `lightglue/superpoint.py:217-231`,
+    `lightglue/utils.py:35-36`), SuperGlue flavour = `SuperGlueMatcher._match_images` (`matchers.py:911-917`). The two
+    un-vendored colour conversions are the restatements above, installed into the stub modules."""
+    from PIL import Image
+    from icepy4d.thirdparty.LightGlue.lightglue import superpoint as r_sp
+    from icepy4d.thirdparty.SuperGlue.models import superpoint as r_sgsp
+    from icepy4d.matching import matchers as r_m
+    sys.modules["kornia"].color.rgb_to_grayscale = kornia_rgb_to_grayscale
+    sys.modules["cv2"].cvtColor = cv2_cvtcolor_rgb2gray
+    sys.modules["cv2"].COLOR_RGB2GRAY = 7
+    rgb = np.asarray(Image.open("/root/reference/assets/img/cam1/IMG_2637.jpg").convert("RGB"))
+    rgb = np.ascontiguousarray(rgb[300:500, 400:704])                       # 200 x 304 x 3 crop of a real colour image
+    lgm = r_m.LightGlueMatcher.__new__(r_m.LightGlueMatcher)               # only its _frame2tensor is needed
+    x = r_m.LightGlueMatcher._frame2tensor(lgm, rgb, "cpu")
+    ext = r_sp.SuperPoint(max_num_keypoints=300).eval()
+    ext.load_state_dict(sp_sd)
+    sg_net = r_sgsp.SuperPoint({"nms_radius": 3, "keypoint_threshold": 0.001, "max_keypoints": 300}).eval()
+    sg_net.load_state_dict(sp_sd)
+    with torch.inference_mode():
+        out = ext.extract(x, resize=None)
+        gray_u8 = sys.modules["cv2"].cvtColor(rgb, 7)                       # `matchers.py:911-912`
+        t = torch.from_numpy(gray_u8 / 255.0).float()[None, None]          # base `_frame2tensor` (`matchers.py:263-274`)
+        sg_out = sg_net({"image": t})
+    print(f"  colour: LG kpts {out['keypoints'].shape[1]}, SG kpts {sg_out['keypoints'][0].shape[0]}")
+    save("g6_colour", rgb=rgb, lg_keypoints=out["keypoints"][0], lg_scores=out["keypoint_scores"][0],
+         lg_descriptors=out["descriptors"][0], lg_gray=kornia_rgb_to_grayscale(x[None])[0, 0],
+         sg_gray_u8=gray_u8, sg_keypoints=sg_out["keypoints"][0], sg_scores=sg_out["scores"][0],
+         sg_descriptors=sg_out["descriptors"][0])
+
+
+def gen_prune_threshold():
+    """g2_lightglue_6: the reference's `desc.shape[-2] > pruning_th` gate (`lightglue.py:495, 503`). On a CPU tensor the
+    reference looks up `pruning_keypoint_thresholds['cpu']` = -1; its CUDA values are 1024 / 1536. The table entry is set to
+    280 here so that the gate is exercised at fixture size (image 0: 300 points, pruned until <= 280 are left; image 1: 257
+    points, never pruned) by the reference's own control flow."""
+    from icepy4d.thirdparty.LightGlue.lightglue import lightglue as r_lg
+    variant, m, n = "prune", 300, 257
+    sd = synthetic.lightglue_state_dict(0, variant)
+    net = r_lg.LightGlue(features="superpoint", depth_confidence=-1).eval()
+    net.load_state_dict(sd)
+    net.pruning_keypoint_thresholds = dict(net.pruning_keypoint_thresholds, cpu=280)
+    f = synthetic.synthetic_features(4, m, n)
+    data = {"image0": {"keypoints": torch.from_numpy(f["kpts0"])[None], "descriptors": torch.from_numpy(f["desc0"])[None],
+                       "image_size": torch.from_numpy(f["size0"])[None]},
+            "image1": {"keypoints": torch.from_numpy(f["kpts1"])[None], "descriptors": torch.from_numpy(f["desc1"])[None],
+                       "image_size": torch.from_numpy(f["size1"])[None]}}
+    with torch.inference_mode():
+        out = net(data)
+    print(f"  LG prune-threshold case: matches={int((out['matches0'] > -1).sum())} prune0 max {int(out['prune0'].max())} "
+          f"prune1 max {int(out['prune1'].max())}")
+    save("g2_lightglue_6", variant=variant, m=m, n=n, depth_confidence=-1, width_confidence=0.99, seed=4, pruning_min_kpts=280,
+         matches0=out["matches0"][0], matches1=out["matches1"][0], matching_scores0=out["matching_scores0"][0],
+         matching_scores1=out["matching_scores1"][0], stop=out["stop"], prune0=out["prune0"][0], prune1=out["prune1"][0])
+
+
 def main():
     logging.disable(logging.CRITICAL)
     install_stubs()
     sys.path.insert(0, REF_SRC)
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == "colour":
+        gen_colour(synthetic.superpoint_state_dict(0))
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "prune_threshold":
+        gen_prune_threshold()
+        return
     from icepy4d.thirdparty.LightGlue.lightglue import superpoint as r_sp, lightglue as r_lg
     from icepy4d.thirdparty.SuperGlue.models import superpoint as r_sgsp, superglue as r_sg
 
@@ -274,6 +352,8 @@ def main():
         f1 = ext.extract(torch.tensor(g1[None] / 255.0, dtype=torch.float), resize=None)
         o = mt({"image0": f0, "image1": f1})
     print(f"  assets: kpts {f0['keypoints'].shape[1]}/{f1['keypoints'].shape[1]} stop={o['stop']} matches={int((o['matches0'] > -1).sum())}")
+    gen_colour(sp_sd)
+    gen_prune_threshold()
     save("g5_assets", gray0=g0, gray1=g1, keypoints0=f0["keypoints"][0], keypoints1=f1["keypoints"][0],
          scores0=f0["keypoint_scores"][0], scores1=f1["keypoint_scores"][0],
          desc0_sha=sha(f0["descriptors"][0]), desc0_sample=f0["descriptors"][0][::16],
