@@ -195,8 +195,11 @@ def test_superpoint_flavours_select_the_same_candidates():
         nms = buf.view(2, 136, 200)[0].cpu()
         a_kp, a_sc = o.select_keypoints_lg(nms, 4, 0.001, 600)
         b_kp, b_sc = o.select_keypoints_sg(nms, 4, 0.001, 600)
-        assert {tuple(p) for p in a_kp.numpy()} == {tuple(p) for p in b_kp.numpy()}
-        assert {tuple(p) for p in a_kp.numpy()} == {tuple(p) for p in res[0][0]}
+        assert np.array_equal(np.sort(a_sc.numpy()), np.sort(b_sc.numpy())) and np.array_equal(np.sort(a_sc.numpy()), np.sort(res[0][2]))
+        if len(np.unique(a_sc.numpy())) == len(a_sc):     # no ties at the cut (the flat image is one big plateau of equal scores:
+            # which of its members make the top-k is torch.topk's unspecified tie order; the library takes the lowest indices)
+            assert {tuple(p) for p in a_kp.numpy()} == {tuple(p) for p in b_kp.numpy()}
+            assert {tuple(p) for p in a_kp.numpy()} == {tuple(p) for p in res[0][0]}
     e.close()
 
 
