@@ -9,6 +9,7 @@ typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define IM_WAVE 64
+#define IM_MAX_DEVICES 16
 
 // v_mfma_f32_32x32x2_f32: D[32x32] += A[32x2] * B[2x32], exact fp32 (k-ordered fmaf chain).
 // Lane l supplies A[i = l & 31][k = l >> 5] and B[k = l >> 5][j = l & 31].

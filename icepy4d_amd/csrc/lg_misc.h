@@ -42,6 +42,7 @@ hipError_t launch_lg_init(LGState* st, const int* n_in, int* ind, int* prune, lo
                           float* out_s, long out_bstride, hipStream_t s);
 hipError_t launch_lg_select_layer(LGState* st, int n_layers, int* sel, int* info, hipStream_t s);
 hipError_t launch_assign(const AssignArgs& a, hipStream_t s);
+hipError_t launch_zero_words(void* p, long nwords, hipStream_t s);   // use instead of hipMemsetAsync inside forwards (see lg_misc.hip)
 hipError_t launch_pack_record(const int* n, const int* matches0, const float* mscores0, const int* info, int epoch, int K,
                               int* rec, hipStream_t s);
 hipError_t launch_logsig(const float* z, long bstride, const LGState* st, int n_max, float* lz, hipStream_t s);

@@ -452,9 +452,23 @@ __global__ __launch_bounds__(256) void filter_scatter_kernel(const int* __restri
     }
 }
 
+// Zero-fill by a kernel, not hipMemsetAsync: a memset NODE inside a captured HIP graph (ROCm 7.2) faulted when that graph
+// was replayed after other graphs had been captured on the same buffers (reproduced with three whole-pair graphs of
+// different image shapes, `tools/dbg`); kernel nodes do not have the problem.
+__global__ void zero_words_kernel(unsigned* __restrict__ p, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = 0u;
+}
+
+hipError_t launch_zero_words(void* p, long nwords, hipStream_t s) {
+    if (nwords <= 0) return hipSuccess;
+    const long nb = (nwords + 255) / 256;
+    hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)(nb > 1024 ? 1024 : nb)), dim3(256), 0, s, reinterpret_cast<unsigned*>(p), nwords);
+    return hipGetLastError();
+}
+
 hipError_t launch_assign(const AssignArgs& a, hipStream_t s) {
     const int kr = a.m_max, kc = a.n_max;
-    hipError_t e = hipMemsetAsync(a.cbest, 0, sizeof(unsigned long long) * kc, s);
+    hipError_t e = launch_zero_words(a.cbest, 2L * kc, s);
     if (e != hipSuccess) return e;
     const int nstrips = (kr + COL_STRIP - 1) / COL_STRIP;
     if (a.mode == 0) {

@@ -301,9 +301,10 @@ int im_ctx_reserve(im_ctx* ctx, int max_h, int max_w, int max_images, int max_kp
     A(ws->rest, (size_t)B * H8 * W8);
     A(ws->mask, (size_t)B * H8 * W8);
     A(ws->supp, (size_t)B * H8 * W8);
-    A(ws->counts, (size_t)B * ((H8 * W8 + 1023) / 1024 + 1));
-    A(ws->n_cand, (size_t)B);
-    A(ws->keys, (size_t)B * H8 * W8);
+    A(ws->kpsel.n_cand, (sel_state_bytes((int)B) + 3) / 4);
+    A(ws->kpsel.keys, (size_t)B * H8 * W8);
+    A(ws->kpsel.ties, (size_t)B * H8 * W8);
+    A(ws->kpsel.chosen, (size_t)B * K);
     for (int i = 0; i < 2; ++i) {
         A(ws->x[i], (size_t)2 * K * 256);
         A(ws->cs[i], (size_t)2 * K * 32);
@@ -392,9 +393,8 @@ int im_superpoint_forward(im_ctx* ctx, const uint8_t* d_img, int n_images, int h
         IM_LAUNCH(ctx, "det_softmax", s, launch_det_softmax(ws->logits, 65, ws->smap, B, hc, wc, s));
     }
     const int H8 = hc * 8, W8 = wc * 8;
-    IM_LAUNCH(ctx, "nms", s, launch_nms(ws->smap, ws->nms, ws->mask, ws->supp, ws->rest, B, H8, W8, nms_radius, s));
-    IM_LAUNCH(ctx, "select_topk", s, launch_select_topk(ws->nms, B, H8, W8, border, threshold, max_kpts, K, ws->counts, ws->n_cand,
-                                                      ws->keys, d_kpts, d_scores, d_n, s));
+    IM_LAUNCH(ctx, "nms_select", s, launch_nms_select(ws->smap, ws->nms, ws->mask, ws->supp, ws->rest, B, H8, W8, nms_radius, border,
+                                                    threshold, max_kpts, K, ws->kpsel, d_kpts, d_scores, d_n, s));
     {
         ConvArgs a;
         a.in = feat; a.bias = W.cb[8]; a.out = tmp; a.B = B; a.H = hc; a.W = wc; a.Cin = 128; a.Cout = 256;
@@ -411,7 +411,7 @@ int im_superpoint_forward(im_ctx* ctx, const uint8_t* d_img, int n_images, int h
 int im_superpoint_candidates(im_ctx* ctx, int n_images, int32_t* h_counts, void* stream) {
     IM_CHECK_CTX(ctx);
     if (!ctx->ws || !h_counts || n_images < 1 || n_images > ctx->max_images) return ctx->fail(-41, "im_superpoint_candidates: bad arguments");
-    IM_HIP(ctx, hipMemcpyAsync(h_counts, ctx->ws->n_cand, sizeof(int32_t) * n_images, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    IM_HIP(ctx, hipMemcpyAsync(h_counts, ctx->ws->kpsel.n_cand, sizeof(int32_t) * n_images, hipMemcpyDeviceToHost, (hipStream_t)stream));
     IM_HIP(ctx, hipStreamSynchronize((hipStream_t)stream));
     return 0;
 }
@@ -599,8 +599,8 @@ int im_select_topk(im_ctx* ctx, const float* d_nms, int n_images, int h, int w, 
     Workspace* ws = ctx->ws;
     if (!ws || (long)n_images * h * w > (long)ctx->max_images * ((ctx->max_h / 8) * 8) * ((ctx->max_w / 8) * 8))
         return ctx->fail(-41, "im_select_topk: exceeds the reserved workspace");
-    IM_HIP(ctx, launch_select_topk(d_nms, n_images, h, w, border, threshold, max_kpts, ctx->max_kpts, ws->counts, ws->n_cand,
-                                   ws->keys, d_kpts, d_scores, d_n, (hipStream_t)stream));
+    IM_HIP(ctx, launch_select_topk(d_nms, n_images, h, w, border, threshold, max_kpts, ctx->max_kpts, ws->kpsel, d_kpts, d_scores, d_n,
+                                   (hipStream_t)stream));
     return 0;
 }
 

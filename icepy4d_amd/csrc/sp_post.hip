@@ -1,9 +1,12 @@
 // SuperPoint post-processing: detector softmax + depth-to-space, simple_nms, border/threshold/top-k
 // selection, descriptor sampling. All HBM-bound integer / compare work: coalesced loads, LDS tiles for the
 // stencils, wavefront reductions; no matrix cores.
+#include <cstdlib>
+
 #include "common.h"
 #include "kernels.h"
 #include "sp_post.h"
+#include "lg_misc.h"
 
 namespace im {
 
@@ -36,9 +39,10 @@ hipError_t launch_det_softmax(const float* logits, int ld, float* smap, int B, i
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// simple_nms (`lightglue/superpoint.py:50-65`): five (2r+1)^2 max-pools (stride 1, -inf padding) chained with
-// exact fp32 equality tests. Each stage is one launch; the pooled quantity of a 32 x 64 tile plus halo r is
-// staged in LDS and reduced separably (row max, then column max).
+// simple_nms (`lightglue/superpoint.py:50-65`), staged form: five (2r+1)^2 max-pools (stride 1, -inf padding) chained with
+// exact fp32 equality tests, one launch per stage; the pooled quantity of a 32 x 64 tile plus halo r is staged in LDS and
+// reduced separably. Only used for radius 5..8 and map widths that are not a multiple of 4; the forward pass with the
+// reference's radii (3, 4) runs nms_fused_kernel below.
 static constexpr int NT_H = 32, NT_W = 64, NMS_RMAX = 8;
 
 template <typename LoadF>
@@ -112,8 +116,8 @@ __global__ __launch_bounds__(256) void nms_stage_kernel(const float* __restrict_
     }
 }
 
-hipError_t launch_nms(const float* s, float* out, uint8_t* mask, uint8_t* supp, float* rest, int B, int H, int W, int r,
-                      hipStream_t st) {
+static hipError_t launch_nms_staged(const float* s, float* out, uint8_t* mask, uint8_t* supp, float* rest, int B, int H, int W, int r,
+                                    hipStream_t st) {
     if (r < 0 || r > NMS_RMAX) return hipErrorInvalidValue;
     dim3 grid((W + NT_W - 1) / NT_W, (H + NT_H - 1) / NT_H, B), block(256);
     hipLaunchKernelGGL((nms_stage_kernel<0, false>), grid, block, 0, st, s, mask, supp, rest, out, H, W, r);
@@ -125,102 +129,400 @@ hipError_t launch_nms(const float* s, float* out, uint8_t* mask, uint8_t* supp, 
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// keypoint selection (`lightglue/superpoint.py:177-200`; SuperGlue flavour `models/superpoint.py:176-203`):
-// candidates = pixels outside the border frame with score > threshold, in row-major order (torch.where /
-// nonzero order). If there are more than k, keep the k largest, sorted descending. Key = score bits in the
-// high word, ~flat-index in the low word: unique, and ties resolve to the lower flat index (torch.topk's tie
-// order is unspecified).
-static constexpr int SEL_CHUNK = 1024;
+// simple_nms in ONE launch (`lightglue/superpoint.py:50-65`): the score tile plus a 20-pixel halo sits in LDS and all
+// three rounds run there; the map is read from HBM once (halo overlap served by L2) and written once. Exact: only
+// max and == on fp32 values, no arithmetic.
+//   keep0 = (S == pool(S))                          needed on tile + 4r   (pool = (2r+1)^2 max, -inf padding)
+//   near1 = dilate_r(keep0)   rest1 = near1 ? 0 : S  needed on tile + 3r
+//   keep1 = keep0 | (rest1 == pool(rest1) & ~near1)  needed on tile + 2r
+//   near2 = dilate_r(keep1)   rest2 = near2 ? 0 : S  needed on tile + r      (near2 contains near1, so S is zeroed in place)
+//   keep2 = keep1 | (rest2 == pool(rest2) & ~near2)  on the tile             -> out = keep2 ? S : 0
+// S therefore needs a halo of 5r <= 20 pixels (r <= 4). Geometry is fixed for every r: 32 x 56 output tile, region 72 x 96
+// = three 32-bit mask words per row. Pools are separable sliding maxima computed in registers (a thread takes 16 outputs
+// of a column, then 32 outputs of a row: ~0.2 LDS instructions per pixel and pass instead of 2 (2r+1)); keep / near are
+// BIT masks, their dilation is shifts and ORs on 96-bit rows.
+// Epilogue (optional): the tile's keypoint candidates (score > threshold, outside the border frame; `superpoint.py:177-187`)
+// are appended to the image's key list (one global atomic per block; order does not matter: the selection stage ranks) and
+// counted into the first radix histogram of the top-k selection.
+namespace nf {
+constexpr int TH = 32, TW = 56, HALO = 20, RH = TH + 2 * HALO, RW = TW + 2 * HALO, PAD = 4, PITCH = 108, NW = 3;
+constexpr int LDS_FLOATS = 2 * RH * PITCH + 2 * RH * 4;   // S, T (scratch: vertical maxima / dilation rows / candidate staging), keep, near
+static_assert(RW == 32 * NW, "three mask words per row");
+}  // namespace nf
 
-__device__ __forceinline__ bool is_cand(float v, long idx, int H, int W, int border, float thr) {
-    const int y = (int)(idx / W), x = (int)(idx - (long)y * W);
-    return (v > thr) && y >= border && y < H - border && x >= border && x < W - border;
+struct SelState {            // per image, zeroed by launch_* before every use
+    unsigned hist[4][256];   // radix histograms of the score bits, 8 bits per pass, most significant first
+    int n_sel, n_eq, pad0, pad1;
+};
+
+// sliding maximum of width 2R+1 over v[0 .. N + 2R): out[i] = max(v[i .. i + 2R]), in place into v[0 .. N)
+template <int R, int N>
+__device__ __forceinline__ void sliding_max(float (&v)[N + 8]) {
+    constexpr int Wd = 2 * R + 1;
+    constexpr int P = Wd >= 8 ? 8 : (Wd >= 4 ? 4 : 2);
+    constexpr int L = N + 2 * R;   // valid inputs
+    // doubling, in place (ascending i reads only entries not yet overwritten): after the step of width d, v[i] = max(v[i .. i + d))
+#pragma unroll
+    for (int i = 0; i < L - 1; ++i) v[i] = fmaxf(v[i], v[i + 1]);                           // width 2
+    if constexpr (P >= 4) {
+#pragma unroll
+        for (int i = 0; i < L - 3; ++i) v[i] = fmaxf(v[i], v[i + 2]);                       // width 4
+    }
+    if constexpr (P >= 8) {
+#pragma unroll
+        for (int i = 0; i < L - 7; ++i) v[i] = fmaxf(v[i], v[i + 4]);                       // width 8
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = fmaxf(v[i], v[i + Wd - P]);                          // width 2R+1 = two overlapping width-P windows
 }
 
-__global__ __launch_bounds__(256) void kp_count_kernel(const float* __restrict__ nms, int H, int W, int border, float thr,
-                                                        int* __restrict__ counts, int nchunks) {
-    const int b = blockIdx.y;
-    const long npix = (long)H * W;
-    const float* s = nms + (long)b * npix;
-    const long base = (long)blockIdx.x * SEL_CHUNK + threadIdx.x * 4;
-    int cnt = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const long idx = base + j;
-        if (idx < npix && is_cand(s[idx], idx, H, W, border, thr)) ++cnt;
-    }
-    __shared__ int red[4];
-    cnt = wave_sum_i(cnt);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
-    __syncthreads();
-    if (threadIdx.x == 0) counts[(long)b * nchunks + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+__device__ __forceinline__ unsigned long long cand_key(float v, unsigned flat_idx) {
+    return ((unsigned long long)__float_as_uint(v) << 32) | (unsigned long long)(0xFFFFFFFFu - flat_idx);
 }
 
-// exclusive scan of the chunk counts of one image (single block), total -> n_cand[b]
-__global__ __launch_bounds__(1024) void kp_scan_kernel(int* __restrict__ counts, int nchunks, int* __restrict__ n_cand) {
-    const int b = blockIdx.x;
-    int* c = counts + (long)b * nchunks;
-    __shared__ int part[1024];
-    const int per = (nchunks + 1023) / 1024;
-    const int lo = threadIdx.x * per, hi = min(lo + per, nchunks);
-    int sum = 0;
-    for (int i = lo; i < hi; ++i) sum += c[i];
-    part[threadIdx.x] = sum;
-    __syncthreads();
-    // Hillis-Steele inclusive scan over 1024 partials
-    for (int off = 1; off < 1024; off <<= 1) {
-        int v = (threadIdx.x >= off) ? part[threadIdx.x - off] : 0;
-        __syncthreads();
-        part[threadIdx.x] += v;
-        __syncthreads();
-    }
-    int run = part[threadIdx.x] - sum;  // exclusive prefix of this thread's range
-    for (int i = lo; i < hi; ++i) {
-        const int v = c[i];
-        c[i] = run;
-        run += v;
-    }
-    if (threadIdx.x == 1023) n_cand[b] = part[1023];
-}
+template <int R>
+__global__ __launch_bounds__(256, 2) void nms_fused_kernel(const float* __restrict__ s, float* __restrict__ out, int H, int W, int tiles_x,
+                                                            int tiles_per_img, int border, float thr,
+                                                            unsigned long long* __restrict__ keys, long key_stride,
+                                                            int* __restrict__ n_cand, SelState* __restrict__ sel) {
+    using namespace nf;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* S = lds;
+    float* T = lds + RH * PITCH;
+    unsigned* keepm = reinterpret_cast<unsigned*>(lds + 2 * RH * PITCH);   // [RH][4]
+    unsigned* nearm = keepm + RH * 4;                                        // [RH][4]
+    unsigned* hdil = reinterpret_cast<unsigned*>(T);                         // [RH][4], alive only while T is not
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x / tiles_per_img;
+    const int trem = blockIdx.x - b * tiles_per_img;
+    const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
+    const long img = (long)b * H * W;
+    const float NINF = -INFINITY;
 
-__global__ __launch_bounds__(256) void kp_scatter_kernel(const float* __restrict__ nms, int H, int W, int border, float thr,
-                                                          const int* __restrict__ offsets, int nchunks,
-                                                          unsigned long long* __restrict__ keys, long key_stride) {
-    const int b = blockIdx.y;
-    const long npix = (long)H * W;
-    const float* s = nms + (long)b * npix;
-    const long base = (long)blockIdx.x * SEL_CHUNK + threadIdx.x * 4;
-    float v[4];
-    bool f[4];
-    int cnt = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const long idx = base + j;
-        v[j] = idx < npix ? s[idx] : 0.f;
-        f[j] = idx < npix && is_cand(v[j], idx, H, W, border, thr);
-        cnt += f[j];
+    // ---- load the region (-inf outside the image: max_pool2d's implicit padding), clear the masks
+    for (int idx = tid; idx < RH * (RW / 4); idx += 256) {
+        const int ry = idx / (RW / 4), q = idx - ry * (RW / 4);
+        const int gy = y0 - HALO + ry, gx = x0 - HALO + 4 * q;
+        float4 v = make_float4(NINF, NINF, NINF, NINF);
+        if (gy >= 0 && gy < H && gx >= 0 && gx + 3 < W) v = *reinterpret_cast<const float4*>(s + img + (long)gy * W + gx);
+        *reinterpret_cast<float4*>(S + ry * PITCH + PAD + 4 * q) = v;
     }
-    // block exclusive scan of cnt (row-major order = thread order)
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    int inc = cnt;
+    for (int idx = tid; idx < RH * 8; idx += 256) keepm[idx] = 0u;           // keep and near
+    // in-image column mask of each word, row validity is tested per task
+    unsigned colmask[NW];
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        int t = __shfl_up(inc, off);
-        if (lane >= off) inc += t;
+    for (int w = 0; w < NW; ++w) {
+        const int g0 = x0 - HALO + 32 * w;                                    // global x of bit 0
+        unsigned m = 0xFFFFFFFFu;
+        if (g0 < 0) m &= (g0 <= -32) ? 0u : (0xFFFFFFFFu << (-g0));
+        if (g0 + 32 > W) m &= (g0 >= W) ? 0u : (0xFFFFFFFFu >> (g0 + 32 - W));
+        colmask[w] = m;
     }
-    __shared__ int wtot[4];
-    if (lane == 63) wtot[wv] = inc;
     __syncthreads();
-    int pos = offsets[(long)b * nchunks + blockIdx.x] + inc - cnt;
-    for (int i = 0; i < wv; ++i) pos += wtot[i];
-    unsigned long long* kd = keys + (long)b * key_stride;
+
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-        if (f[j]) {
-            const unsigned long long key = ((unsigned long long)__float_as_uint(v[j]) << 32) |
-                                           (unsigned long long)(0xFFFFFFFFu - (unsigned)(base + j));
-            kd[pos++] = key;
+    for (int st = 0; st < 3; ++st) {
+        const int inset = HALO - (2 - st) * 2 * R;       // keep_st is needed on rows / columns [inset, R? - inset)
+        if (st > 0) {
+            // ---- near = dilate_r(keep) on [inset - R, ..): horizontal on 96-bit rows, then vertical OR
+            const int r_lo = inset - 2 * R, r_hi = RH - inset + 2 * R;       // rows of keep_{st-1}
+            if (tid >= r_lo && tid < r_hi) {
+                const unsigned k0 = keepm[tid * 4], k1 = keepm[tid * 4 + 1], k2 = keepm[tid * 4 + 2];
+                unsigned d0 = k0, d1 = k1, d2 = k2;                       // 96-bit row k2:k1:k0, bit x = column x
+#pragma unroll
+                for (int i = 1; i <= R; ++i) {
+                    d0 |= (k0 << i) | (k0 >> i) | (k1 << (32 - i));
+                    d1 |= (k1 << i) | (k0 >> (32 - i)) | (k1 >> i) | (k2 << (32 - i));
+                    d2 |= (k2 << i) | (k1 >> (32 - i)) | (k2 >> i);
+                }
+                hdil[tid * 4] = d0; hdil[tid * 4 + 1] = d1; hdil[tid * 4 + 2] = d2;
+            }
+            __syncthreads();
+            const int n_lo = inset - R, n_rows = RH - 2 * (inset - R);
+            if (tid < n_rows * NW) {
+                const int w = tid / n_rows, ry = n_lo + tid - w * n_rows;
+                unsigned m = 0;
+#pragma unroll
+                for (int dy = -R; dy <= R; ++dy) m |= hdil[(ry + dy) * 4 + w];
+                nearm[ry * 4 + w] = m;
+                // rest = near ? 0 : S, in place (in-image pixels only: the padding stays -inf)
+                const int gy = y0 - HALO + ry;
+                const unsigned z = (gy >= 0 && gy < H) ? (m & colmask[w]) : 0u;
+                if (z) {
+                    float4* row = reinterpret_cast<float4*>(S + ry * PITCH + PAD + 32 * w);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const unsigned nib = (z >> (4 * q)) & 15u;
+                        if (nib) {
+                            float4 v = row[q];
+                            if (nib & 1u) v.x = 0.f;
+                            if (nib & 2u) v.y = 0.f;
+                            if (nib & 4u) v.z = 0.f;
+                            if (nib & 8u) v.w = 0.f;
+                            row[q] = v;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
         }
+        // ---- vertical pass: T[ry][rx] = max_{|dy| <= R} S[ry + dy][rx], rows [inset, RH - inset), columns [inset - R, RW - inset + R)
+        {
+            const int c_lo = inset - R, ncol = RW - 2 * (inset - R);
+            const int r_lo = inset, nrow = RH - 2 * inset;
+            const int nseg = (nrow + 15) / 16;
+            for (int t = tid; t < ncol * nseg; t += 256) {
+                const int seg = t / ncol, rx = c_lo + t - seg * ncol;
+                const int ry0 = r_lo + 16 * seg;
+                float v[16 + 8];
+#pragma unroll
+                for (int i = 0; i < 16 + 2 * R; ++i) v[i] = S[min(ry0 - R + i, RH - 1) * PITCH + PAD + rx];
+#pragma unroll
+                for (int i = 16 + 2 * R; i < 24; ++i) v[i] = NINF;
+                sliding_max<R, 16>(v);
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (ry0 + i < r_lo + nrow) T[(ry0 + i) * PITCH + PAD + rx] = v[i];
+            }
+        }
+        __syncthreads();
+        // ---- horizontal pass + equality test: 32 outputs of one row per thread -> one mask word
+        {
+            const int r_lo = inset, nrow = RH - 2 * inset;
+            if (tid < nrow * NW) {
+                const int w = tid / nrow, ry = r_lo + tid - w * nrow;
+                const float4* tr = reinterpret_cast<const float4*>(T + ry * PITCH + PAD + 32 * w - 4);   // columns 32w-4 .. 32w+35
+                float v[32 + 8];
+#pragma unroll
+                for (int q = 0; q < 10; ++q) { const float4 t4 = tr[q]; v[4 * q] = t4.x; v[4 * q + 1] = t4.y; v[4 * q + 2] = t4.z; v[4 * q + 3] = t4.w; }
+                // window of output i starts at column 32w + i - R = v index i + 4 - R
+                if constexpr (R < 4) {
+#pragma unroll
+                    for (int i = 0; i < 32 + 2 * R; ++i) v[i] = v[i + 4 - R];
+                }
+                sliding_max<R, 32>(v);
+                const float4* cr = reinterpret_cast<const float4*>(S + ry * PITCH + PAD + 32 * w);
+                unsigned eq = 0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float4 c4 = cr[q];
+                    eq |= (c4.x == v[4 * q] ? 1u : 0u) << (4 * q);
+                    eq |= (c4.y == v[4 * q + 1] ? 1u : 0u) << (4 * q + 1);
+                    eq |= (c4.z == v[4 * q + 2] ? 1u : 0u) << (4 * q + 2);
+                    eq |= (c4.w == v[4 * q + 3] ? 1u : 0u) << (4 * q + 3);
+                }
+                // valid outputs: columns [inset, RW - inset) of this word, inside the image, not suppressed
+                const int lo = max(inset - 32 * w, 0), hi = min(RW - inset - 32 * w, 32);
+                unsigned vm = (hi > lo) ? ((hi - lo == 32 ? 0xFFFFFFFFu : ((1u << (hi - lo)) - 1u)) << lo) : 0u;
+                const int gy = y0 - HALO + ry;
+                vm = (gy >= 0 && gy < H) ? (vm & colmask[w]) : 0u;
+                if (st > 0) vm &= ~nearm[ry * 4 + w];
+                keepm[ry * 4 + w] |= eq & vm;
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: out = keep2 ? S : 0 on the tile (S re-read from global: the LDS copy has been zeroed around maxima)
+    int* cnt = reinterpret_cast<int*>(T);                                     // [0] candidates of this block, [1] global base
+    unsigned* lhist = reinterpret_cast<unsigned*>(T) + 4;                     // [256]
+    unsigned long long* stage = reinterpret_cast<unsigned long long*>(T + 512);
+    if (keys) {
+        for (int i = tid; i < 260; i += 256) reinterpret_cast<unsigned*>(T)[i] = 0u;
+        __syncthreads();
+    }
+    for (int t = tid; t < TH * (TW / 4); t += 256) {
+        const int ty = t / (TW / 4), q = t - ty * (TW / 4);
+        const int gy = y0 + ty, gx = x0 + 4 * q;
+        if (gy >= H || gx >= W) continue;
+        const int ry = HALO + ty, rx = HALO + 4 * q;
+        const unsigned bits = (keepm[ry * 4 + (rx >> 5)] >> (rx & 31)) & 15u;
+        const float4 sv = *reinterpret_cast<const float4*>(s + img + (long)gy * W + gx);
+        const float4 o = make_float4((bits & 1u) ? sv.x : 0.f, (bits & 2u) ? sv.y : 0.f, (bits & 4u) ? sv.z : 0.f, (bits & 8u) ? sv.w : 0.f);
+        if (out) *reinterpret_cast<float4*>(out + img + (long)gy * W + gx) = o;
+        if (keys && bits && gy >= border && gy < H - border) {
+            const float ov[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int x = gx + j;
+                if (ov[j] > thr && x >= border && x < W - border) {
+                    const int p = atomicAdd(&cnt[0], 1);
+                    stage[p] = cand_key(ov[j], (unsigned)(gy * W + x));
+                    atomicAdd(&lhist[__float_as_uint(ov[j]) >> 24], 1u);
+                }
+            }
+        }
+    }
+    if (keys) {
+        __syncthreads();
+        const int n = cnt[0];
+        if (n > 0) {
+            if (tid == 0) cnt[1] = atomicAdd(&n_cand[b], n);
+            if (lhist[tid]) atomicAdd(&sel[b].hist[0][tid], lhist[tid]);
+            __syncthreads();
+            unsigned long long* kd = keys + (long)b * key_stride + cnt[1];
+            for (int i = tid; i < n; i += 256) kd[i] = stage[i];
+        }
+    }
+}
+
+// candidates of an existing NMS map (stage entry point im_select_topk; also the path for radius > 4)
+__global__ __launch_bounds__(256) void kp_extract_kernel(const float* __restrict__ nms, int H, int W, int border, float thr,
+                                                          unsigned long long* __restrict__ keys, long key_stride,
+                                                          int* __restrict__ n_cand, SelState* __restrict__ sel) {
+    __shared__ int cnt[2];
+    __shared__ unsigned lhist[256];
+    __shared__ unsigned long long stage[1024];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const long npix = (long)H * W;
+    const float* s = nms + (long)b * npix;
+    if (tid < 2) cnt[tid] = 0;
+    lhist[tid] = 0u;
+    __syncthreads();
+    const long base = (long)blockIdx.x * 1024 + tid * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const long idx = base + j;
+        if (idx >= npix) break;
+        const float v = s[idx];
+        const int y = (int)(idx / W), x = (int)(idx - (long)y * W);
+        if (v > thr && y >= border && y < H - border && x >= border && x < W - border) {
+            const int p = atomicAdd(&cnt[0], 1);
+            stage[p] = cand_key(v, (unsigned)idx);
+            atomicAdd(&lhist[__float_as_uint(v) >> 24], 1u);
+        }
+    }
+    __syncthreads();
+    const int n = cnt[0];
+    if (n == 0) return;
+    if (tid == 0) cnt[1] = atomicAdd(&n_cand[b], n);
+    if (lhist[tid]) atomicAdd(&sel[b].hist[0][tid], lhist[tid]);
+    __syncthreads();
+    unsigned long long* kd = keys + (long)b * key_stride + cnt[1];
+    for (int i = tid; i < n; i += 256) kd[i] = stage[i];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// top-k selection (`top_k_keypoints`, `lightglue/superpoint.py:68-72`; SuperGlue flavour `models/superpoint.py:196-203`)
+// over the UNORDERED candidate keys of an image. Key = score bits (positive floats order like unsigned integers) in the
+// high word, ~flat pixel index in the low word: unique; among equal scores the lower index wins (torch.topk's order among
+// ties is unspecified).
+//   n <= k : every candidate, in row-major order (torch.where / nonzero order): ranked by pixel index
+//   n >  k : multi-block radix select of the k-th largest score (4 passes of 8 bits; pass 0 is counted where the candidates
+//            are produced), then the keys above the cut are collected and ranked by counting (rank = number of larger keys).
+//            Only if the k-th score is shared by more candidates than fit, those equal ones are ranked by index among
+//            themselves and the first ones fill the remaining slots.
+// Every kernel finds the cut again from the histograms (one wave, 256 bins per pass): no host round trip, no extra launch.
+struct Cut { unsigned prefix; int remaining; int in_bin; };
+
+// all 64 lanes of one wave; digits of passes 0 .. passes-1 -> prefix (score bits fixed so far), how many keys of the cut
+// bin are still wanted, how many keys that bin holds
+__device__ __forceinline__ Cut find_cut(const SelState* __restrict__ st, int k, int passes) {
+    const int lane = threadIdx.x & 63;
+    Cut c{0u, k, 0};
+    for (int p = 0; p < passes; ++p) {
+        const uint4 h = *reinterpret_cast<const uint4*>(&st->hist[p][lane * 4]);
+        const int sum = (int)(h.x + h.y + h.z + h.w);
+        int inc = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(inc, off);
+            if (lane >= off) inc += t;
+        }
+        const int total = __shfl(inc, 63);
+        const int above = total - inc;                                    // keys in bins of higher lanes
+        const bool mine = above < c.remaining && c.remaining <= above + sum;
+        const unsigned long long bal = __ballot(mine);
+        const int src = bal ? (int)__builtin_ctzll(bal) : 0;              // (remaining <= total always holds when n > k)
+        int digit = 0, rem = c.remaining, inb = 0;
+        if (mine) {
+            const unsigned hb[4] = {h.x, h.y, h.z, h.w};
+            int cum = above;
+#pragma unroll
+            for (int j = 3; j >= 0; --j) {
+                if (inb == 0 && cum + (int)hb[j] >= c.remaining && hb[j] > 0) { digit = lane * 4 + j; rem = c.remaining - cum; inb = (int)hb[j]; }
+                if (inb == 0) cum += (int)hb[j];
+            }
+        }
+        digit = __shfl(digit, src); rem = __shfl(rem, src); inb = __shfl(inb, src);
+        c.prefix |= (unsigned)digit << (24 - 8 * p);
+        c.remaining = rem;
+        c.in_bin = inb;
+    }
+    return c;
+}
+
+static constexpr int SEL_BLOCKS = 64;     // blocks per image in the histogram / collect / tie kernels (grid-stride over the keys)
+
+__global__ __launch_bounds__(256) void sel_hist_kernel(const unsigned long long* __restrict__ keys, long key_stride,
+                                                        const int* __restrict__ n_cand, SelState* __restrict__ sel, int k_req, int kmax,
+                                                        int pass) {
+    __shared__ unsigned lhist[256];
+    __shared__ unsigned sh_prefix;
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int n = n_cand[b];
+    const int k = (k_req > 0 && k_req < kmax) ? k_req : kmax;
+    if (n <= k) return;
+    lhist[tid] = 0u;
+    if (tid < 64) {
+        const Cut c = find_cut(&sel[b], k, pass);
+        if (tid == 0) sh_prefix = c.prefix;
+    }
+    __syncthreads();
+    const int shift = 24 - 8 * pass;
+    const unsigned want = sh_prefix >> (shift + 8);
+    const unsigned long long* kd = keys + (long)b * key_stride;
+    for (int i = blockIdx.x * 256 + tid; i < n; i += gridDim.x * 256) {
+        const unsigned sc = (unsigned)(kd[i] >> 32);
+        if ((sc >> (shift + 8)) == want) atomicAdd(&lhist[(sc >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (lhist[tid]) atomicAdd(&sel[b].hist[pass][tid], lhist[tid]);
+}
+
+// keys above the cut -> selected list; keys AT the cut score go there too when all of them fit, else to the tie list
+__global__ __launch_bounds__(256) void sel_collect_kernel(const unsigned long long* __restrict__ keys, long key_stride,
+                                                           const int* __restrict__ n_cand, SelState* __restrict__ sel, int k_req, int kmax,
+                                                           unsigned long long* __restrict__ chosen, long chosen_stride,
+                                                           unsigned long long* __restrict__ ties, long ties_stride) {
+    __shared__ Cut sh_cut;
+    __shared__ int cnt[4];
+    __shared__ unsigned long long st_sel[1024], st_eq[1024];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int n = n_cand[b];
+    const int k = (k_req > 0 && k_req < kmax) ? k_req : kmax;
+    if (n <= k) return;
+    if (tid < 64) {
+        const Cut c = find_cut(&sel[b], k, 4);
+        if (tid == 0) sh_cut = c;
+    }
+    const unsigned long long* kd = keys + (long)b * key_stride;
+    // chunks of 1024 keys so that the LDS staging lists cannot overflow
+    for (int base = blockIdx.x * 1024; base < n; base += gridDim.x * 1024) {
+        __syncthreads();
+        if (tid < 4) cnt[tid] = 0;
+        __syncthreads();
+        const unsigned cut = sh_cut.prefix;
+        const bool all_equal_fit = sh_cut.remaining == sh_cut.in_bin;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = base + j * 256 + tid;
+            if (i < n) {
+                const unsigned long long key = kd[i];
+                const unsigned sc = (unsigned)(key >> 32);
+                if (sc > cut || (sc == cut && all_equal_fit)) st_sel[atomicAdd(&cnt[0], 1)] = key;
+                else if (sc == cut) st_eq[atomicAdd(&cnt[1], 1)] = key;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            cnt[2] = cnt[0] ? atomicAdd(&sel[b].n_sel, cnt[0]) : 0;
+            cnt[3] = cnt[1] ? atomicAdd(&sel[b].n_eq, cnt[1]) : 0;
+        }
+        __syncthreads();
+        for (int i = tid; i < cnt[0]; i += 256) chosen[(long)b * chosen_stride + cnt[2] + i] = st_sel[i];
+        for (int i = tid; i < cnt[1]; i += 256) ties[(long)b * ties_stride + cnt[3] + i] = st_eq[i];
+    }
 }
 
 __device__ __forceinline__ void emit_kp(unsigned long long key, int W, float* kp, float* sc) {
@@ -231,105 +533,181 @@ __device__ __forceinline__ void emit_kp(unsigned long long key, int W, float* kp
     *sc = __uint_as_float((unsigned)(key >> 32));
 }
 
-// one block per image: n <= k -> row-major copy; else radix-select the k-th largest key (8 passes of 8 bits),
-// collect the k keys >= it into LDS, bitonic-sort them descending, emit.
-__global__ __launch_bounds__(1024) void kp_topk_kernel(const unsigned long long* __restrict__ keys, long key_stride,
-                                                        const int* __restrict__ n_cand, int k_req, int kmax, int W,
-                                                        float* __restrict__ kpts, float* __restrict__ scores,
-                                                        int* __restrict__ n_out, int pow2) {
-    extern __shared__ __attribute__((aligned(16))) unsigned long long sk[];  // [pow2]
-    __shared__ int hist[256];
-    __shared__ int sh_digit, sh_remaining, sh_count;
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const unsigned long long* kd = keys + (long)b * key_stride;
-    float* kp = kpts + (long)b * kmax * 2;
-    float* sc = scores + (long)b * kmax;
-    const int n = n_cand[b];
-    const int k = (k_req > 0 && k_req < kmax) ? k_req : kmax;
-    if (n <= k) {
-        for (int i = tid; i < n; i += 1024) emit_kp(kd[i], W, kp + 2 * i, sc + i);
-        if (tid == 0) n_out[b] = n;
-        return;
-    }
-    unsigned long long prefix = 0;
-    int remaining = k;
-    for (int pass = 7; pass >= 0; --pass) {
-        const int shift = pass * 8;
-        for (int i = tid; i < 256; i += 1024) hist[i] = 0;
+// rank of `mine` among src[0 .. m): number of keys larger under `mask` (tiles of 1024 keys through LDS, broadcast reads)
+__device__ __forceinline__ int rank_among(const unsigned long long* __restrict__ src, int m, unsigned long long mine,
+                                          unsigned long long mask, unsigned long long* tile) {
+    int rank = 0;
+    const unsigned long long me = mine & mask;
+    for (int base = 0; base < m; base += 1024) {
         __syncthreads();
-        for (int i = tid; i < n; i += 1024) {
-            const unsigned long long key = kd[i];
-            const bool match = (pass == 7) || ((key >> (shift + 8)) == (prefix >> (shift + 8)));
-            if (match) atomicAdd(&hist[(int)((key >> shift) & 255ull)], 1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = base + j * 256 + threadIdx.x;
+            tile[j * 256 + threadIdx.x] = i < m ? (src[i] & mask) : 0ull;      // 0 is smaller than every real key
         }
         __syncthreads();
-        if (tid == 0) {
-            int cum = 0, d = 255;
-            for (; d > 0; --d) {
-                if (cum + hist[d] >= remaining) break;
-                cum += hist[d];
-            }
-            sh_digit = d;
-            sh_remaining = remaining - cum;
-        }
-        __syncthreads();
-        prefix |= (unsigned long long)sh_digit << shift;
-        remaining = sh_remaining;
-        const int in_bin = hist[sh_digit];
-        __syncthreads();
-        // all 32 score bits are fixed after pass 4; if every key with exactly that score is wanted there is no tie at
-        // the cut, the index passes cannot change anything and the threshold key is (score, lowest possible index word)
-        if (pass == 4 && remaining == in_bin) break;
-    }
-    // prefix is now the k-th largest key; keys are unique so exactly k keys are >= prefix
-    if (tid == 0) sh_count = 0;
-    for (int i = tid; i < pow2; i += 1024) sk[i] = 0ull;
-    __syncthreads();
-    for (int i = tid; i < n; i += 1024) {
-        const unsigned long long key = kd[i];
-        if (key >= prefix) {
-            const int p = atomicAdd(&sh_count, 1);
-            if (p < pow2) sk[p] = key;
+        const int lim = min(1024, m - base);
+        const ulonglong2* t2 = reinterpret_cast<const ulonglong2*>(tile);
+        for (int i = 0; i < (lim + 1) / 2; ++i) {
+            const ulonglong2 kk = t2[i];
+            rank += (kk.x > me) + (kk.y > me);
         }
     }
-    __syncthreads();
-    for (int size = 2; size <= pow2; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int i = tid; i < (pow2 >> 1); i += 1024) {
-                const int pos = 2 * i - (i & (stride - 1));
-                const unsigned long long x = sk[pos], y = sk[pos + stride];
-                const bool first_half = (pos & size) == 0;  // descending overall
-                if ((x < y) == first_half) { sk[pos] = y; sk[pos + stride] = x; }
-            }
-            __syncthreads();
-        }
-    }
-    for (int i = tid; i < k; i += 1024) emit_kp(sk[i], W, kp + 2 * i, sc + i);
-    if (tid == 0) n_out[b] = k;
+    return rank;
 }
 
-hipError_t launch_select_topk(const float* nms, int B, int H, int W, int border, float thr, int k_req, int kmax,
-                              int* counts, int* n_cand, unsigned long long* keys, float* kpts, float* scores,
-                              int* n_out, hipStream_t st) {
-    const long npix = (long)H * W;
-    const int nchunks = (int)((npix + SEL_CHUNK - 1) / SEL_CHUNK);
-    hipLaunchKernelGGL(kp_count_kernel, dim3(nchunks, B), dim3(256), 0, st, nms, H, W, border, thr, counts, nchunks);
-    hipLaunchKernelGGL(kp_scan_kernel, dim3(B), dim3(1024), 0, st, counts, nchunks, n_cand);
-    hipLaunchKernelGGL(kp_scatter_kernel, dim3(nchunks, B), dim3(256), 0, st, nms, H, W, border, thr, counts, nchunks, keys, npix);
+// ties at the cut: the `remaining` equal-score keys with the lowest pixel index fill slots k - remaining .. k - 1
+__global__ __launch_bounds__(256) void sel_tie_kernel(const int* __restrict__ n_cand, const SelState* __restrict__ sel, int k_req, int kmax,
+                                                       const unsigned long long* __restrict__ ties, long ties_stride, int W,
+                                                       float* __restrict__ kpts, float* __restrict__ scores) {
+    __shared__ __attribute__((aligned(16))) unsigned long long tile[1024];
+    __shared__ Cut sh_cut;
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int n = n_cand[b];
     const int k = (k_req > 0 && k_req < kmax) ? k_req : kmax;
-    int pow2 = 2;
-    while (pow2 < k) pow2 <<= 1;
-    const size_t lds = (size_t)pow2 * sizeof(unsigned long long);
-    if (lds > 150 * 1024) return hipErrorInvalidValue;
-    static size_t attr_lds = 0;
-    if (lds > attr_lds) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&kp_topk_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_lds = lds;
+    if (n <= k) return;
+    if (tid < 64) {
+        const Cut c = find_cut(&sel[b], k, 4);
+        if (tid == 0) sh_cut = c;
     }
-    hipLaunchKernelGGL(kp_topk_kernel, dim3(B), dim3(1024), lds, st, keys, npix, n_cand, k_req, kmax, W, kpts, scores, n_out, pow2);
+    __syncthreads();
+    const int r = sh_cut.remaining, m = sh_cut.in_bin;
+    if (r == m) return;                                           // every key of the cut score was taken by sel_collect
+    const unsigned long long* src = ties + (long)b * ties_stride;
+    for (int base = blockIdx.x * 256; base < m; base += gridDim.x * 256) {   // block-uniform trip count (rank_among synchronises)
+        const int i = base + tid;
+        const unsigned long long mine = i < m ? src[i] : 0ull;
+        const int rank = rank_among(src, m, mine, ~0ull, tile);
+        if (i < m && rank < r) {
+            const int pos = k - r + rank;
+            emit_kp(mine, W, kpts + ((long)b * kmax + pos) * 2, scores + (long)b * kmax + pos);
+        }
+    }
+}
+
+// final order: n <= k -> all candidates by ascending pixel index; else the selected keys by descending key
+__global__ __launch_bounds__(256) void sel_rank_kernel(const unsigned long long* __restrict__ keys, long key_stride,
+                                                        const int* __restrict__ n_cand, const SelState* __restrict__ sel, int k_req, int kmax,
+                                                        const unsigned long long* __restrict__ chosen, long chosen_stride, int W,
+                                                        float* __restrict__ kpts, float* __restrict__ scores, int* __restrict__ n_out) {
+    __shared__ __attribute__((aligned(16))) unsigned long long tile[1024];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int n = n_cand[b];
+    const int k = (k_req > 0 && k_req < kmax) ? k_req : kmax;
+    const bool all = n <= k;
+    const unsigned long long* src = all ? keys + (long)b * key_stride : chosen + (long)b * chosen_stride;
+    const int m = all ? n : sel[b].n_sel;
+    const unsigned long long mask = all ? 0xFFFFFFFFull : ~0ull;   // low word = ~index: larger = earlier in row-major order
+    if (blockIdx.x == 0 && tid == 0) n_out[b] = all ? n : k;
+    if (blockIdx.x * 256 >= m) return;
+    const int i = blockIdx.x * 256 + tid;
+    const unsigned long long mine = i < m ? src[i] : 0ull;
+    const int rank = rank_among(src, m, mine, mask, tile);
+    if (i < m) emit_kp(mine, W, kpts + ((long)b * kmax + rank) * 2, scores + (long)b * kmax + rank);
+}
+
+// per-device opt-in for more than 64 KB of dynamic LDS (a process may hold contexts on several GPUs)
+hipError_t ensure_dyn_lds(const void* fn, size_t bytes, size_t* cache) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= IM_MAX_DEVICES) return hipErrorInvalidDevice;
+    if (bytes > cache[dev]) {
+        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return e;
+        cache[dev] = bytes;
+    }
+    return hipSuccess;
+}
+
+size_t sel_state_bytes(int B) { return (size_t)B * sizeof(int) + 16 + (size_t)B * sizeof(SelState); }
+
+static hipError_t sel_reset(const SelBuffers& sb, int B, hipStream_t st) {   // a kernel, not a memset node (see lg_misc.hip)
+    return launch_zero_words(sb.n_cand, (long)(sel_state_bytes(B) / 4), st);
+}
+
+static SelState* sel_states(int* n_cand, int B) {
+    return reinterpret_cast<SelState*>(reinterpret_cast<char*>(n_cand) + (((size_t)B * sizeof(int) + 15) & ~(size_t)15));
+}
+
+template <int R>
+static hipError_t launch_nms_fused_r(const float* s, float* out, int B, int H, int W, int border, float thr, unsigned long long* keys,
+                                     long key_stride, int* n_cand, hipStream_t st) {
+    static size_t cache[IM_MAX_DEVICES] = {0};
+    const size_t lds = nf::LDS_FLOATS * sizeof(float);
+    hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(&nms_fused_kernel<R>), lds, cache);
+    if (e != hipSuccess) return e;
+    const int tx = (W + nf::TW - 1) / nf::TW, ty = (H + nf::TH - 1) / nf::TH;
+    hipLaunchKernelGGL(nms_fused_kernel<R>, dim3(tx * ty * B), dim3(256), lds, st, s, out, H, W, tx, tx * ty, border, thr, keys, key_stride,
+                       n_cand, keys ? sel_states(n_cand, B) : nullptr);
     return hipGetLastError();
+}
+
+static bool nms_fusable(int H, int W, int r) {
+    static const bool staged = getenv("IM_NMS_STAGED") && getenv("IM_NMS_STAGED")[0] == '1';   // A/B switch: the five-launch form
+    return !staged && r >= 1 && r <= 4 && (W % 4) == 0;
+}
+
+static hipError_t launch_nms_fused(const float* s, float* out, int B, int H, int W, int r, int border, float thr, unsigned long long* keys,
+                                   long key_stride, int* n_cand, hipStream_t st) {
+    switch (r) {
+        case 1: return launch_nms_fused_r<1>(s, out, B, H, W, border, thr, keys, key_stride, n_cand, st);
+        case 2: return launch_nms_fused_r<2>(s, out, B, H, W, border, thr, keys, key_stride, n_cand, st);
+        case 3: return launch_nms_fused_r<3>(s, out, B, H, W, border, thr, keys, key_stride, n_cand, st);
+        default: return launch_nms_fused_r<4>(s, out, B, H, W, border, thr, keys, key_stride, n_cand, st);
+    }
+}
+
+hipError_t launch_nms(const float* s, float* out, uint8_t* mask, uint8_t* supp, float* rest, int B, int H, int W, int r,
+                      hipStream_t st) {
+    if (r < 0 || r > NMS_RMAX) return hipErrorInvalidValue;
+    if (nms_fusable(H, W, r)) return launch_nms_fused(s, out, B, H, W, r, 0, 0.f, nullptr, 0, nullptr, st);
+    return launch_nms_staged(s, out, mask, supp, rest, B, H, W, r, st);
+}
+
+// radix passes 1..3, collect, ties, rank on the candidate keys (pass 0 was counted by the producer of the keys)
+static hipError_t launch_select(int B, int H, int W, int k_req, int kmax, const SelBuffers& sb, float* kpts, float* scores, int* n_out,
+                                hipStream_t st) {
+    const long npix = (long)H * W;
+    SelState* ss = sel_states(sb.n_cand, B);
+    for (int pass = 1; pass < 4; ++pass)
+        hipLaunchKernelGGL(sel_hist_kernel, dim3(SEL_BLOCKS, B), dim3(256), 0, st, sb.keys, npix, sb.n_cand, ss, k_req, kmax, pass);
+    hipLaunchKernelGGL(sel_collect_kernel, dim3(SEL_BLOCKS, B), dim3(256), 0, st, sb.keys, npix, sb.n_cand, ss, k_req, kmax, sb.chosen,
+                       (long)kmax, sb.ties, npix);
+    hipLaunchKernelGGL(sel_tie_kernel, dim3(SEL_BLOCKS, B), dim3(256), 0, st, sb.n_cand, ss, k_req, kmax, sb.ties, npix, W, kpts, scores);
+    hipLaunchKernelGGL(sel_rank_kernel, dim3((kmax + 255) / 256, B), dim3(256), 0, st, sb.keys, npix, sb.n_cand, ss, k_req, kmax, sb.chosen,
+                       (long)kmax, W, kpts, scores, n_out);
+    return hipGetLastError();
+}
+
+// the forward pass: score map -> NMS map (+ candidates) -> keypoints, 7 launches
+hipError_t launch_nms_select(const float* s, float* nms_out, uint8_t* mask, uint8_t* supp, float* rest, int B, int H, int W, int r,
+                             int border, float thr, int k_req, int kmax, const SelBuffers& sb, float* kpts, float* scores, int* n_out,
+                             hipStream_t st) {
+    if (r < 0 || r > NMS_RMAX) return hipErrorInvalidValue;
+    hipError_t e = sel_reset(sb, B, st);
+    if (e != hipSuccess) return e;
+    const long npix = (long)H * W;
+    if (nms_fusable(H, W, r)) {
+        e = launch_nms_fused(s, nms_out, B, H, W, r, border, thr, sb.keys, npix, sb.n_cand, st);
+        if (e != hipSuccess) return e;
+    } else {
+        e = launch_nms_staged(s, nms_out, mask, supp, rest, B, H, W, r, st);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kp_extract_kernel, dim3((unsigned)((npix + 1023) / 1024), B), dim3(256), 0, st, nms_out, H, W, border, thr, sb.keys,
+                           npix, sb.n_cand, sel_states(sb.n_cand, B));
+    }
+    return launch_select(B, H, W, k_req, kmax, sb, kpts, scores, n_out, st);
+}
+
+hipError_t launch_select_topk(const float* nms, int B, int H, int W, int border, float thr, int k_req, int kmax, const SelBuffers& sb,
+                              float* kpts, float* scores, int* n_out, hipStream_t st) {
+    hipError_t e = sel_reset(sb, B, st);
+    if (e != hipSuccess) return e;
+    const long npix = (long)H * W;
+    hipLaunchKernelGGL(kp_extract_kernel, dim3((unsigned)((npix + 1023) / 1024), B), dim3(256), 0, st, nms, H, W, border, thr, sb.keys, npix,
+                       sb.n_cand, sel_states(sb.n_cand, B));
+    return launch_select(B, H, W, k_req, kmax, sb, kpts, scores, n_out, st);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -169,8 +169,8 @@ __global__ __launch_bounds__(256) void ot_materialize_kernel(const float* __rest
 static int sinkhorn(im_ctx* ctx, hipStream_t s, const float* sim, int ld, const int* m_ptr, const int* n_ptr, int m_max, int n_max,
                     float alpha, int iters, float* u, float* v, float* norm_out) {
     Workspace* ws = ctx->ws;
-    IM_HIP(ctx, hipMemsetAsync(u, 0, sizeof(float) * (m_max + 1), s));
-    IM_HIP(ctx, hipMemsetAsync(v, 0, sizeof(float) * (n_max + 1), s));
+    IM_HIP(ctx, launch_zero_words(u, m_max + 1, s));
+    IM_HIP(ctx, launch_zero_words(v, n_max + 1, s));
     const int nstrips = (m_max + SK_STRIP - 1) / SK_STRIP;
     const int pstride = n_max + 1;
     for (int it = 0; it < iters; ++it) {

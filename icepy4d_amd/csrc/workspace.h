@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "lg_misc.h"
+#include "sp_post.h"
 
 // device workspace of one context, sized by im_ctx_reserve
 struct Workspace {
@@ -16,7 +17,7 @@ struct Workspace {
     float* logits = nullptr; float* dense = nullptr;    // [cells][65], [cells][256]
     float* smap = nullptr; float* nms = nullptr; float* rest = nullptr;
     uint8_t* mask = nullptr; uint8_t* supp = nullptr;
-    int* counts = nullptr; int* n_cand = nullptr; unsigned long long* keys = nullptr;
+    im::SelBuffers kpsel;   // keypoint selection: candidate counters + radix state, candidate keys, tie list, chosen keys
     // LightGlue / SuperGlue
     float* x[2] = {nullptr, nullptr}; float* cs[2] = {nullptr, nullptr}; float* sn[2] = {nullptr, nullptr};
     int* ind[2] = {nullptr, nullptr};

@@ -763,3 +763,69 @@ def test_matchers_with_different_weights_do_not_share_a_context():
     n_graphs = len(A.engine.graphs)
     fa3 = A2._match_images(g["image0"], g["image1"], max_keypoints=256)      # fresh object, same weights: no new capture
     assert len(A.engine.graphs) == n_graphs and np.array_equal(fa[2], fa3[2])
+
+
+# ------------------------------------------------------------------------------------------- fused NMS / multi-block top-k
+@pytest.mark.parametrize("radius", [1, 2, 3, 4, 5])
+def test_nms_fused_kernel_random_maps(radius):
+    """The one-launch LDS-resident simple_nms (radius <= 4; 5 runs the staged fallback) against the oracle, bit-exact, on
+    maps whose sizes do not divide into its 32 x 56 tiles, with continuous values (no ties), coarsely quantised values (large
+    tie plateaus, including across tile borders) and a constant map."""
+    from icepy4d_amd.engine import Engine
+    from icepy4d_amd._lib import stream_ptr
+    o = oracle()
+    e = Engine(0)
+    e.reserve(272, 480, 3, 64)
+    for (h, w) in ((8, 8), (40, 56), (72, 96), (136, 200), (264, 472)):
+        rng = np.random.default_rng(h * 1000 + w + radius)
+        a = rng.uniform(0, 1, size=(h, w)).astype(np.float32)
+        b = (np.round(rng.uniform(0, 1, size=(h, w)) * 6) / 6).astype(np.float32)
+        c = np.full((h, w), 0.25, np.float32)
+        maps = torch.from_numpy(np.stack([a, b, c]))
+        ref = o.simple_nms(maps, radius)
+        d_in = maps.cuda()
+        d_out = torch.full_like(d_in, float("nan"))
+        e.ctx.call("im_nms", *ptrs(d_in, d_out), 3, h, w, radius, stream_ptr())
+        torch.cuda.synchronize()
+        got = d_out.cpu()
+        assert torch.equal(got, ref), (h, w, radius, int((got != ref).sum()))
+    e.close()
+
+
+@pytest.mark.parametrize("k", [1, 7, 100, 256, 1000, 4000])
+def test_select_topk_multiblock_with_ties_at_the_cut(k):
+    """Radix select + rank over unordered candidates: continuous scores (no ties), quantised scores (the k-th score is shared by
+    many candidates: the lowest pixel indices are taken, torch.topk's tie order being unspecified) and fewer candidates than
+    k (row-major order, no sort). Scores equal the oracle's exactly; keypoints equal as sets outside the tie group at the cut."""
+    from icepy4d_amd.engine import Engine
+    from icepy4d_amd._lib import stream_ptr
+    o = oracle()
+    h, w = 136, 200
+    e = Engine(0)
+    e.reserve(h, w, 2, 4096)
+    rng = np.random.default_rng(k)
+    cont = rng.uniform(0, 1, size=(h, w)).astype(np.float32) * (rng.uniform(size=(h, w)) < 0.15)
+    quant = (np.round(rng.uniform(0, 1, size=(h, w)) * 16) / 16).astype(np.float32) * (rng.uniform(size=(h, w)) < 0.15)
+    maps = torch.from_numpy(np.stack([cont, quant]).astype(np.float32)).contiguous()
+    e.ctx.call("im_select_topk", *ptrs(maps.cuda()), 2, h, w, 4, 0.0005, k, *ptrs(e.kpts, e.scores, e.n), stream_ptr())
+    torch.cuda.synchronize()
+    for b in range(2):
+        ref_kp, ref_sc = o.select_keypoints_lg(maps[b], 4, 0.0005, k)
+        n = int(e.n[b])
+        assert n == len(ref_sc)
+        kp, sc = e.kpts[b, :n].cpu().numpy(), e.scores[b, :n].cpu().numpy()
+        assert np.array_equal(sc, ref_sc.numpy())                                  # same score at every rank
+        assert len({tuple(p) for p in kp}) == n                                    # no keypoint twice
+        assert np.array_equal(maps[b].numpy()[kp[:, 1].astype(int), kp[:, 0].astype(int)], sc)   # each score is its pixel's
+        cut = sc[-1] if n else None
+        above = sc > cut if n else np.zeros(0, bool)
+        assert {tuple(p) for p in kp[above]} == {tuple(p) for p in ref_kp.numpy()[ref_sc.numpy() > cut]}
+        if n and b == 1:     # ties: inside a group of equal scores the order is ascending pixel index; at the cut the lowest indices win
+            flat = kp[:, 1] * w + kp[:, 0]
+            for v in np.unique(sc):
+                assert (np.diff(flat[sc == v]) > 0).all()
+            cand = np.argwhere((maps[b].numpy() == cut) & (np.arange(h)[:, None] >= 4) & (np.arange(h)[:, None] < h - 4)
+                               & (np.arange(w)[None, :] >= 4) & (np.arange(w)[None, :] < w - 4))
+            cand_flat = np.sort(cand[:, 0] * w + cand[:, 1])
+            assert np.array_equal(flat[sc == cut], cand_flat[:int((sc == cut).sum())])
+    e.close()
