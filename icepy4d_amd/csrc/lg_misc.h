@@ -17,7 +17,7 @@ struct AssignArgs {
     const int* m_ptr = nullptr; const int* n_ptr = nullptr; int m_max = 0, n_max = 0;
     const float* lz0 = nullptr; const float* lz1 = nullptr;   // logsigmoid(z)
     float* rmax = nullptr; float* rlog = nullptr; float* cmax = nullptr; float* clog = nullptr;
-    float2* part = nullptr;                                   // [ceil(m_max/128)][n_max]
+    float2* part = nullptr;                                   // [ceil(m_max/16)][n_max] strip partials (8 bytes per entry)
     int* ridx = nullptr; float* rval = nullptr; unsigned long long* cbest = nullptr;
     float threshold = 0.1f;
     int mode = 0;   // 0: LightGlue double log-softmax; 1: SuperGlue OT (rmax = u, cmax = v, rlog[0] = norm)

@@ -295,57 +295,155 @@ hipError_t launch_lg_select_layer(LGState* st, int n_layers, int* sel, int* info
 //   score(i, j) = ((x - rmax_i) - rlog_i) + ((x - cmax_j) - clog_j) + (lz0_i + lz1_j)
 // (same association as the reference: log_softmax rows + log_softmax columns, then + certainties).
 
-// wave per row: max, then sum exp(x - max) (torch's log_softmax order), plus lz = logsigmoid(z)
-__global__ __launch_bounds__(256) void row_lse_kernel(const float* __restrict__ sim, int ld, const int* __restrict__ m_ptr,
-                                                       const int* __restrict__ n_ptr, float* __restrict__ rmax,
-                                                       float* __restrict__ rlog) {
-    const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int m = *m_ptr, n = *n_ptr;
-    if (i >= m) return;
-    const float* p = sim + (long)i * ld;
-    float mx = -INFINITY;
-    for (int j = lane; j < n; j += 64) mx = fmaxf(mx, p[j]);
-    mx = wave_max(mx);
-    float s = 0.f;
-    for (int j = lane; j < n; j += 64) s += expf(p[j] - mx);
-    s = wave_sum(s);
-    if (lane == 0) { rmax[i] = mx; rlog[i] = logf(s); }
+// Two sweeps over sim, each reading it ONCE for both directions (16 rows per block, a wave owns 1024-column chunks, 16-byte
+// loads; rows reduce across the lanes of a wave, columns inside a lane over the block's rows):
+//   lse_stats  : row (max, log sum exp) complete per block; column (max, sum) partials per 16-row strip -> col_lse_combine
+//   best_sweep : with both normalisers known, row arg-max complete per block; column arg-max partials per strip -> col_best_combine
+static constexpr int AS_ROWS = 16;       // rows per block (= per strip of the column partials)
+static constexpr int AS_CHUNK = 1024;    // columns a wave takes per pass: 4 x (64 lanes x float4)
+static constexpr float AS_NEG = -3.0e38f;  // stands in for -inf on masked entries (finite: no inf - inf in the online merges)
+
+// 16 values of row `p` (chunk base c0): columns c0 + q * 256 + lane * 4 + e; entries >= n read as AS_NEG
+template <bool VEC>
+__device__ __forceinline__ void load_row16(const float* __restrict__ p, int c0, int lane, int n, float (&x)[16]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int j = c0 + q * 256 + lane * 4;
+        if constexpr (VEC) {
+            float4 v = make_float4(AS_NEG, AS_NEG, AS_NEG, AS_NEG);
+            if (j < n) v = *reinterpret_cast<const float4*>(p + j);      // ld % 4 == 0: the quad lies inside the row's storage
+            x[4 * q] = v.x; x[4 * q + 1] = (j + 1 < n) ? v.y : AS_NEG; x[4 * q + 2] = (j + 2 < n) ? v.z : AS_NEG; x[4 * q + 3] = (j + 3 < n) ? v.w : AS_NEG;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[4 * q + e] = (j + e < n) ? p[j + e] : AS_NEG;
+        }
+    }
 }
 
-static constexpr int COL_STRIP = 128;
+// exp of a non-positive difference to a running maximum: v_exp_f32 on x * log2(e) (2 instructions instead of expf's ~12; the
+// sweeps below evaluate 2.3 of them per matrix entry). Relative error <= 2^-22 for |x| < 16, growing with |x| * 2^-24.
+__device__ __forceinline__ float fexp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
 
-// thread per column, strip of COL_STRIP rows: online (max, sum)
-__global__ __launch_bounds__(256) void col_lse_partial_kernel(const float* __restrict__ sim, int ld, const int* __restrict__ m_ptr,
-                                                               const int* __restrict__ n_ptr, float2* __restrict__ part, int kmax) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
+template <bool VEC>
+__global__ __launch_bounds__(256) void lse_stats_kernel(const float* __restrict__ sim, int ld, const int* __restrict__ m_ptr,
+                                                         const int* __restrict__ n_ptr, float* __restrict__ rmax, float* __restrict__ rlog,
+                                                         float2* __restrict__ cpart, int kmax) {
+    __shared__ float2 rs[AS_ROWS][4];
     const int m = *m_ptr, n = *n_ptr;
-    const int i0 = blockIdx.y * COL_STRIP;
-    if (j >= n || i0 >= m) return;
-    const int i1 = min(i0 + COL_STRIP, m);
-    float mx = -INFINITY;
-    for (int i = i0; i < i1; ++i) mx = fmaxf(mx, sim[(long)i * ld + j]);
-    float s = 0.f;
-    for (int i = i0; i < i1; ++i) s += expf(sim[(long)i * ld + j] - mx);
-    part[(long)blockIdx.y * kmax + j] = make_float2(mx, s);
+    const int i0 = blockIdx.x * AS_ROWS;
+    if (i0 >= m || n <= 0) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nrow = min(AS_ROWS, m - i0);
+    float rM[AS_ROWS], rS[AS_ROWS];
+#pragma unroll
+    for (int r = 0; r < AS_ROWS; ++r) { rM[r] = AS_NEG; rS[r] = 0.f; }
+    for (int c0 = wave * AS_CHUNK; c0 < n; c0 += 4 * AS_CHUNK) {
+        float cM[16], cS[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { cM[e] = AS_NEG; cS[e] = 0.f; }
+#pragma unroll
+        for (int g = 0; g < AS_ROWS / 4; ++g) {
+            float x[4][16];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int r = 4 * g + rr;
+                if (r < nrow) load_row16<VEC>(sim + (long)(i0 + r) * ld, c0, lane, n, x[rr]);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) x[rr][e] = AS_NEG;
+                }
+            }
+            // rows: one online step per row with the lane's 16 entries
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int r = 4 * g + rr;
+                float mx = x[rr][0];
+#pragma unroll
+                for (int e = 1; e < 16; ++e) mx = fmaxf(mx, x[rr][e]);
+                const float nm = fmaxf(rM[r], mx);
+                float acc = 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc += fexp(x[rr][e] - nm);
+                rS[r] = rS[r] * fexp(rM[r] - nm) + acc;
+                rM[r] = nm;
+            }
+            // columns: one online step per column with these four rows
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float mx = fmaxf(fmaxf(x[0][e], x[1][e]), fmaxf(x[2][e], x[3][e]));
+                const float nm = fmaxf(cM[e], mx);
+                cS[e] = cS[e] * fexp(cM[e] - nm) + ((fexp(x[0][e] - nm) + fexp(x[1][e] - nm)) + (fexp(x[2][e] - nm) + fexp(x[3][e] - nm)));
+                cM[e] = nm;
+            }
+        }
+        float2* cp = cpart + (long)blockIdx.x * kmax;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int j = c0 + q * 256 + lane * 4 + e;
+                if (j < n) cp[j] = make_float2(cM[4 * q + e], cS[4 * q + e]);   // rows >= nrow contributed exp(AS_NEG - max) = 0
+            }
+    }
+#pragma unroll
+    for (int r = 0; r < AS_ROWS; ++r) {
+        const float M = wave_max(rM[r]);
+        const float S = wave_sum(rS[r] * fexp(rM[r] - M));
+        if (lane == 0) rs[r][wave] = make_float2(M, S);
+    }
+    __syncthreads();
+    if (tid < nrow) {
+        const float2 a = rs[tid][0], b = rs[tid][1], c = rs[tid][2], d = rs[tid][3];
+        const float M = fmaxf(fmaxf(a.x, b.x), fmaxf(c.x, d.x));
+        const float S = (a.y * fexp(a.x - M) + b.y * fexp(b.x - M)) + (c.y * fexp(c.x - M) + d.y * fexp(d.x - M));
+        rmax[i0 + tid] = M;
+        rlog[i0 + tid] = logf(S);
+    }
 }
 
-__global__ __launch_bounds__(256) void col_lse_combine_kernel(const float2* __restrict__ part, int kmax, const int* __restrict__ m_ptr,
+// column normalisers from the strip partials: 32 columns x 8 strip groups per block, loads issued eight at a time
+static constexpr int CC_COLS = 32, CC_GROUPS = 8;
+
+__global__ __launch_bounds__(256) void col_lse_combine_kernel(const float2* __restrict__ cpart, int kmax, const int* __restrict__ m_ptr,
                                                                const int* __restrict__ n_ptr, float* __restrict__ cmax,
                                                                float* __restrict__ clog) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
+    __shared__ float2 red[CC_GROUPS][CC_COLS];
     const int m = *m_ptr, n = *n_ptr;
-    if (j >= n) return;
-    const int ns = (m + COL_STRIP - 1) / COL_STRIP;
-    float mx = -INFINITY;
-    for (int s = 0; s < ns; ++s) mx = fmaxf(mx, part[(long)s * kmax + j].x);
-    float sum = 0.f;
-    for (int s = 0; s < ns; ++s) {
-        const float2 p = part[(long)s * kmax + j];
-        sum += p.y * expf(p.x - mx);
+    const int c = threadIdx.x & (CC_COLS - 1), g = threadIdx.x / CC_COLS;
+    const int j = blockIdx.x * CC_COLS + c;
+    if (blockIdx.x * CC_COLS >= n) return;
+    const int ns = (m + AS_ROWS - 1) / AS_ROWS;
+    float M = AS_NEG, S = 0.f;
+    if (j < n)
+        for (int s0 = g; s0 < ns; s0 += 8 * CC_GROUPS) {
+            float2 p[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int sidx = s0 + u * CC_GROUPS;
+                p[u] = sidx < ns ? cpart[(long)sidx * kmax + j] : make_float2(AS_NEG, 0.f);
+            }
+            float mx = p[0].x;
+#pragma unroll
+            for (int u = 1; u < 8; ++u) mx = fmaxf(mx, p[u].x);
+            const float nm = fmaxf(M, mx);
+            float acc = 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += p[u].y * fexp(p[u].x - nm);
+            S = S * fexp(M - nm) + acc;
+            M = nm;
+        }
+    red[g][c] = make_float2(M, S);
+    __syncthreads();
+    if (g == 0 && j < n) {
+        float Mx = red[0][c].x;
+#pragma unroll
+        for (int u = 1; u < CC_GROUPS; ++u) Mx = fmaxf(Mx, red[u][c].x);
+        float Sx = 0.f;
+#pragma unroll
+        for (int u = 0; u < CC_GROUPS; ++u) Sx += red[u][c].y * fexp(red[u][c].x - Mx);
+        cmax[j] = Mx;
+        clog[j] = logf(Sx);
     }
-    cmax[j] = mx;
-    clog[j] = logf(sum);
 }
 
 __global__ __launch_bounds__(256) void logsig_kernel(const float* __restrict__ z, long bstride, const LGState* __restrict__ st,
@@ -362,60 +460,140 @@ __device__ __forceinline__ float assign_score(float x, float rm, float rl, float
     else return ((x + rm) + cm) - rl;
 }
 
-// wave per row: argmax over columns, first index among ties (torch.max semantics)
-template <int MODE>
-__global__ __launch_bounds__(256) void row_argmax_kernel(const float* __restrict__ sim, int ld, const int* __restrict__ m_ptr,
+// One sweep: row arg-max (first column among ties: torch.max semantics) complete per block; per-strip column arg-max keys
+// (ordered score bits, ~row): a larger key = a larger score or, at equal score, a lower row.
+template <int MODE, bool VEC>
+__global__ __launch_bounds__(256) void best_sweep_kernel(const float* __restrict__ sim, int ld, const int* __restrict__ m_ptr,
                                                           const int* __restrict__ n_ptr, const float* __restrict__ rmax,
                                                           const float* __restrict__ rlog, const float* __restrict__ cmax,
                                                           const float* __restrict__ clog, const float* __restrict__ lz0,
-                                                          const float* __restrict__ lz1, int* __restrict__ ridx,
-                                                          float* __restrict__ rval) {
-    const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+                                                          const float* __restrict__ lz1, int* __restrict__ ridx, float* __restrict__ rval,
+                                                          unsigned long long* __restrict__ cbpart, int kmax) {
+    __shared__ float rb_v[AS_ROWS][4];
+    __shared__ int rb_j[AS_ROWS][4];
+    __shared__ float sh_rm[AS_ROWS], sh_rl[AS_ROWS], sh_l0[AS_ROWS];
     const int m = *m_ptr, n = *n_ptr;
-    if (i >= m) return;
-    const float* p = sim + (long)i * ld;
-    const float rm = rmax[i], rl = MODE == 0 ? rlog[i] : rlog[0], l0 = MODE == 0 ? lz0[i] : 0.f;
-    float best = -INFINITY;
-    int bj = 0x7fffffff;
-    for (int j = lane; j < n; j += 64) {
-        const float v = MODE == 0 ? assign_score<0>(p[j], rm, rl, cmax[j], clog[j], l0, lz1[j])
-                                  : assign_score<1>(p[j], rm, rl, cmax[j], 0.f, 0.f, 0.f);
-        if (v > best || (bj == 0x7fffffff)) { best = v; bj = j; }
+    const int i0 = blockIdx.x * AS_ROWS;
+    if (i0 >= m || n <= 0) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nrow = min(AS_ROWS, m - i0);
+    if (tid < AS_ROWS) {
+        const int i = min(i0 + tid, m - 1);
+        sh_rm[tid] = rmax[i];
+        sh_rl[tid] = MODE == 0 ? rlog[i] : rlog[0];
+        sh_l0[tid] = MODE == 0 ? lz0[i] : 0.f;
     }
+    __syncthreads();
+    float bv[AS_ROWS];
+    int bj[AS_ROWS];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const float ov = __shfl_xor(best, off);
-        const int oj = __shfl_xor(bj, off);
-        if (ov > best || (ov == best && oj < bj)) { best = ov; bj = oj; }
+    for (int r = 0; r < AS_ROWS; ++r) { bv[r] = -INFINITY; bj[r] = 0x7fffffff; }
+    for (int c0 = wave * AS_CHUNK; c0 < n; c0 += 4 * AS_CHUNK) {
+        float cm[16], cl[16], l1[16], cbv[16];
+        int cbi[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int j = min(c0 + q * 256 + lane * 4 + e, n - 1);
+                cm[4 * q + e] = cmax[j];
+                cl[4 * q + e] = MODE == 0 ? clog[j] : 0.f;
+                l1[4 * q + e] = MODE == 0 ? lz1[j] : 0.f;
+                cbv[4 * q + e] = -INFINITY;
+                cbi[4 * q + e] = -1;
+            }
+#pragma unroll
+        for (int g = 0; g < AS_ROWS / 4; ++g) {
+            if (4 * g >= nrow) break;     // block-uniform
+            float x[4][16];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)      // four rows = 16 sixteen-byte loads in flight per lane
+                load_row16<VEC>(sim + (long)min(i0 + 4 * g + rr, m - 1) * ld, c0, lane, n, x[rr]);
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int r = 4 * g + rr;
+                if (r >= nrow) break;     // block-uniform
+                const float rm = sh_rm[r], rl = sh_rl[r], l0 = sh_l0[r];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int j = c0 + q * 256 + lane * 4 + e;
+                        const int k = 4 * q + e;
+                        const float v = assign_score<MODE>(x[rr][k], rm, rl, cm[k], cl[k], l0, l1[k]);
+                        if (j < n) {
+                            if (v > bv[r] || bj[r] == 0x7fffffff) { bv[r] = v; bj[r] = j; }      // ascending j in a lane's visit order
+                            if (v > cbv[k] || cbi[k] < 0) { cbv[k] = v; cbi[k] = i0 + r; }
+                        }
+                    }
+            }
+        }
+        unsigned long long* cb = cbpart + (long)blockIdx.x * kmax;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int j = c0 + q * 256 + lane * 4 + e;
+                if (j < n) cb[j] = ((unsigned long long)f2ord(cbv[4 * q + e]) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)cbi[4 * q + e]);
+            }
     }
-    if (lane == 0) { ridx[i] = bj; rval[i] = best; }
+    // rows: lanes / chunks visit columns out of order, so ties resolve on the column index explicitly
+#pragma unroll
+    for (int r = 0; r < AS_ROWS; ++r) {
+        float v = bv[r];
+        int j = bj[r];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ov = __shfl_xor(v, off);
+            const int oj = __shfl_xor(j, off);
+            if (ov > v || (ov == v && oj < j)) { v = ov; j = oj; }
+        }
+        if (lane == 0) { rb_v[r][wave] = v; rb_j[r][wave] = j; }
+    }
+    __syncthreads();
+    if (tid < nrow) {
+        float v = rb_v[tid][0];
+        int j = rb_j[tid][0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const float ov = rb_v[tid][w];
+            const int oj = rb_j[tid][w];
+            if (ov > v || (ov == v && oj < j)) { v = ov; j = oj; }
+        }
+        ridx[i0 + tid] = j;
+        rval[i0 + tid] = v;
+    }
 }
 
-// thread per column, strip of rows: running best (strict > keeps the first row), merged with a 64-bit atomicMax
-// on (ordered score bits, ~row): max is order independent => deterministic
-template <int MODE>
-__global__ __launch_bounds__(256) void col_argmax_kernel(const float* __restrict__ sim, int ld, const int* __restrict__ m_ptr,
-                                                          const int* __restrict__ n_ptr, const float* __restrict__ rmax,
-                                                          const float* __restrict__ rlog, const float* __restrict__ cmax,
-                                                          const float* __restrict__ clog, const float* __restrict__ lz0,
-                                                          const float* __restrict__ lz1, unsigned long long* __restrict__ cbest) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(256) void col_best_combine_kernel(const unsigned long long* __restrict__ cbpart, int kmax,
+                                                                const int* __restrict__ m_ptr, const int* __restrict__ n_ptr,
+                                                                unsigned long long* __restrict__ cbest) {
+    __shared__ unsigned long long red[CC_GROUPS][CC_COLS];
     const int m = *m_ptr, n = *n_ptr;
-    const int i0 = blockIdx.y * COL_STRIP;
-    if (j >= n || i0 >= m) return;
-    const int i1 = min(i0 + COL_STRIP, m);
-    const float cm = cmax[j], cl = MODE == 0 ? clog[j] : 0.f, l1 = MODE == 0 ? lz1[j] : 0.f;
-    const float nrm = MODE == 0 ? 0.f : rlog[0];
-    float best = -INFINITY;
-    int bi = -1;
-    for (int i = i0; i < i1; ++i) {
-        const float v = MODE == 0 ? assign_score<0>(sim[(long)i * ld + j], rmax[i], rlog[i], cm, cl, lz0[i], l1)
-                                  : assign_score<1>(sim[(long)i * ld + j], rmax[i], nrm, cm, 0.f, 0.f, 0.f);
-        if (v > best || bi < 0) { best = v; bi = i; }
+    const int c = threadIdx.x & (CC_COLS - 1), g = threadIdx.x / CC_COLS;
+    const int j = blockIdx.x * CC_COLS + c;
+    if (blockIdx.x * CC_COLS >= n) return;
+    const int ns = (m + AS_ROWS - 1) / AS_ROWS;
+    unsigned long long best = 0ull;
+    if (j < n)
+        for (int s0 = g; s0 < ns; s0 += 8 * CC_GROUPS) {
+            unsigned long long k[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int sidx = s0 + u * CC_GROUPS;
+                k[u] = sidx < ns ? cbpart[(long)sidx * kmax + j] : 0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) best = k[u] > best ? k[u] : best;
+        }
+    red[g][c] = best;
+    __syncthreads();
+    if (g == 0 && j < n) {
+        unsigned long long bb = red[0][c];
+#pragma unroll
+        for (int u = 1; u < CC_GROUPS; ++u) bb = red[u][c] > bb ? red[u][c] : bb;
+        cbest[j] = bb;
     }
-    const unsigned long long key = ((unsigned long long)f2ord(best) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)bi);
-    atomicMax(cbest + j, key);
 }
 
 // mutual check + threshold (`filter_matches`), then scatter to the original index space (`lightglue.py:528-539`)
@@ -468,23 +646,24 @@ hipError_t launch_zero_words(void* p, long nwords, hipStream_t s) {
 
 hipError_t launch_assign(const AssignArgs& a, hipStream_t s) {
     const int kr = a.m_max, kc = a.n_max;
-    hipError_t e = launch_zero_words(a.cbest, 2L * kc, s);
-    if (e != hipSuccess) return e;
-    const int nstrips = (kr + COL_STRIP - 1) / COL_STRIP;
+    const int nstrips = (kr + AS_ROWS - 1) / AS_ROWS;
+    const bool vec = (a.ld % 4) == 0 && (reinterpret_cast<uintptr_t>(a.sim) % 16) == 0;
+    unsigned long long* cbpart = reinterpret_cast<unsigned long long*>(a.part);      // the strip partials of both sweeps share one buffer
     if (a.mode == 0) {
-        hipLaunchKernelGGL(row_lse_kernel, dim3((kr + 3) / 4), dim3(256), 0, s, a.sim, a.ld, a.m_ptr, a.n_ptr, a.rmax, a.rlog);
-        hipLaunchKernelGGL(col_lse_partial_kernel, dim3((kc + 255) / 256, nstrips), dim3(256), 0, s, a.sim, a.ld, a.m_ptr, a.n_ptr, a.part, kc);
-        hipLaunchKernelGGL(col_lse_combine_kernel, dim3((kc + 255) / 256), dim3(256), 0, s, a.part, kc, a.m_ptr, a.n_ptr, a.cmax, a.clog);
-        hipLaunchKernelGGL(row_argmax_kernel<0>, dim3((kr + 3) / 4), dim3(256), 0, s, a.sim, a.ld, a.m_ptr, a.n_ptr, a.rmax, a.rlog, a.cmax,
-                           a.clog, a.lz0, a.lz1, a.ridx, a.rval);
-        hipLaunchKernelGGL(col_argmax_kernel<0>, dim3((kc + 255) / 256, nstrips), dim3(256), 0, s, a.sim, a.ld, a.m_ptr, a.n_ptr, a.rmax, a.rlog,
-                           a.cmax, a.clog, a.lz0, a.lz1, a.cbest);
+        if (vec) hipLaunchKernelGGL(lse_stats_kernel<true>, dim3(nstrips), dim3(256), 0, s, a.sim, a.ld, a.m_ptr, a.n_ptr, a.rmax, a.rlog, a.part, kc);
+        else hipLaunchKernelGGL(lse_stats_kernel<false>, dim3(nstrips), dim3(256), 0, s, a.sim, a.ld, a.m_ptr, a.n_ptr, a.rmax, a.rlog, a.part, kc);
+        hipLaunchKernelGGL(col_lse_combine_kernel, dim3((kc + CC_COLS - 1) / CC_COLS), dim3(256), 0, s, a.part, kc, a.m_ptr, a.n_ptr, a.cmax, a.clog);
+        if (vec) hipLaunchKernelGGL((best_sweep_kernel<0, true>), dim3(nstrips), dim3(256), 0, s, a.sim, a.ld, a.m_ptr, a.n_ptr, a.rmax, a.rlog, a.cmax,
+                                    a.clog, a.lz0, a.lz1, a.ridx, a.rval, cbpart, kc);
+        else hipLaunchKernelGGL((best_sweep_kernel<0, false>), dim3(nstrips), dim3(256), 0, s, a.sim, a.ld, a.m_ptr, a.n_ptr, a.rmax, a.rlog, a.cmax,
+                                a.clog, a.lz0, a.lz1, a.ridx, a.rval, cbpart, kc);
     } else {  // optimal transport: rmax = u, cmax = v, rlog[0] = norm were produced by the Sinkhorn sweeps
-        hipLaunchKernelGGL(row_argmax_kernel<1>, dim3((kr + 3) / 4), dim3(256), 0, s, a.sim, a.ld, a.m_ptr, a.n_ptr, a.rmax, a.rlog, a.cmax,
-                           a.clog, a.lz0, a.lz1, a.ridx, a.rval);
-        hipLaunchKernelGGL(col_argmax_kernel<1>, dim3((kc + 255) / 256, nstrips), dim3(256), 0, s, a.sim, a.ld, a.m_ptr, a.n_ptr, a.rmax, a.rlog,
-                           a.cmax, a.clog, a.lz0, a.lz1, a.cbest);
+        if (vec) hipLaunchKernelGGL((best_sweep_kernel<1, true>), dim3(nstrips), dim3(256), 0, s, a.sim, a.ld, a.m_ptr, a.n_ptr, a.rmax, a.rlog, a.cmax,
+                                    a.clog, a.lz0, a.lz1, a.ridx, a.rval, cbpart, kc);
+        else hipLaunchKernelGGL((best_sweep_kernel<1, false>), dim3(nstrips), dim3(256), 0, s, a.sim, a.ld, a.m_ptr, a.n_ptr, a.rmax, a.rlog, a.cmax,
+                                a.clog, a.lz0, a.lz1, a.ridx, a.rval, cbpart, kc);
     }
+    hipLaunchKernelGGL(col_best_combine_kernel, dim3((kc + CC_COLS - 1) / CC_COLS), dim3(256), 0, s, cbpart, kc, a.m_ptr, a.n_ptr, a.cbest);
     const int kk = kr > kc ? kr : kc;
     hipLaunchKernelGGL(filter_scatter_kernel, dim3((kk + 255) / 256, 2), dim3(256), 0, s, a.m_ptr, a.n_ptr, a.ridx, a.rval, a.cbest,
                        a.threshold, a.ind0, a.ind1, a.out_m0, a.out_m1, a.out_s0, a.out_s1);

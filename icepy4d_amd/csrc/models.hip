@@ -323,7 +323,7 @@ int im_ctx_reserve(im_ctx* ctx, int max_h, int max_w, int max_images, int max_kp
     A(ws->sim, (size_t)(K + 1) * (K + 1));
     A(ws->sim2, (size_t)1);
     A(ws->rmax, (size_t)K + 1); A(ws->rlog, (size_t)K + 1); A(ws->cmax, (size_t)K + 1); A(ws->clog, (size_t)K + 1);
-    A(ws->part, (size_t)((K + 127) / 128 + 1) * (K + 1));
+    A(ws->part, (size_t)((K + 15) / 16 + 1) * (K + 4));
     A(ws->ridx, (size_t)K + 1); A(ws->rval, (size_t)K + 1); A(ws->cbest, (size_t)K + 1);
     A(ws->st, (size_t)1); A(ws->sel, (size_t)4);
     A(ws->uv, (size_t)4 * (K + 8));

@@ -146,6 +146,7 @@ static hipError_t launch_nms_staged(const float* s, float* out, uint8_t* mask, u
 // counted into the first radix histogram of the top-k selection.
 namespace nf {
 constexpr int TH = 32, TW = 56, HALO = 20, RH = TH + 2 * HALO, RW = TW + 2 * HALO, PAD = 4, PITCH = 108, NW = 3;
+constexpr int NT = 512;   // threads per block: two blocks per CU (LDS), so 16 waves to hide the load / barrier latency
 constexpr int LDS_FLOATS = 2 * RH * PITCH + 2 * RH * 4;   // S, T (scratch: vertical maxima / dilation rows / candidate staging), keep, near
 static_assert(RW == 32 * NW, "three mask words per row");
 }  // namespace nf
@@ -181,7 +182,7 @@ __device__ __forceinline__ unsigned long long cand_key(float v, unsigned flat_id
 }
 
 template <int R>
-__global__ __launch_bounds__(256, 2) void nms_fused_kernel(const float* __restrict__ s, float* __restrict__ out, int H, int W, int tiles_x,
+__global__ __launch_bounds__(nf::NT, 4) void nms_fused_kernel(const float* __restrict__ s, float* __restrict__ out, int H, int W, int tiles_x,
                                                             int tiles_per_img, int border, float thr,
                                                             unsigned long long* __restrict__ keys, long key_stride,
                                                             int* __restrict__ n_cand, SelState* __restrict__ sel) {
@@ -200,14 +201,21 @@ __global__ __launch_bounds__(256, 2) void nms_fused_kernel(const float* __restri
     const float NINF = -INFINITY;
 
     // ---- load the region (-inf outside the image: max_pool2d's implicit padding), clear the masks
-    for (int idx = tid; idx < RH * (RW / 4); idx += 256) {
+    for (int idx = tid; idx < RH * (RW / 4); idx += NT) {
         const int ry = idx / (RW / 4), q = idx - ry * (RW / 4);
         const int gy = y0 - HALO + ry, gx = x0 - HALO + 4 * q;
         float4 v = make_float4(NINF, NINF, NINF, NINF);
         if (gy >= 0 && gy < H && gx >= 0 && gx + 3 < W) v = *reinterpret_cast<const float4*>(s + img + (long)gy * W + gx);
         *reinterpret_cast<float4*>(S + ry * PITCH + PAD + 4 * q) = v;
     }
-    for (int idx = tid; idx < RH * 8; idx += 256) keepm[idx] = 0u;           // keep and near
+    for (int idx = tid; idx < RH * 8; idx += NT) keepm[idx] = 0u;           // keep and near
+    // the tile's own scores stay in registers for the epilogue (the LDS copy gets zeroed around maxima): one float4 per thread
+    static_assert(TH * (TW / 4) <= NT, "one output quad per thread");
+    const int e_ty = tid / (TW / 4), e_q = tid - e_ty * (TW / 4);
+    const int e_gy = y0 + e_ty, e_gx = x0 + 4 * e_q;
+    const bool e_on = tid < TH * (TW / 4) && e_gy < H && e_gx < W;
+    float4 e_sv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e_on) e_sv = *reinterpret_cast<const float4*>(s + img + (long)e_gy * W + e_gx);
     // in-image column mask of each word, row validity is tested per task
     unsigned colmask[NW];
 #pragma unroll
@@ -271,7 +279,7 @@ __global__ __launch_bounds__(256, 2) void nms_fused_kernel(const float* __restri
             const int c_lo = inset - R, ncol = RW - 2 * (inset - R);
             const int r_lo = inset, nrow = RH - 2 * inset;
             const int nseg = (nrow + 15) / 16;
-            for (int t = tid; t < ncol * nseg; t += 256) {
+            for (int t = tid; t < ncol * nseg; t += NT) {
                 const int seg = t / ncol, rx = c_lo + t - seg * ncol;
                 const int ry0 = r_lo + 16 * seg;
                 float v[16 + 8];
@@ -328,41 +336,39 @@ __global__ __launch_bounds__(256, 2) void nms_fused_kernel(const float* __restri
     unsigned* lhist = reinterpret_cast<unsigned*>(T) + 4;                     // [256]
     unsigned long long* stage = reinterpret_cast<unsigned long long*>(T + 512);
     if (keys) {
-        for (int i = tid; i < 260; i += 256) reinterpret_cast<unsigned*>(T)[i] = 0u;
+        for (int i = tid; i < 260; i += NT) reinterpret_cast<unsigned*>(T)[i] = 0u;
         __syncthreads();
     }
-    for (int t = tid; t < TH * (TW / 4); t += 256) {
-        const int ty = t / (TW / 4), q = t - ty * (TW / 4);
-        const int gy = y0 + ty, gx = x0 + 4 * q;
-        if (gy >= H || gx >= W) continue;
-        const int ry = HALO + ty, rx = HALO + 4 * q;
+    float4 e_o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e_on) {
+        const int ry = HALO + e_ty, rx = HALO + 4 * e_q;
         const unsigned bits = (keepm[ry * 4 + (rx >> 5)] >> (rx & 31)) & 15u;
-        const float4 sv = *reinterpret_cast<const float4*>(s + img + (long)gy * W + gx);
-        const float4 o = make_float4((bits & 1u) ? sv.x : 0.f, (bits & 2u) ? sv.y : 0.f, (bits & 4u) ? sv.z : 0.f, (bits & 8u) ? sv.w : 0.f);
-        if (out) *reinterpret_cast<float4*>(out + img + (long)gy * W + gx) = o;
-        if (keys && bits && gy >= border && gy < H - border) {
-            const float ov[4] = {o.x, o.y, o.z, o.w};
+        e_o = make_float4((bits & 1u) ? e_sv.x : 0.f, (bits & 2u) ? e_sv.y : 0.f, (bits & 4u) ? e_sv.z : 0.f, (bits & 8u) ? e_sv.w : 0.f);
+        if (keys && bits && e_gy >= border && e_gy < H - border) {
+            const float ov[4] = {e_o.x, e_o.y, e_o.z, e_o.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int x = gx + j;
+                const int x = e_gx + j;
                 if (ov[j] > thr && x >= border && x < W - border) {
                     const int p = atomicAdd(&cnt[0], 1);
-                    stage[p] = cand_key(ov[j], (unsigned)(gy * W + x));
+                    stage[p] = cand_key(ov[j], (unsigned)(e_gy * W + x));
                     atomicAdd(&lhist[__float_as_uint(ov[j]) >> 24], 1u);
                 }
             }
         }
     }
+    int n = 0;
     if (keys) {
         __syncthreads();
-        const int n = cnt[0];
-        if (n > 0) {
-            if (tid == 0) cnt[1] = atomicAdd(&n_cand[b], n);
-            if (lhist[tid]) atomicAdd(&sel[b].hist[0][tid], lhist[tid]);
-            __syncthreads();
-            unsigned long long* kd = keys + (long)b * key_stride + cnt[1];
-            for (int i = tid; i < n; i += 256) kd[i] = stage[i];
-        }
+        n = cnt[0];
+        if (n > 0 && tid == 0) cnt[1] = atomicAdd(&n_cand[b], n);       // its latency hides behind the map store below
+        if (n > 0 && tid < 256 && lhist[tid]) atomicAdd(&sel[b].hist[0][tid], lhist[tid]);
+    }
+    if (out && e_on) *reinterpret_cast<float4*>(out + img + (long)e_gy * W + e_gx) = e_o;
+    if (n > 0) {
+        __syncthreads();
+        unsigned long long* kd = keys + (long)b * key_stride + cnt[1];
+        for (int i = tid; i < n; i += NT) kd[i] = stage[i];
     }
 }
 
@@ -533,34 +539,50 @@ __device__ __forceinline__ void emit_kp(unsigned long long key, int W, float* kp
     *sc = __uint_as_float((unsigned)(key >> 32));
 }
 
-// rank of `mine` among src[0 .. m): number of keys larger under `mask` (tiles of 1024 keys through LDS, broadcast reads)
+// rank of `mine` among src[0 .. m): number of keys larger under `mask`. A block ranks RK_T = 64 keys (lane l of every wave holds
+// key l) and its RK_W waves each sweep their own slice of every 1024-key tile (LDS broadcast reads, two keys per read); the
+// partial ranks meet in LDS. The sweep is bound by the 64-bit compares (one wave needs ~12 ns per key), so k keys are spread
+// over k / 64 blocks x 8 waves.
+static constexpr int RK_T = 64, RK_W = 8, RK_N = RK_T * RK_W;
 __device__ __forceinline__ int rank_among(const unsigned long long* __restrict__ src, int m, unsigned long long mine,
-                                          unsigned long long mask, unsigned long long* tile) {
+                                          unsigned long long mask, unsigned long long* tile, int* part) {
     int rank = 0;
     const unsigned long long me = mine & mask;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int base = 0; base < m; base += 1024) {
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int i = base + j * 256 + threadIdx.x;
-            tile[j * 256 + threadIdx.x] = i < m ? (src[i] & mask) : 0ull;      // 0 is smaller than every real key
+        for (int j = 0; j < 1024 / RK_N; ++j) {
+            const int i = base + j * RK_N + threadIdx.x;
+            tile[j * RK_N + threadIdx.x] = i < m ? (src[i] & mask) : 0ull;      // 0 is smaller than every real key
         }
         __syncthreads();
-        const int lim = min(1024, m - base);
-        const ulonglong2* t2 = reinterpret_cast<const ulonglong2*>(tile);
-        for (int i = 0; i < (lim + 1) / 2; ++i) {
-            const ulonglong2 kk = t2[i];
-            rank += (kk.x > me) + (kk.y > me);
+        // the padding entries of a partial tile are 0 and never count: always sweep the whole slice, 8 reads in flight
+        const ulonglong2* t2 = reinterpret_cast<const ulonglong2*>(tile) + wave * (512 / RK_W);
+#pragma unroll 1
+        for (int i = 0; i < 512 / RK_W; i += 8) {
+            ulonglong2 kk[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) kk[u] = t2[i + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) rank += (kk[u].x > me) + (kk[u].y > me);
         }
     }
-    return rank;
+    __syncthreads();
+    part[wave * RK_T + lane] = rank;
+    __syncthreads();
+    int total = 0;
+#pragma unroll
+    for (int w = 0; w < RK_W; ++w) total += part[w * RK_T + lane];
+    return total;
 }
 
 // ties at the cut: the `remaining` equal-score keys with the lowest pixel index fill slots k - remaining .. k - 1
-__global__ __launch_bounds__(256) void sel_tie_kernel(const int* __restrict__ n_cand, const SelState* __restrict__ sel, int k_req, int kmax,
+__global__ __launch_bounds__(RK_N) void sel_tie_kernel(const int* __restrict__ n_cand, const SelState* __restrict__ sel, int k_req, int kmax,
                                                        const unsigned long long* __restrict__ ties, long ties_stride, int W,
                                                        float* __restrict__ kpts, float* __restrict__ scores) {
     __shared__ __attribute__((aligned(16))) unsigned long long tile[1024];
+    __shared__ int part[RK_N];
     __shared__ Cut sh_cut;
     const int b = blockIdx.y, tid = threadIdx.x;
     const int n = n_cand[b];
@@ -574,11 +596,11 @@ __global__ __launch_bounds__(256) void sel_tie_kernel(const int* __restrict__ n_
     const int r = sh_cut.remaining, m = sh_cut.in_bin;
     if (r == m) return;                                           // every key of the cut score was taken by sel_collect
     const unsigned long long* src = ties + (long)b * ties_stride;
-    for (int base = blockIdx.x * 256; base < m; base += gridDim.x * 256) {   // block-uniform trip count (rank_among synchronises)
-        const int i = base + tid;
+    for (int base = blockIdx.x * RK_T; base < m; base += gridDim.x * RK_T) {   // block-uniform trip count (rank_among synchronises)
+        const int i = base + (tid & 63);
         const unsigned long long mine = i < m ? src[i] : 0ull;
-        const int rank = rank_among(src, m, mine, ~0ull, tile);
-        if (i < m && rank < r) {
+        const int rank = rank_among(src, m, mine, ~0ull, tile, part);
+        if (tid < RK_T && i < m && rank < r) {
             const int pos = k - r + rank;
             emit_kp(mine, W, kpts + ((long)b * kmax + pos) * 2, scores + (long)b * kmax + pos);
         }
@@ -586,11 +608,12 @@ __global__ __launch_bounds__(256) void sel_tie_kernel(const int* __restrict__ n_
 }
 
 // final order: n <= k -> all candidates by ascending pixel index; else the selected keys by descending key
-__global__ __launch_bounds__(256) void sel_rank_kernel(const unsigned long long* __restrict__ keys, long key_stride,
+__global__ __launch_bounds__(RK_N) void sel_rank_kernel(const unsigned long long* __restrict__ keys, long key_stride,
                                                         const int* __restrict__ n_cand, const SelState* __restrict__ sel, int k_req, int kmax,
                                                         const unsigned long long* __restrict__ chosen, long chosen_stride, int W,
                                                         float* __restrict__ kpts, float* __restrict__ scores, int* __restrict__ n_out) {
     __shared__ __attribute__((aligned(16))) unsigned long long tile[1024];
+    __shared__ int part[RK_N];
     const int b = blockIdx.y, tid = threadIdx.x;
     const int n = n_cand[b];
     const int k = (k_req > 0 && k_req < kmax) ? k_req : kmax;
@@ -599,11 +622,11 @@ __global__ __launch_bounds__(256) void sel_rank_kernel(const unsigned long long*
     const int m = all ? n : sel[b].n_sel;
     const unsigned long long mask = all ? 0xFFFFFFFFull : ~0ull;   // low word = ~index: larger = earlier in row-major order
     if (blockIdx.x == 0 && tid == 0) n_out[b] = all ? n : k;
-    if (blockIdx.x * 256 >= m) return;
-    const int i = blockIdx.x * 256 + tid;
+    if (blockIdx.x * RK_T >= m) return;
+    const int i = blockIdx.x * RK_T + (tid & 63);
     const unsigned long long mine = i < m ? src[i] : 0ull;
-    const int rank = rank_among(src, m, mine, mask, tile);
-    if (i < m) emit_kp(mine, W, kpts + ((long)b * kmax + rank) * 2, scores + (long)b * kmax + rank);
+    const int rank = rank_among(src, m, mine, mask, tile, part);
+    if (tid < RK_T && i < m) emit_kp(mine, W, kpts + ((long)b * kmax + rank) * 2, scores + (long)b * kmax + rank);
 }
 
 // per-device opt-in for more than 64 KB of dynamic LDS (a process may hold contexts on several GPUs)
@@ -638,7 +661,7 @@ static hipError_t launch_nms_fused_r(const float* s, float* out, int B, int H, i
     hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(&nms_fused_kernel<R>), lds, cache);
     if (e != hipSuccess) return e;
     const int tx = (W + nf::TW - 1) / nf::TW, ty = (H + nf::TH - 1) / nf::TH;
-    hipLaunchKernelGGL(nms_fused_kernel<R>, dim3(tx * ty * B), dim3(256), lds, st, s, out, H, W, tx, tx * ty, border, thr, keys, key_stride,
+    hipLaunchKernelGGL(nms_fused_kernel<R>, dim3(tx * ty * B), dim3(nf::NT), lds, st, s, out, H, W, tx, tx * ty, border, thr, keys, key_stride,
                        n_cand, keys ? sel_states(n_cand, B) : nullptr);
     return hipGetLastError();
 }
@@ -674,8 +697,8 @@ static hipError_t launch_select(int B, int H, int W, int k_req, int kmax, const 
         hipLaunchKernelGGL(sel_hist_kernel, dim3(SEL_BLOCKS, B), dim3(256), 0, st, sb.keys, npix, sb.n_cand, ss, k_req, kmax, pass);
     hipLaunchKernelGGL(sel_collect_kernel, dim3(SEL_BLOCKS, B), dim3(256), 0, st, sb.keys, npix, sb.n_cand, ss, k_req, kmax, sb.chosen,
                        (long)kmax, sb.ties, npix);
-    hipLaunchKernelGGL(sel_tie_kernel, dim3(SEL_BLOCKS, B), dim3(256), 0, st, sb.n_cand, ss, k_req, kmax, sb.ties, npix, W, kpts, scores);
-    hipLaunchKernelGGL(sel_rank_kernel, dim3((kmax + 255) / 256, B), dim3(256), 0, st, sb.keys, npix, sb.n_cand, ss, k_req, kmax, sb.chosen,
+    hipLaunchKernelGGL(sel_tie_kernel, dim3(4 * SEL_BLOCKS, B), dim3(RK_N), 0, st, sb.n_cand, ss, k_req, kmax, sb.ties, npix, W, kpts, scores);
+    hipLaunchKernelGGL(sel_rank_kernel, dim3((kmax + RK_T - 1) / RK_T, B), dim3(RK_N), 0, st, sb.keys, npix, sb.n_cand, ss, k_req, kmax, sb.chosen,
                        (long)kmax, W, kpts, scores, n_out);
     return hipGetLastError();
 }
