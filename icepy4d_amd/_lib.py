@@ -57,6 +57,8 @@ SIGNATURES = {
     "im_assign_from_sim": [_P, _P, _I, _I, _I, _P, _P, _F, _P, _P, _P, _P, _P],
     "im_log_optimal_transport": [_P, _P, _I, _I, _I, _F, _I, _P, _P],
     "im_flash_attn_bf16x3": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
+    "im_merge_tile_matches": [_P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "im_gather_rows": [_P, _P, _I, _P, _I, _P, _P],
     "im_ransac_fundamental": [_P, _P, _P, _I, _I, C.c_double, C.c_uint, _P, _P, _P, _P],
 }
 

@@ -13,6 +13,13 @@
 
 namespace im {
 
+struct MergeScratch {                     // im_merge_tile_matches (tile_merge.hip); device memory owned by im_ctx::allocs
+    unsigned long long* key = nullptr;    // (ordered bits of x) << 32 | ordered bits of y, of mkpts0
+    unsigned long long* skey = nullptr;   // the same for first occurrences, ~0 for later duplicates
+    unsigned* seq = nullptr;              // p * K + i: the position in the reference's concatenation order
+    int* count = nullptr;                 // [0] entries collected, [1] unique rows
+    size_t cap = 0;
+};
 std::vector<float> pack_conv3x3(const float* w, int cout, int cin);       // [cout][cin][3][3] -> [cin/16][9][cout][16]
 std::vector<float> pack_conv3x3_wino(const float* w, int cout, int cin);  // -> G g G^T as [cin/8][16][cout][8]
 
@@ -84,6 +91,7 @@ struct im_ctx {
     struct Workspace* ws = nullptr;
     float* stage_attn_part = nullptr; int* stage_attn_cnt = nullptr; size_t stage_attn_floats = 0, stage_attn_ints = 0;  // im_flash_attn
     unsigned short *x3_q = nullptr, *x3_k = nullptr, *x3_vt = nullptr; size_t x3_elems = 0;  // im_flash_attn_bf16x3 (experiment)
+    im::MergeScratch* merge = nullptr;   // scratch of im_merge_tile_matches (tile_merge.hip), grown on demand
     int dbg_cur = 0;  // which ping-pong descriptor buffer the last LightGlue forward ended in (im_debug_read)
 
     int fail(int code, const char* fmt, ...) {

@@ -7,6 +7,7 @@
 #include "kernels.h"
 #include "sp_post.h"
 #include "lg_misc.h"
+#include "rank_sweep.h"
 
 namespace im {
 
@@ -537,44 +538,6 @@ __device__ __forceinline__ void emit_kp(unsigned long long key, int W, float* kp
     kp[0] = (float)x;
     kp[1] = (float)y;
     *sc = __uint_as_float((unsigned)(key >> 32));
-}
-
-// rank of `mine` among src[0 .. m): number of keys larger under `mask`. A block ranks RK_T = 64 keys (lane l of every wave holds
-// key l) and its RK_W waves each sweep their own slice of every 1024-key tile (LDS broadcast reads, two keys per read); the
-// partial ranks meet in LDS. The sweep is bound by the 64-bit compares (one wave needs ~12 ns per key), so k keys are spread
-// over k / 64 blocks x 8 waves.
-static constexpr int RK_T = 64, RK_W = 8, RK_N = RK_T * RK_W;
-__device__ __forceinline__ int rank_among(const unsigned long long* __restrict__ src, int m, unsigned long long mine,
-                                          unsigned long long mask, unsigned long long* tile, int* part) {
-    int rank = 0;
-    const unsigned long long me = mine & mask;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int base = 0; base < m; base += 1024) {
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < 1024 / RK_N; ++j) {
-            const int i = base + j * RK_N + threadIdx.x;
-            tile[j * RK_N + threadIdx.x] = i < m ? (src[i] & mask) : 0ull;      // 0 is smaller than every real key
-        }
-        __syncthreads();
-        // the padding entries of a partial tile are 0 and never count: always sweep the whole slice, 8 reads in flight
-        const ulonglong2* t2 = reinterpret_cast<const ulonglong2*>(tile) + wave * (512 / RK_W);
-#pragma unroll 1
-        for (int i = 0; i < 512 / RK_W; i += 8) {
-            ulonglong2 kk[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) kk[u] = t2[i + u];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) rank += (kk[u].x > me) + (kk[u].y > me);
-        }
-    }
-    __syncthreads();
-    part[wave * RK_T + lane] = rank;
-    __syncthreads();
-    int total = 0;
-#pragma unroll
-    for (int w = 0; w < RK_W; ++w) total += part[w * RK_T + lane];
-    return total;
 }
 
 // ties at the cut: the `remaining` equal-score keys with the lowest pixel index fill slots k - remaining .. k - 1

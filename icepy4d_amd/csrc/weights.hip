@@ -49,4 +49,6 @@ void im_ctx::free_all() {
         delete ws;
         ws = nullptr;
     }
+    delete merge;
+    merge = nullptr;
 }

@@ -412,38 +412,41 @@ class ImageMatcherBase:
         KP = torch.stack([cache[k]["kpts"] for k in keys])          # [T, K, 2]
         SC = torch.stack([cache[k]["scores"] for k in keys])        # [T, K]
         DE = torch.stack([cache[k]["desc"] for k in keys])          # [T, K, 256]
-        NN = torch.cat([cache[k]["n"] for k in keys]).long()        # [T]
+        NN = torch.cat([cache[k]["n"] for k in keys])               # [T] int32
         P = len(tile_pairs)
         M = torch.empty(P, K, dtype=torch.int32, device=dev)
         for p, (tidx0, tidx1) in enumerate(tile_pairs):
             logger.info(f" - Matching tile pair ({tidx0}, {tidx1})")
             self._enqueue_cached(cache[(0, tidx0)], cache[(1, tidx1)], **config)
             M[p].copy_(eng.matches[0])
-        s0 = torch.tensor([slot[(0, a)] for a, _ in tile_pairs], device=dev)
-        s1 = torch.tensor([slot[(1, b)] for _, b in tile_pairs], device=dev)
-        off0 = torch.tensor([[float(t0_lims[a][0]), float(t0_lims[a][1])] for a, _ in tile_pairs], dtype=torch.float32, device=dev)
-        off1 = torch.tensor([[float(t1_lims[b][0]), float(t1_lims[b][1])] for _, b in tile_pairs], dtype=torch.float32, device=dev)
-        org0 = torch.tensor([float(t0_origin[0]), float(t0_origin[1])], dtype=torch.float32, device=dev)
-        org1 = torch.tensor([float(t1_origin[0]), float(t1_origin[1])], dtype=torch.float32, device=dev)
-        valid = (M > -1) & (torch.arange(K, device=dev)[None, :] < NN[s0][:, None])
-        p_idx, i_idx = torch.nonzero(valid, as_tuple=True)          # pair-major, keypoint order inside a pair: the host loop's order
-        j_idx = M[p_idx, i_idx].long()
-        t0i, t1i = s0[p_idx], s1[p_idx]
-        kp0 = (KP[t0i, i_idx] + off0[p_idx]) + org0
-        kp1 = (KP[t1i, j_idx] + off1[p_idx]) + org1
-        S = kp0.shape[0]
-        if S:
-            mk0, inv = torch.unique(kp0, dim=0, return_inverse=True)
-            first = torch.full((mk0.shape[0],), S, dtype=torch.long, device=dev).scatter_reduce_(
-                0, inv, torch.arange(S, device=dev), reduce="amin")
-        else:
-            mk0, first = kp0, torch.zeros(0, dtype=torch.long, device=dev)
-        features0 = FeaturesBase(keypoints=mk0.cpu().numpy(),
-                                 descriptors=np.ascontiguousarray(DE[t0i[first], i_idx[first]].cpu().numpy().T),
-                                 scores=SC[t0i[first], i_idx[first]].cpu().numpy())
-        features1 = FeaturesBase(keypoints=kp1[first].cpu().numpy(),
-                                 descriptors=np.ascontiguousarray(DE[t1i[first], j_idx[first]].cpu().numpy().T),
-                                 scores=SC[t1i[first], j_idx[first]].cpu().numpy())
+        # one library call for the whole tail of the loop (`im_merge_tile_matches`): selection of the valid matches of every
+        # pair, the two fp32 origin shifts, `np.unique(axis=0, return_index=True)` (lexicographic order, first occurrence) by
+        # counting ranks on the device; then row gathers of descriptors / scores for the surviving matches only
+        from .._lib import ptr, stream_ptr
+        slots = torch.tensor([[slot[(0, a)], slot[(1, b)]] for a, b in tile_pairs], dtype=torch.int32, device=dev)
+        off = torch.tensor([[float(t0_lims[a][0]), float(t0_lims[a][1]), float(t1_lims[b][0]), float(t1_lims[b][1])]
+                            for a, b in tile_pairs], dtype=torch.float32, device=dev)
+        origin = np.array([t0_origin[0], t0_origin[1], t1_origin[0], t1_origin[1]], dtype=np.float32)
+        cap = P * K
+        count = torch.zeros(1, dtype=torch.int32, device=dev)
+        idx0 = torch.empty(cap, dtype=torch.int32, device=dev)
+        idx1 = torch.empty(cap, dtype=torch.int32, device=dev)
+        kp0 = torch.empty(cap, 2, device=dev)
+        kp1 = torch.empty(cap, 2, device=dev)
+        NN32 = NN.to(torch.int32)
+        eng.ctx.call("im_merge_tile_matches", P, K, ptr(M), ptr(slots), ptr(off), origin.ctypes.data, ptr(KP), ptr(NN32), ptr(count),
+                     ptr(idx0), ptr(idx1), ptr(kp0), ptr(kp1), stream_ptr())
+        S = int(count.item())                                       # the only host round trip of the tile loop
+        out = []
+        for idx, cols, bank in ((idx0, 256, DE), (idx1, 256, DE), (idx0, 1, SC), (idx1, 1, SC)):
+            dst = torch.empty(S, cols, device=dev)
+            eng.ctx.call("im_gather_rows", ptr(bank), cols, ptr(idx), S, ptr(dst), stream_ptr())
+            out.append(dst)
+        d0, d1, sc0, sc1 = out
+        features0 = FeaturesBase(keypoints=kp0[:S].cpu().numpy(), descriptors=np.ascontiguousarray(d0.cpu().numpy().T),
+                                 scores=sc0[:, 0].cpu().numpy())
+        features1 = FeaturesBase(keypoints=kp1[:S].cpu().numpy(), descriptors=np.ascontiguousarray(d1.cpu().numpy().T),
+                                 scores=sc1[:, 0].cpu().numpy())
         matches0 = np.arange(features0.keypoints.shape[0])
         mconf = features0.scores[matches0 > -1]  # q5: keypoint scores, not match confidences
         logger.info("Matching by tile completed.")

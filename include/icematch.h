@@ -139,6 +139,24 @@ int im_assign_from_sim(im_ctx* ctx, const float* d_sim, int m, int n, int ld, co
 int im_log_optimal_transport(im_ctx* ctx, const float* d_scores, int m, int n, int ld, float bin_score, int iters,
                              float* d_out, void* stream);
 
+/* ---- tile mode (`ImageMatcherBase._match_by_tile`, `matchers.py:304-469`) -----------------------------------------------
+ * The tail of the tile loop for ALL tile pairs of an image pair in one call (`matchers.py:402-448`): valid matches of every
+ * pair are shifted to image coordinates ((kpt + tile origin) + image origin, fp32), concatenated in tile-pair order, and
+ * `np.unique(mkpts0, axis=0, return_index=True)` is applied: rows in lexicographic (x, y) order, first occurrence kept.
+ *   d_matches [n_pairs][max_kpts] int32 : matches0 of every tile pair (-1 = none), rows = keypoints of its first tile
+ *   d_slots   [n_pairs][2] int32        : which entry of the feature bank holds tile 0 / tile 1 of the pair
+ *   d_off     [n_pairs][4] float        : (x, y) origin of tile 0 and of tile 1 in their images (`lim0[0:2]`, `lim1[0:2]`)
+ *   h_origin  [4] float (host)          : `t0_origin`, `t1_origin`
+ *   d_kp_bank [n_tiles][max_kpts][2], d_n_bank [n_tiles] : keypoints and keypoint counts of every extracted tile
+ * Outputs (capacity n_pairs * max_kpts rows): d_count = number of unique rows S; d_idx0 / d_idx1 [S] = flat bank row
+ * (tile * max_kpts + keypoint) of each surviving match in image 0 / 1 (for im_gather_rows on descriptors and scores);
+ * d_kp0 / d_kp1 [S][2] = the matched points in image coordinates. Enqueues only. */
+int im_merge_tile_matches(im_ctx* ctx, int n_pairs, int max_kpts, const int32_t* d_matches, const int32_t* d_slots, const float* d_off,
+                          const float* h_origin, const float* d_kp_bank, const int32_t* d_n_bank, int32_t* d_count, int32_t* d_idx0,
+                          int32_t* d_idx1, float* d_kp0, float* d_kp1, void* stream);
+/* d_dst[r][:] = d_src[d_idx[r]][:] for r < n, rows of row_floats floats (descriptor / score banks -> matched features). */
+int im_gather_rows(im_ctx* ctx, const float* d_src, int row_floats, const int32_t* d_idx, int n, float* d_dst, void* stream);
+
 /* Fundamental-matrix RANSAC over matched keypoints (`src/icepy4d/matching/geometric_verification.py:11-102`, which
  * calls pydegensac / cv2 USAC_MAGSAC on the CPU): n_hyp seeded 8-point hypotheses scored by Sampson error in parallel.
  * d_p0, d_p1 [n][2] float (x, y); d_F [9] double = matrix of the best hypothesis (unit Frobenius norm); d_mask [n] uint8

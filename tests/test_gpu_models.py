@@ -829,3 +829,36 @@ def test_select_topk_multiblock_with_ties_at_the_cut(k):
             cand_flat = np.sort(cand[:, 0] * w + cand[:, 1])
             assert np.array_equal(flat[sc == cut], cand_flat[:int((sc == cut).sum())])
     e.close()
+
+
+def test_preselection_selects_the_oracle_tile_pairs():
+    """TileSelection.PRESELECTION (`matchers.py:513-560`): pyramid down, one low-resolution match with 4096 keypoints, keypoints
+    scaled back by 2^n, a tile pair is kept when MORE than `min_matches_per_tile` matches fall strictly inside both tiles. The
+    matcher's selection against the same rule evaluated on the oracle's matches of the same pyramid images (the cv2.pyrDown
+    restatement is cross-checked on the CPU, tests/test_host_cpu.py::test_pyramid; parity with a cv2 build is unpinned)."""
+    from icepy4d_amd.matching import LightGlueMatcher, TileSelection
+    from icepy4d_amd.matching.pyramid import pyr_down
+    from icepy4d_amd.matching.tiling import Tiler
+    from itertools import product
+    o = oracle()
+    a, b = synthetic.translated_pair(21, 400, 608, 48, 16)
+    lg_sd = synthetic.lightglue_state_dict(0, "passthrough")
+    m = LightGlueMatcher({"state_dicts": {"superpoint": SP_SD, "lightglue": lg_sd}})
+    from icepy4d_amd.utils import AverageTimer
+    m.timer = AverageTimer()
+    t = Tiler(grid=[2, 3], overlap=10)
+    l0, _ = t.compute_limits_by_grid(a)
+    l1, _ = t.compute_limits_by_grid(b)
+    for min_matches in (5, 40):
+        got = m._tile_selection(a, b, l0, l1, TileSelection.PRESELECTION, min_matches_per_tile=min_matches)
+        i0, i1 = pyr_down(a), pyr_down(b)                            # 400 rows: one pyramid level (`matchers.py:516-523`)
+        F0, F1, m0, _, _ = o.match_images_lightglue(i0, i1, SP_SD, lg_sd, max_keypoints=4096)
+        v = m0 > -1
+        kp0, kp1 = F0[0][v] * 2, F1[0][m0[v]] * 2
+        want = []
+        for t0, t1 in sorted(product(l0.keys(), l1.keys())):
+            r0, r1 = np.asarray(l0[t0]), np.asarray(l1[t1])
+            inside = (np.all(kp0 > r0[:2], 1) & np.all(kp0 < r0[2:], 1)) & (np.all(kp1 > r1[:2], 1) & np.all(kp1 < r1[2:], 1))
+            if int(inside.sum()) > min_matches:
+                want.append((t0, t1))
+        assert got == want and 0 < len(want) < 36, (got, want)

@@ -80,6 +80,22 @@ def test_pyramid():
     ref = (np.outer(k, k) * b[2 * y - 2:2 * y + 3, 2 * x - 2:2 * x + 3].astype(np.int64)).sum()
     assert d[y, x] == (ref + 128) >> 8
     assert abs(float(pyr_up(d).mean()) - float(b.mean())) < 2.0
+    # whole-image cross-check against an independent formulation of the documented algorithm (scipy correlate, mode
+    # 'mirror' = BORDER_REFLECT_101): separable [1 4 6 4 1] on the full-resolution image, every second sample, (s + 128) >> 8;
+    # odd sizes and 3 channels included. (cv2 itself is absent: parity with an OpenCV build stays unpinned.)
+    from scipy import ndimage
+    k2 = np.outer(k, k)
+    for img in (b, b[:63, :95], np.stack([b, b[::-1], b[:, ::-1]], -1)):
+        planes = img[..., None] if img.ndim == 2 else img
+        ref = np.stack([(ndimage.correlate(planes[..., c].astype(np.int64), k2, mode="mirror")[::2, ::2] + 128) >> 8
+                        for c in range(planes.shape[-1])], -1).astype(np.uint8)
+        got = pyr_down(img)
+        assert np.array_equal(got if img.ndim == 3 else got[..., None], ref)
+    # pyrUp: zero insertion, the same kernel, (s + 32) >> 6; interior samples (the border rule acts on source indices)
+    z = np.zeros((2 * d.shape[0], 2 * d.shape[1]), np.int64)
+    z[::2, ::2] = d
+    ref_up = (ndimage.correlate(z, k2, mode="constant") + 32) >> 6
+    assert np.array_equal(pyr_up(d)[2:-2, 2:-2], np.clip(ref_up, 0, 255)[2:-2, 2:-2].astype(np.uint8))
 
 
 def test_geometric_verification():
@@ -351,3 +367,36 @@ def test_margin_extractor_explains_perturbed_decisions():
     m_ref = np.array([0, 2, 1])
     assert margins.explain_match_diffs(la, np.array([1, 2, 1]), m_ref, 0.1, 1e-4)["unexplained"] == []
     assert margins.explain_match_diffs(la, np.array([0, 0, 1]), m_ref, 0.1, 1e-4)["unexplained"] != []
+
+
+def test_features_pickle_is_the_references_format(tmp_path):
+    """Row f-3: `icepy4d_amd.features_io` writes the pickle `icepy4d.core.Features.save_as_pickle` writes (fixtures
+    g7_features_ref*.pkl were produced by the reference's own class from the arrays in g7_features_in.npz): same bytes, and a
+    reference-written file reads back to the arrays that went in."""
+    from conftest import load_golden, GOLDEN
+    from icepy4d_amd import features_io as fio
+    g = load_golden("g7_features_in")
+    ref = fio.load_features_pickle(os.path.join(GOLDEN, "g7_features_ref.pkl"))
+    assert np.array_equal(ref["kpts"], g["kpts"]) and np.array_equal(ref["descr"], g["descr"]) and np.array_equal(ref["scores"], g["scores"])
+    assert ref["track_ids"].tolist() == list(range(12)) and ref["epoch"] is None
+    out = tmp_path / "features_0.pkl"
+    fio.save_features_pickle(out, g["kpts"], g["descr"], g["scores"])
+    assert out.read_bytes() == open(os.path.join(GOLDEN, "g7_features_ref.pkl"), "rb").read()
+    out2 = tmp_path / "features_ep.pkl"
+    fio.save_features_pickle(out2, g["kpts"], g["descr"], g["scores"].reshape(-1, 1), epoch=3)
+    assert out2.read_bytes() == open(os.path.join(GOLDEN, "g7_features_ref_epoch.pkl"), "rb").read()
+    back = fio.load_features_pickle(out2)
+    assert int(back["epoch"]) == 3 and np.array_equal(back["descr"], g["descr"])
+    assert "icepy4d.core.features" not in sys.modules            # the stand-in module is only registered while (un)pickling
+    # COLMAP-export arithmetic (`io/export2colmap.py:27-88`): rounded unique keypoints, re-indexed pairs
+    rng = np.random.default_rng(1)
+    a = rng.uniform(0, 50, size=(40, 2)).astype(np.float32)
+    b = a + np.float32(3.2)
+    a[5] = a[4]
+    kp, mt = fio.matches_to_h5_arrays(a, b, "im0.jpg", "im1.jpg")
+    m = mt["im0.jpg"]["im1.jpg"]
+    assert np.array_equal(kp["im0.jpg"][m[:, 0]], np.round(a)) and np.array_equal(kp["im1.jpg"][m[:, 1]], np.round(b))
+    assert len(kp["im0.jpg"]) <= 39 and fio.matches_to_h5_arrays(a[:10], b[:10], "x", "y") == ({}, {})
+    txt = tmp_path / "k.txt"
+    fio.save_features_txt(txt, g["kpts"])
+    assert np.array_equal(np.loadtxt(txt, delimiter=",", skiprows=1), g["kpts"])

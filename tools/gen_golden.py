@@ -139,6 +139,36 @@ def gen_colour(sp_sd):
          sg_descriptors=sg_out["descriptors"][0])
 
 
+def gen_features_pickle():
+    """g7: a `Features` pickle written by the reference's own class (`core/features.py:362-453, 596-600`) from seeded arrays,
+    the file format the epoch loop persists (`main_dev.py:160-173`)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("icepy4d.core.features", REF_SRC + "/icepy4d/core/features.py")
+    mod = importlib.util.module_from_spec(spec)
+    for name in ("icepy4d", "icepy4d.core"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["icepy4d.core.features"] = mod
+    spec.loader.exec_module(mod)
+    rng = np.random.default_rng(77)
+    n = 12
+    kpts = rng.integers(4, 600, size=(n, 2)).astype(np.float32)
+    descr = rng.normal(size=(256, n)).astype(np.float32)
+    scores = rng.uniform(0.01, 0.5, size=n).astype(np.float32)
+    fs = mod.Features()
+    fs.append_features_from_numpy(x=kpts[:, 0], y=kpts[:, 1], descr=descr, scores=scores)
+    path = os.path.join(OUT, "g7_features_ref.pkl")
+    fs.save_as_pickle(path)
+    fs2 = mod.Features()
+    fs2.append_features_from_numpy(x=kpts[:, 0], y=kpts[:, 1], descr=descr, scores=scores.reshape(-1, 1), epoch=3)
+    fs2.save_as_pickle(os.path.join(OUT, "g7_features_ref_epoch.pkl"))
+    save("g7_features_in", kpts=kpts, descr=descr, scores=scores)
+    print(f"wrote {path} ({os.path.getsize(path)} bytes)")
+    for name in ("icepy4d.core.features", "icepy4d.core", "icepy4d"):
+        if isinstance(sys.modules.get(name), types.ModuleType) and not getattr(sys.modules[name], "__file__", None):
+            sys.modules.pop(name, None)
+    sys.modules.pop("icepy4d.core.features", None)
+
+
 def gen_prune_threshold():
     """g2_lightglue_6: the reference's `desc.shape[-2] > pruning_th` gate (`lightglue.py:495, 503`). On a CPU tensor the
     reference looks up `pruning_keypoint_thresholds['cpu']` = -1; its CUDA values are 1024 / 1536. The table entry is set to
@@ -171,6 +201,9 @@ def main():
     torch.set_num_threads(8)
     if len(sys.argv) > 1 and sys.argv[1] == "colour":
         gen_colour(synthetic.superpoint_state_dict(0))
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "features_pickle":
+        gen_features_pickle()
         return
     if len(sys.argv) > 1 and sys.argv[1] == "prune_threshold":
         gen_prune_threshold()
