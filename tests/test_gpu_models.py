@@ -841,7 +841,11 @@ def test_preselection_selects_the_oracle_tile_pairs():
     from icepy4d_amd.matching.tiling import Tiler
     from itertools import product
     o = oracle()
-    a, b = synthetic.translated_pair(21, 400, 608, 48, 16)
+    # a pair whose HALF-resolution pyramid level is textured and related by a translation of (24, 8): each pixel of a
+    # half-size translated pair blown up to a 2 x 2 block (with seeded weights the doubly smoothed full-size noise would
+    # leave only a few dozen low-resolution matches)
+    ha, hb = synthetic.translated_pair(21, 200, 304, 24, 8, noise=0.0)
+    a, b = np.kron(ha, np.ones((2, 2), np.uint8)), np.kron(hb, np.ones((2, 2), np.uint8))
     lg_sd = synthetic.lightglue_state_dict(0, "passthrough")
     m = LightGlueMatcher({"state_dicts": {"superpoint": SP_SD, "lightglue": lg_sd}})
     from icepy4d_amd.utils import AverageTimer
