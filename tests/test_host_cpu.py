@@ -400,3 +400,42 @@ def test_features_pickle_is_the_references_format(tmp_path):
     txt = tmp_path / "k.txt"
     fio.save_features_txt(txt, g["kpts"])
     assert np.array_equal(np.loadtxt(txt, delimiter=",", skiprows=1), g["kpts"])
+
+
+def test_geometric_verification_lo_degeneracy_and_magsac():
+    """Row f-2 beyond plain RANSAC: (a) MAGSAC ignores the caller's threshold like the reference's fallback call and keeps the
+    tight sigma-consensus inliers; (b) a scene dominated by one plane plus a few off-plane points: the degeneracy repair
+    (plane-and-parallax) recovers the off-plane inliers that a plane-degenerate F misses; (c) `confidence` changes how many
+    hypotheses are drawn."""
+    from icepy4d_amd.matching import GeometricVerification, geometric_verification
+    gv = sys.modules["icepy4d_amd.matching.geometric_verification"]     # the module (the package exports the function by that name)
+    rng = np.random.default_rng(5)
+    K = np.array([[900, 0, 400], [0, 900, 300], [0, 0, 1.0]])
+    t = np.array([0.6, 0.02, 0.05])
+
+    def project(X, noise):
+        p0 = (K @ X.T).T
+        p1 = (K @ (X + t).T).T
+        p0, p1 = p0[:, :2] / p0[:, 2:], p1[:, :2] / p1[:, 2:]
+        return p0, p1 + rng.normal(0, noise, p1.shape)
+
+    # (a) general scene, 0.2 px noise, 25 % gross outliers
+    X = np.c_[rng.uniform(-1, 1, 400), rng.uniform(-1, 1, 400), rng.uniform(4, 9, 400)]
+    p0, p1 = project(X, 0.2)
+    p1[:100] += rng.uniform(15, 40, size=(100, 2))
+    F, m_mag = geometric_verification(p0, p1, GeometricVerification.MAGSAC, threshold=50.0)      # threshold is ignored
+    F2, m_deg = geometric_verification(p0, p1, GeometricVerification.PYDEGENSAC, threshold=1.0)
+    assert m_mag[:100].mean() < 0.05 and m_mag[100:].mean() > 0.9 and m_deg[100:].mean() > 0.95
+    x0, x1 = np.c_[p0[100:], np.ones(300)], np.c_[p1[100:], np.ones(300)]
+    assert np.abs(np.einsum("ni,ij,nj->n", x1, F, x0)).mean() < 2e-3 * np.abs(F).max() * 900
+    # (b) 90 % of the points on one plane
+    n_pl, n_off = 360, 40
+    Xp = np.c_[rng.uniform(-1, 1, n_pl), rng.uniform(-1, 1, n_pl), np.full(n_pl, 6.0)]
+    Xo = np.c_[rng.uniform(-1, 1, n_off), rng.uniform(-1, 1, n_off), rng.uniform(3, 9, n_off)]
+    p0, p1 = project(np.r_[Xp, Xo], 0.1)
+    _, m_on = geometric_verification(p0, p1, GeometricVerification.PYDEGENSAC, threshold=0.7, seed=3)
+    assert m_on[:n_pl].mean() > 0.95 and m_on[n_pl:].mean() > 0.8, (m_on[:n_pl].mean(), m_on[n_pl:].mean())
+    # (c) confidence drives the hypothesis count
+    assert gv._needed(0.9999, 0.5) > gv._needed(0.9, 0.5) > 0 and gv._needed(0.99, 0.9) < 10
+    w = gv._magsac_weights(np.array([0.0, 0.5, 1.0, 1.81, 1.83, 5.0]))
+    assert (np.diff(w[:4]) < 0).all() and w[4] == 0 and w[5] == 0
