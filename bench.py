@@ -276,7 +276,7 @@ def main():
         prof_steps = 1 if cfg5 else 3
         _, pstream, psm = sm.slots[0]
         psm.use_graph = False  # per-launch events need direct launches (same kernels, same stream, one pair in flight)
-        psm.pairs_per_launch = 1
+        psm.P = 1
         with torch.cuda.stream(pstream):
             for i in range(prof_steps):
                 psm.match_pair(pool[i % len(pool)], epochs[i], scratch, 0)

@@ -44,6 +44,8 @@ SIGNATURES = {
     "im_superpoint_forward": [_P, _P, _I, _I, _I, _I, _I, _F, _I, _I, _I, _P, _P, _P, _P, _P],
     "im_superpoint_candidates": [_P, _I, _P, _P],
     "im_lightglue_forward": [_P, _P, _P, _P, _P, C.POINTER(LightGlueConf), _P, _P, _P, _P, _P],
+    "im_lightglue_forward_pairs": [_P, _I, _P, _P, _P, _P, C.POINTER(LightGlueConf), _P, _P, _P, _P, _P],
+    "im_pack_records": [_P, _I, _P, _P, _P, _P, _I, _P, _P],
     "im_superglue_forward": [_P, _P, _P, _P, _P, _P, C.POINTER(SuperGlueConf), _P, _P, _P, _P],
     "im_pack_record": [_P, _P, _P, _P, _P, _I, _P, _P],
     "im_debug_read": [_P, C.c_char_p, _P, C.c_size_t, _P],

@@ -199,20 +199,25 @@ __device__ __forceinline__ void pv_tile(const float* __restrict__ sV, int c, int
 template <int G>
 __global__ __launch_bounds__(256 * G, 2 / G) void flash_attn_f32_kernel(AttnArgs a) {
     constexpr int NT = 256 * G;
-    if (a.active && *a.active == 0) return;
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     // XCD-aware block -> tile map: workgroups are dealt round-robin over the 8 XCDs (bid % 8), each with a private
     // 4 MB L2. The (image, head) index is the fastest-varying part of the linear block id, so with
     // heads * batch = 8 every query block of one (image, head) lands on the same XCD and that XCD's L2 holds exactly
     // one K/V set (2 MB at 4096 keys) instead of all eight.
-    const int hz = a.heads * a.batch;
-    const int bid = blockIdx.x;
-    const int head = (bid % hz) % a.heads, z = (bid % hz) / a.heads;
-    const int y = a.cross ? (z ^ 1) : z;
-    const int nq = a.n_ptr ? a.n_ptr[z] : a.n_max;
-    const int nk_all = a.n_ptr ? a.n_ptr[y] : a.n_max;
+    // With more than one pair in the batch the pair index is the SLOWEST part of the block id: the blocks resident at any
+    // time belong to one or two pairs, so an XCD's L2 still holds one K/V set per (image, head) it serves.
+    const int gsz = (a.batch % 2 == 0) ? 2 : a.batch;                  // images per group (a pair; or the whole odd batch)
+    const int hz = a.heads * gsz;
     const int nqb = (a.n_max + 127) / 128;
+    const int per_group = hz * nqb * (a.part ? ATTN_MAX_SPLIT : 1);
+    const int grp_idx = blockIdx.x / per_group;
+    const int bid = blockIdx.x - grp_idx * per_group;
+    const int head = (bid % hz) % a.heads, z = grp_idx * gsz + (bid % hz) / a.heads;
+    const int y = a.cross ? (z ^ 1) : z;
+    if (a.active && a.active[(z >> 1) * a.pstride] == 0) return;
+    const int nq = a.n_ptr ? a.n_ptr[(z >> 1) * a.pstride + (z & 1)] : a.n_max;
+    const int nk_all = a.n_ptr ? a.n_ptr[(y >> 1) * a.pstride + (y & 1)] : a.n_max;
     const int qblk = (bid / hz) % nqb, split = (bid / hz) / nqb;
     const int qb = qblk * 128;
     if (qb >= nq || nk_all <= 0) return;

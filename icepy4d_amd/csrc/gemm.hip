@@ -32,7 +32,6 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t gmake_rsrc(const void* base, u
 
 template <int BM, int BN, int BK, int EPI>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
-    if (a.active && *a.active == 0) return;
     constexpr int LDS_LD = BK + 4;
     constexpr int WM = BM / 2, WN = BN / 2;
     constexpr int MB = WM / 32, NB = WN / 32;
@@ -47,8 +46,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
     // into one L2 instead of up to eight.
     const int gm = (a.m_max + BM - 1) / BM;
     const int z = blockIdx.y;
-    const int M = a.m_ptr ? a.m_ptr[z] : a.m_max;
-    const int Nlive = a.n_ptr ? min(*a.n_ptr, a.N) : a.N;
+    const int pair = a.pair_batched ? z : (z >> 1);
+    if (a.active && a.active[pair * a.pstride] == 0) return;
+    const int M = a.m_ptr ? a.m_ptr[a.pair_batched ? z * a.pstride : (z >> 1) * a.pstride + (z & 1)] : a.m_max;
+    const int Nlive = a.n_ptr ? min(a.n_ptr[z * a.pstride], a.N) : a.N;
     const int m0 = (blockIdx.x % gm) * BM, n0 = (blockIdx.x / gm) * BN;
     if (m0 >= M || n0 >= Nlive) return;
 
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
     const int c = lane & 31, hh = lane >> 5;
     const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
 
-    const int sel = a.sel ? *a.sel : 0;
+    const int sel = a.sel ? a.sel[pair] : 0;
     const float* Wp = a.W + (long)z * a.w_bstride + (long)sel * a.w_sel_stride;
     const float* bias = a.bias ? a.bias + (long)sel * a.bias_sel_stride : nullptr;
     const float* A0 = a.A + (long)z * a.a_bstride;

@@ -24,13 +24,16 @@ struct GemmArgs {
     const float* A1 = nullptr; long a1_bstride = 0; int lda1 = 0; int ksplit = 0;  // k >= ksplit reads A1[m][k - ksplit]
     const float* W = nullptr;  int ldw = 0; long w_bstride = 0;
     const float* bias = nullptr;
-    const int* sel = nullptr; long w_sel_stride = 0; long bias_sel_stride = 0;     // W += *sel * stride
+    const int* sel = nullptr; long w_sel_stride = 0; long bias_sel_stride = 0;     // W += sel[pair] * stride (device-side layer index)
     int N = 0, K = 0;
     int m_max = 0;                 // rows the grid covers
-    const int* m_ptr = nullptr;    // live rows per batch element (device), or null => m_max
-    int m_ptr_xor = 0;             // rows taken from m_ptr[z ^ m_ptr_xor]
-    const int* n_ptr = nullptr;    // live columns (device) for the score GEMM, or null => N
-    const int* active = nullptr;   // device flag, 0 => kernel is a no-op
+    // Batch element z is image (z & 1) of pair (z >> 1) - or, with pair_batched, pair z itself (the score GEMM). Live sizes and
+    // flags of a pair sit `pstride` ints apart (2 = a plain int array [n0, n1, n2, ...]; sizeof(LGState) / 4 = the matcher state):
+    const int* m_ptr = nullptr;    // live rows: m_ptr[(z >> 1) * pstride + (z & 1)]  (pair_batched: m_ptr[z * pstride]); null => m_max
+    const int* n_ptr = nullptr;    // live columns of the score GEMM: n_ptr[z * pstride]; null => N
+    const int* active = nullptr;   // per-pair flag active[pair * pstride], 0 => this batch element is a no-op
+    int pstride = 2;
+    int pair_batched = 0;
     int batch = 1;
     float alpha = 1.f;
     float* C = nullptr; long c_bstride = 0; int ldc = 0;
@@ -48,10 +51,11 @@ struct AttnArgs {
     const float* q = nullptr; const float* k = nullptr; const float* v = nullptr;
     long bstride = 0; long hstride = 0;         // [z][head][row][64]
     float* out = nullptr; long out_bstride = 0; int ldo = 256;
-    const int* n_ptr = nullptr;                 // n_ptr[z] live points of image z
+    const int* n_ptr = nullptr;                 // live points of image z: n_ptr[(z >> 1) * pstride + (z & 1)]
+    int pstride = 2;                            // ints between the states of consecutive pairs (2 = plain array n[batch])
     int n_max = 0; int batch = 2; int heads = 4; int cross = 0;
     float scale = 1.f;
-    const int* active = nullptr;
+    const int* active = nullptr;                // per-pair flag active[(z >> 1) * pstride]
     // split-KV workspace (optional): when set, (image, head, query block)s with few queries are cut into up to
     // ATTN_MAX_SPLIT key ranges on separate blocks; the last block to finish merges the partials (fixed order)
     float* part = nullptr;       // [ATTN_MAX_SPLIT][batch][heads][n_max][66]  (64 x O, m, l)

@@ -9,14 +9,14 @@ namespace im {
 
 // ---------------------------------------------------------------------------------------------------------
 // normalize_keypoints + LearnableFourierPositionalEncoding (`lightglue/lightglue.py:23-35, 60-74`)
-__global__ __launch_bounds__(256) void posenc_kernel(const float* __restrict__ kpts, long kp_bstride, const int* __restrict__ n_ptr,
+__global__ __launch_bounds__(256) void posenc_kernel(const float* __restrict__ kpts, long kp_bstride, const LGState* __restrict__ st,
                                                       const float* __restrict__ wr, float4 sizes, float* __restrict__ cs,
                                                       float* __restrict__ sn, long enc_bstride) {
-    const int b = blockIdx.y;
+    const int b = blockIdx.y;      // image b & 1 of pair b >> 1; every pair of a batch has the same two image sizes
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int i = t >> 5, f = t & 31;
-    if (i >= n_ptr[b]) return;
-    const float sw = b == 0 ? sizes.x : sizes.z, sh = b == 0 ? sizes.y : sizes.w;
+    if (i >= st[b >> 1].n[b & 1]) return;
+    const float sw = (b & 1) == 0 ? sizes.x : sizes.z, sh = (b & 1) == 0 ? sizes.y : sizes.w;
     const float scale = fmaxf(sw, sh) / 2.f;
     const float kx = (kpts[(long)b * kp_bstride + i * 2] - sw / 2.f) / scale;
     const float ky = (kpts[(long)b * kp_bstride + i * 2 + 1] - sh / 2.f) / scale;
@@ -25,22 +25,21 @@ __global__ __launch_bounds__(256) void posenc_kernel(const float* __restrict__ k
     sn[(long)b * enc_bstride + (long)i * 32 + f] = sinf(proj);
 }
 
-hipError_t launch_posenc(const float* kpts, long kp_bstride, const int* n_ptr, int n_max, const float* wr,
+hipError_t launch_posenc(const float* kpts, long kp_bstride, const LGState* st, int n_images, int n_max, const float* wr,
                          const float* h_size, float* cs, float* sn, long enc_bstride, hipStream_t s) {
     float4 sizes = make_float4(h_size[0], h_size[1], h_size[2], h_size[3]);
-    hipLaunchKernelGGL(posenc_kernel, dim3((n_max * 32 + 255) / 256, 2), dim3(256), 0, s, kpts, kp_bstride, n_ptr, wr, sizes, cs, sn, enc_bstride);
+    hipLaunchKernelGGL(posenc_kernel, dim3((n_max * 32 + 255) / 256, n_images), dim3(256), 0, s, kpts, kp_bstride, st, wr, sizes, cs, sn, enc_bstride);
     return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // LayerNorm(512, eps 1e-5, affine) + exact-erf GELU in place (`lightglue/lightglue.py:144-149`). Wave per row.
-__global__ __launch_bounds__(256) void layernorm_gelu_kernel(float* __restrict__ h, long bstride, const int* __restrict__ n_ptr,
-                                                              const float* __restrict__ g, const float* __restrict__ be,
-                                                              const int* __restrict__ active) {
-    if (active && *active == 0) return;
+__global__ __launch_bounds__(256) void layernorm_gelu_kernel(float* __restrict__ h, long bstride, const LGState* __restrict__ st,
+                                                              const float* __restrict__ g, const float* __restrict__ be) {
     const int b = blockIdx.y, lane = threadIdx.x & 63;
+    if (st[b >> 1].active == 0) return;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= n_ptr[b]) return;
+    if (row >= st[b >> 1].n[b & 1]) return;
     float* p = h + (long)b * bstride + (long)row * 512;
     float4 v0 = *reinterpret_cast<float4*>(p + lane * 4);
     float4 v1 = *reinterpret_cast<float4*>(p + 256 + lane * 4);
@@ -64,9 +63,9 @@ __global__ __launch_bounds__(256) void layernorm_gelu_kernel(float* __restrict__
     *reinterpret_cast<float4*>(p + 256 + lane * 4) = make_float4(o[4], o[5], o[6], o[7]);
 }
 
-hipError_t launch_layernorm_gelu(float* h, long bstride, const int* n_ptr, int n_max, const float* g, const float* be,
-                                 const int* active, hipStream_t s) {
-    hipLaunchKernelGGL(layernorm_gelu_kernel, dim3((n_max + 3) / 4, 2), dim3(256), 0, s, h, bstride, n_ptr, g, be, active);
+hipError_t launch_layernorm_gelu(float* h, long bstride, const LGState* st, int n_images, int n_max, const float* g, const float* be,
+                                 hipStream_t s) {
+    hipLaunchKernelGGL(layernorm_gelu_kernel, dim3((n_max + 3) / 4, n_images), dim3(256), 0, s, h, bstride, st, g, be);
     return hipGetLastError();
 }
 
@@ -77,21 +76,23 @@ hipError_t launch_layernorm_gelu(float* h, long bstride, const int* n_ptr, int n
 // and an integer count of rows with out0 < thr (the early-stop statistic, `:571-579`).
 static constexpr int RD_ROWS = 8;  // rows per wave: one counter atomic per block of 32 rows instead of one per row
 
-__global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ x, long bstride, const int* __restrict__ n_ptr,
+__global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ x, long bstride, LGState* __restrict__ st,
                                                       const float* __restrict__ w0, const float* __restrict__ b0, int act0,
                                                       const float* __restrict__ w1, const float* __restrict__ b1,
                                                       const int* __restrict__ sel, float* __restrict__ out0,
                                                       float* __restrict__ out1, long out_bstride, float thr,
-                                                      int* __restrict__ counter, const int* __restrict__ active) {
-    if (active && *active == 0) return;
+                                                      int count_layer, int check_active) {
     __shared__ int blk_cnt;
     const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int n = n_ptr[b];
+    LGState* sp = st + (b >> 1);
+    if (check_active && sp->active == 0) return;
+    int* counter = count_layer >= 0 ? &sp->cnt[count_layer] : nullptr;
+    const int n = sp->n[b & 1];
     const int row0 = (blockIdx.x * 4 + wave) * RD_ROWS;
     if (blockIdx.x * 4 * RD_ROWS >= n) return;  // block-uniform
     if (threadIdx.x == 0) blk_cnt = 0;
     __syncthreads();
-    const int l = sel ? *sel : 0;
+    const int l = sel ? sel[b >> 1] : 0;
     float4 wa = make_float4(0.f, 0.f, 0.f, 0.f), wb = wa;
     float ba = 0.f, bb = 0.f;
     if (w0) { wa = *reinterpret_cast<const float4*>(w0 + (long)l * 256 + lane * 4); ba = b0[l]; }
@@ -122,11 +123,11 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ x
     }
 }
 
-hipError_t launch_rowdot(const float* x, long bstride, const int* n_ptr, int n_max, const float* w0, const float* b0, int act0,
+hipError_t launch_rowdot(const float* x, long bstride, LGState* st, int n_images, int n_max, const float* w0, const float* b0, int act0,
                          const float* w1, const float* b1, const int* sel, float* out0, float* out1, long out_bstride,
-                         float thr, int* counter, const int* active, hipStream_t s) {
-    hipLaunchKernelGGL(rowdot_kernel, dim3((n_max + 4 * RD_ROWS - 1) / (4 * RD_ROWS), 2), dim3(256), 0, s, x, bstride, n_ptr, w0, b0, act0, w1,
-                       b1, sel, out0, out1, out_bstride, thr, counter, active);
+                         float thr, int count_layer, int check_active, hipStream_t s) {
+    hipLaunchKernelGGL(rowdot_kernel, dim3((n_max + 4 * RD_ROWS - 1) / (4 * RD_ROWS), n_images), dim3(256), 0, s, x, bstride, st, w0, b0, act0,
+                       w1, b1, sel, out0, out1, out_bstride, thr, count_layer, check_active);
     return hipGetLastError();
 }
 
@@ -144,6 +145,10 @@ __global__ __launch_bounds__(1024) void stop_prune_kernel(LGState* __restrict__ 
     __shared__ int part[1024];
     __shared__ int sh_active;
     const int tid = threadIdx.x;
+    const int pair = blockIdx.x;
+    st += pair;
+    conf += 2 * pair * vec_bstride; msc += 2 * pair * vec_bstride;
+    ind_cur += 2 * pair * idx_bstride; ind_next += 2 * pair * idx_bstride; keep_idx += 2 * pair * idx_bstride; prune += 2 * pair * idx_bstride;
     if (tid == 0) {
         int act = st->active;
         if (act && do_stop) {
@@ -208,10 +213,10 @@ __global__ __launch_bounds__(1024) void stop_prune_kernel(LGState* __restrict__ 
     }
 }
 
-hipError_t launch_stop_prune(LGState* st, int layer, int do_stop, int do_prune, float depth_conf, float keep_thr,
+hipError_t launch_stop_prune(LGState* st, int n_pairs, int layer, int do_stop, int do_prune, float depth_conf, float keep_thr,
                              float conf_thr, const float* conf, const float* msc, long vec_bstride, const int* ind_cur,
                              int* ind_next, int* keep_idx, int* prune, long idx_bstride, int prune_min, hipStream_t s) {
-    hipLaunchKernelGGL(stop_prune_kernel, dim3(1), dim3(1024), 0, s, st, layer, do_stop, do_prune, depth_conf, keep_thr, conf_thr,
+    hipLaunchKernelGGL(stop_prune_kernel, dim3(n_pairs), dim3(1024), 0, s, st, layer, do_stop, do_prune, depth_conf, keep_thr, conf_thr,
                        conf, msc, vec_bstride, ind_cur, ind_next, keep_idx, prune, idx_bstride, prune_min);
     return hipGetLastError();
 }
@@ -225,7 +230,7 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const LGState* __restr
                                                            long enc_bstride) {
     const int b = blockIdx.y, lane = threadIdx.x & 63;
     const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (p >= st->n[b]) return;
+    if (p >= st[b >> 1].n[b & 1]) return;
     const int e = keep_idx[(long)b * idx_bstride + p];
     *reinterpret_cast<float4*>(x_dst + (long)b * x_bstride + (long)p * 256 + lane * 4) =
         *reinterpret_cast<const float4*>(x_src + (long)b * x_bstride + (long)e * 256 + lane * 4);
@@ -237,10 +242,10 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const LGState* __restr
             *reinterpret_cast<const float4*>(sn_src + (long)b * enc_bstride + (long)e * 32 + (lane - 8) * 4);
 }
 
-hipError_t launch_gather_rows(const LGState* st, int n_max, const int* keep_idx, long idx_bstride, const float* x_src,
+hipError_t launch_gather_rows(const LGState* st, int n_images, int n_max, const int* keep_idx, long idx_bstride, const float* x_src,
                               float* x_dst, long x_bstride, const float* cs_src, float* cs_dst, const float* sn_src,
                               float* sn_dst, long enc_bstride, hipStream_t s) {
-    hipLaunchKernelGGL(gather_rows_kernel, dim3((n_max + 3) / 4, 2), dim3(256), 0, s, st, keep_idx, idx_bstride, x_src, x_dst,
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((n_max + 3) / 4, n_images), dim3(256), 0, s, st, keep_idx, idx_bstride, x_src, x_dst,
                        x_bstride, cs_src, cs_dst, sn_src, sn_dst, enc_bstride);
     return hipGetLastError();
 }
@@ -250,13 +255,14 @@ __global__ void lg_init_kernel(LGState* st, const int* __restrict__ n_in, int* _
     const int b = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
+        LGState* sp = st + (b >> 1);
         const int n = min(n_in[b], n_max);
-        st->n[b] = n;
-        st->n_orig[b] = n;
-        if (b == 0) {
-            st->active = 1;
-            st->stop_layer = -1;
-            for (int l = 0; l < 16; ++l) st->cnt[l] = 0;
+        sp->n[b & 1] = n;
+        sp->n_orig[b & 1] = n;
+        if ((b & 1) == 0) {
+            sp->active = 1;
+            sp->stop_layer = -1;
+            for (int l = 0; l < 16; ++l) sp->cnt[l] = 0;
         }
     }
     if (i < n_max) {
@@ -267,25 +273,28 @@ __global__ void lg_init_kernel(LGState* st, const int* __restrict__ n_in, int* _
     }
 }
 
-hipError_t launch_lg_init(LGState* st, const int* n_in, int* ind, int* prune, long idx_bstride, int n_max, int* out_m,
+hipError_t launch_lg_init(LGState* st, int n_images, const int* n_in, int* ind, int* prune, long idx_bstride, int n_max, int* out_m,
                           float* out_s, long out_bstride, hipStream_t s) {
-    hipLaunchKernelGGL(lg_init_kernel, dim3((n_max + 255) / 256, 2), dim3(256), 0, s, st, n_in, ind, prune, idx_bstride, n_max, out_m, out_s, out_bstride);
+    hipLaunchKernelGGL(lg_init_kernel, dim3((n_max + 255) / 256, n_images), dim3(256), 0, s, st, n_in, ind, prune, idx_bstride, n_max, out_m, out_s, out_bstride);
     return hipGetLastError();
 }
 
 // sel = last executed layer: stop_layer if the matcher stopped early, else n_layers - 1 (`lightglue.py:512-513`)
-__global__ void lg_select_layer_kernel(LGState* st, int n_layers, int* sel, int* info) {
+__global__ void lg_select_layer_kernel(LGState* st, int n_pairs, int n_layers, int* sel, int* info) {
+    const int p = threadIdx.x;
+    if (p >= n_pairs) return;
+    st += p;
     const int last = st->stop_layer >= 0 ? st->stop_layer : n_layers - 1;
-    *sel = last;
-    info[0] = last + 1;
-    info[1] = st->n[0];
-    info[2] = st->n[1];
-    info[3] = 0;
+    sel[p] = last;
+    info[4 * p] = last + 1;
+    info[4 * p + 1] = st->n[0];
+    info[4 * p + 2] = st->n[1];
+    info[4 * p + 3] = 0;
     st->active = 1;  // the assignment stage always runs
 }
 
-hipError_t launch_lg_select_layer(LGState* st, int n_layers, int* sel, int* info, hipStream_t s) {
-    hipLaunchKernelGGL(lg_select_layer_kernel, dim3(1), dim3(1), 0, s, st, n_layers, sel, info);
+hipError_t launch_lg_select_layer(LGState* st, int n_pairs, int n_layers, int* sel, int* info, hipStream_t s) {
+    hipLaunchKernelGGL(lg_select_layer_kernel, dim3(1), dim3(64), 0, s, st, n_pairs, n_layers, sel, info);
     return hipGetLastError();
 }
 
@@ -302,6 +311,19 @@ hipError_t launch_lg_select_layer(LGState* st, int n_layers, int* sel, int* info
 static constexpr int AS_ROWS = 16;       // rows per block (= per strip of the column partials)
 static constexpr int AS_CHUNK = 1024;    // columns a wave takes per pass: 4 x (64 lanes x float4)
 static constexpr float AS_NEG = -3.0e38f;  // stands in for -inf on masked entries (finite: no inf - inf in the online merges)
+
+// the arguments of pair `pr` of a batch (blockIdx.y of every assignment kernel): every buffer is laid out [pair][...]
+__device__ __forceinline__ AssignArgs for_pair(AssignArgs a, int pr) {
+    a.sim += (long)pr * a.sim_ps;
+    a.m_ptr += (long)pr * a.state_ps; a.n_ptr += (long)pr * a.state_ps;
+    if (a.lz0) { a.lz0 += (long)pr * a.lz_ps; a.lz1 += (long)pr * a.lz_ps; }
+    a.rmax += (long)pr * a.vec_ps; a.rlog += (long)pr * a.vec_ps; a.cmax += (long)pr * a.vec_ps; a.clog += (long)pr * a.vec_ps;
+    a.ridx += (long)pr * a.vec_ps; a.rval += (long)pr * a.vec_ps; a.cbest += (long)pr * a.vec_ps;
+    a.part += (long)pr * a.part_ps;
+    if (a.ind0) { a.ind0 += (long)pr * a.out_ps; a.ind1 += (long)pr * a.out_ps; }
+    a.out_m0 += (long)pr * a.out_ps; a.out_m1 += (long)pr * a.out_ps; a.out_s0 += (long)pr * a.out_ps; a.out_s1 += (long)pr * a.out_ps;
+    return a;
+}
 
 // 16 values of row `p` (chunk base c0): columns c0 + q * 256 + lane * 4 + e; entries >= n read as AS_NEG
 template <bool VEC>
@@ -325,11 +347,14 @@ __device__ __forceinline__ void load_row16(const float* __restrict__ p, int c0, 
 __device__ __forceinline__ float fexp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
 
 template <bool VEC>
-__global__ __launch_bounds__(256) void lse_stats_kernel(const float* __restrict__ sim, int ld, const int* __restrict__ m_ptr,
-                                                         const int* __restrict__ n_ptr, float* __restrict__ rmax, float* __restrict__ rlog,
-                                                         float2* __restrict__ cpart, int kmax) {
+__global__ __launch_bounds__(256) void lse_stats_kernel(AssignArgs aa) {
     __shared__ float2 rs[AS_ROWS][4];
-    const int m = *m_ptr, n = *n_ptr;
+    const AssignArgs a = for_pair(aa, blockIdx.y);
+    const float* __restrict__ sim = a.sim;
+    const int ld = a.ld, kmax = a.n_max;
+    float* __restrict__ rmax = a.rmax; float* __restrict__ rlog = a.rlog;
+    float2* __restrict__ cpart = a.part;
+    const int m = *a.m_ptr, n = *a.n_ptr;
     const int i0 = blockIdx.x * AS_ROWS;
     if (i0 >= m || n <= 0) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -404,11 +429,13 @@ __global__ __launch_bounds__(256) void lse_stats_kernel(const float* __restrict_
 // column normalisers from the strip partials: 32 columns x 8 strip groups per block, loads issued eight at a time
 static constexpr int CC_COLS = 32, CC_GROUPS = 8;
 
-__global__ __launch_bounds__(256) void col_lse_combine_kernel(const float2* __restrict__ cpart, int kmax, const int* __restrict__ m_ptr,
-                                                               const int* __restrict__ n_ptr, float* __restrict__ cmax,
-                                                               float* __restrict__ clog) {
+__global__ __launch_bounds__(256) void col_lse_combine_kernel(AssignArgs aa) {
     __shared__ float2 red[CC_GROUPS][CC_COLS];
-    const int m = *m_ptr, n = *n_ptr;
+    const AssignArgs a = for_pair(aa, blockIdx.y);
+    const float2* __restrict__ cpart = a.part;
+    const int kmax = a.n_max;
+    float* __restrict__ cmax = a.cmax; float* __restrict__ clog = a.clog;
+    const int m = *a.m_ptr, n = *a.n_ptr;
     const int c = threadIdx.x & (CC_COLS - 1), g = threadIdx.x / CC_COLS;
     const int j = blockIdx.x * CC_COLS + c;
     if (blockIdx.x * CC_COLS >= n) return;
@@ -449,7 +476,7 @@ __global__ __launch_bounds__(256) void col_lse_combine_kernel(const float2* __re
 __global__ __launch_bounds__(256) void logsig_kernel(const float* __restrict__ z, long bstride, const LGState* __restrict__ st,
                                                       float* __restrict__ lz) {
     const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
-    if (i < st->n[b]) lz[(long)b * bstride + i] = log_sigmoid(z[(long)b * bstride + i]);
+    if (i < st[b >> 1].n[b & 1]) lz[(long)b * bstride + i] = log_sigmoid(z[(long)b * bstride + i]);
 }
 
 // MODE 0 (LightGlue): score = log_softmax_row + log_softmax_col + certainties
@@ -463,16 +490,19 @@ __device__ __forceinline__ float assign_score(float x, float rm, float rl, float
 // One sweep: row arg-max (first column among ties: torch.max semantics) complete per block; per-strip column arg-max keys
 // (ordered score bits, ~row): a larger key = a larger score or, at equal score, a lower row.
 template <int MODE, bool VEC>
-__global__ __launch_bounds__(256) void best_sweep_kernel(const float* __restrict__ sim, int ld, const int* __restrict__ m_ptr,
-                                                          const int* __restrict__ n_ptr, const float* __restrict__ rmax,
-                                                          const float* __restrict__ rlog, const float* __restrict__ cmax,
-                                                          const float* __restrict__ clog, const float* __restrict__ lz0,
-                                                          const float* __restrict__ lz1, int* __restrict__ ridx, float* __restrict__ rval,
-                                                          unsigned long long* __restrict__ cbpart, int kmax) {
+__global__ __launch_bounds__(256) void best_sweep_kernel(AssignArgs aa) {
     __shared__ float rb_v[AS_ROWS][4];
     __shared__ int rb_j[AS_ROWS][4];
     __shared__ float sh_rm[AS_ROWS], sh_rl[AS_ROWS], sh_l0[AS_ROWS];
-    const int m = *m_ptr, n = *n_ptr;
+    const AssignArgs a = for_pair(aa, blockIdx.y);
+    const float* __restrict__ sim = a.sim;
+    const int ld = a.ld, kmax = a.n_max;
+    const float* __restrict__ rmax = a.rmax; const float* __restrict__ rlog = a.rlog;
+    const float* __restrict__ cmax = a.cmax; const float* __restrict__ clog = a.clog;
+    const float* __restrict__ lz0 = a.lz0; const float* __restrict__ lz1 = a.lz1;
+    int* __restrict__ ridx = a.ridx; float* __restrict__ rval = a.rval;
+    unsigned long long* __restrict__ cbpart = reinterpret_cast<unsigned long long*>(a.part);
+    const int m = *a.m_ptr, n = *a.n_ptr;
     const int i0 = blockIdx.x * AS_ROWS;
     if (i0 >= m || n <= 0) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -565,11 +595,13 @@ __global__ __launch_bounds__(256) void best_sweep_kernel(const float* __restrict
     }
 }
 
-__global__ __launch_bounds__(256) void col_best_combine_kernel(const unsigned long long* __restrict__ cbpart, int kmax,
-                                                                const int* __restrict__ m_ptr, const int* __restrict__ n_ptr,
-                                                                unsigned long long* __restrict__ cbest) {
+__global__ __launch_bounds__(256) void col_best_combine_kernel(AssignArgs aa) {
     __shared__ unsigned long long red[CC_GROUPS][CC_COLS];
-    const int m = *m_ptr, n = *n_ptr;
+    const AssignArgs a = for_pair(aa, blockIdx.y);
+    const unsigned long long* __restrict__ cbpart = reinterpret_cast<const unsigned long long*>(a.part);
+    const int kmax = a.n_max;
+    unsigned long long* __restrict__ cbest = a.cbest;
+    const int m = *a.m_ptr, n = *a.n_ptr;
     const int c = threadIdx.x & (CC_COLS - 1), g = threadIdx.x / CC_COLS;
     const int j = blockIdx.x * CC_COLS + c;
     if (blockIdx.x * CC_COLS >= n) return;
@@ -597,14 +629,16 @@ __global__ __launch_bounds__(256) void col_best_combine_kernel(const unsigned lo
 }
 
 // mutual check + threshold (`filter_matches`), then scatter to the original index space (`lightglue.py:528-539`)
-__global__ __launch_bounds__(256) void filter_scatter_kernel(const int* __restrict__ m_ptr, const int* __restrict__ n_ptr,
-                                                              const int* __restrict__ ridx, const float* __restrict__ rval,
-                                                              const unsigned long long* __restrict__ cbest, float th,
-                                                              const int* __restrict__ ind0, const int* __restrict__ ind1,
-                                                              int* __restrict__ out_m0, int* __restrict__ out_m1,
-                                                              float* __restrict__ out_s0, float* __restrict__ out_s1) {
+__global__ __launch_bounds__(256) void filter_scatter_kernel(AssignArgs aa) {
+    const AssignArgs a = for_pair(aa, blockIdx.z);
+    const int* __restrict__ ridx = a.ridx; const float* __restrict__ rval = a.rval;
+    const unsigned long long* __restrict__ cbest = a.cbest;
+    const float th = a.threshold;
+    const int* __restrict__ ind0 = a.ind0; const int* __restrict__ ind1 = a.ind1;
+    int* __restrict__ out_m0 = a.out_m0; int* __restrict__ out_m1 = a.out_m1;
+    float* __restrict__ out_s0 = a.out_s0; float* __restrict__ out_s1 = a.out_s1;
     const int t = blockIdx.x * 256 + threadIdx.x;
-    const int m = *m_ptr, n = *n_ptr;
+    const int m = *a.m_ptr, n = *a.n_ptr;
     if (m <= 0 || n <= 0) return;  // outputs keep their -1 / 0 initialisation (`superglue.py:255-262`)
     auto col_of = [&](int j) { return (int)(0xFFFFFFFFu - (unsigned)(cbest[j] & 0xFFFFFFFFull)); };
     if (blockIdx.y == 0) {
@@ -645,28 +679,23 @@ hipError_t launch_zero_words(void* p, long nwords, hipStream_t s) {
 }
 
 hipError_t launch_assign(const AssignArgs& a, hipStream_t s) {
-    const int kr = a.m_max, kc = a.n_max;
+    const int kr = a.m_max, kc = a.n_max, P = a.n_pairs > 0 ? a.n_pairs : 1;
     const int nstrips = (kr + AS_ROWS - 1) / AS_ROWS;
-    const bool vec = (a.ld % 4) == 0 && (reinterpret_cast<uintptr_t>(a.sim) % 16) == 0;
-    unsigned long long* cbpart = reinterpret_cast<unsigned long long*>(a.part);      // the strip partials of both sweeps share one buffer
+    const bool vec = (a.ld % 4) == 0 && (reinterpret_cast<uintptr_t>(a.sim) % 16) == 0 && (a.sim_ps % 4) == 0;
+    const dim3 gs(nstrips, P), gc((kc + CC_COLS - 1) / CC_COLS, P);
     if (a.mode == 0) {
-        if (vec) hipLaunchKernelGGL(lse_stats_kernel<true>, dim3(nstrips), dim3(256), 0, s, a.sim, a.ld, a.m_ptr, a.n_ptr, a.rmax, a.rlog, a.part, kc);
-        else hipLaunchKernelGGL(lse_stats_kernel<false>, dim3(nstrips), dim3(256), 0, s, a.sim, a.ld, a.m_ptr, a.n_ptr, a.rmax, a.rlog, a.part, kc);
-        hipLaunchKernelGGL(col_lse_combine_kernel, dim3((kc + CC_COLS - 1) / CC_COLS), dim3(256), 0, s, a.part, kc, a.m_ptr, a.n_ptr, a.cmax, a.clog);
-        if (vec) hipLaunchKernelGGL((best_sweep_kernel<0, true>), dim3(nstrips), dim3(256), 0, s, a.sim, a.ld, a.m_ptr, a.n_ptr, a.rmax, a.rlog, a.cmax,
-                                    a.clog, a.lz0, a.lz1, a.ridx, a.rval, cbpart, kc);
-        else hipLaunchKernelGGL((best_sweep_kernel<0, false>), dim3(nstrips), dim3(256), 0, s, a.sim, a.ld, a.m_ptr, a.n_ptr, a.rmax, a.rlog, a.cmax,
-                                a.clog, a.lz0, a.lz1, a.ridx, a.rval, cbpart, kc);
+        if (vec) hipLaunchKernelGGL(lse_stats_kernel<true>, gs, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(lse_stats_kernel<false>, gs, dim3(256), 0, s, a);
+        hipLaunchKernelGGL(col_lse_combine_kernel, gc, dim3(256), 0, s, a);
+        if (vec) hipLaunchKernelGGL((best_sweep_kernel<0, true>), gs, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((best_sweep_kernel<0, false>), gs, dim3(256), 0, s, a);
     } else {  // optimal transport: rmax = u, cmax = v, rlog[0] = norm were produced by the Sinkhorn sweeps
-        if (vec) hipLaunchKernelGGL((best_sweep_kernel<1, true>), dim3(nstrips), dim3(256), 0, s, a.sim, a.ld, a.m_ptr, a.n_ptr, a.rmax, a.rlog, a.cmax,
-                                    a.clog, a.lz0, a.lz1, a.ridx, a.rval, cbpart, kc);
-        else hipLaunchKernelGGL((best_sweep_kernel<1, false>), dim3(nstrips), dim3(256), 0, s, a.sim, a.ld, a.m_ptr, a.n_ptr, a.rmax, a.rlog, a.cmax,
-                                a.clog, a.lz0, a.lz1, a.ridx, a.rval, cbpart, kc);
+        if (vec) hipLaunchKernelGGL((best_sweep_kernel<1, true>), gs, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((best_sweep_kernel<1, false>), gs, dim3(256), 0, s, a);
     }
-    hipLaunchKernelGGL(col_best_combine_kernel, dim3((kc + CC_COLS - 1) / CC_COLS), dim3(256), 0, s, cbpart, kc, a.m_ptr, a.n_ptr, a.cbest);
+    hipLaunchKernelGGL(col_best_combine_kernel, gc, dim3(256), 0, s, a);
     const int kk = kr > kc ? kr : kc;
-    hipLaunchKernelGGL(filter_scatter_kernel, dim3((kk + 255) / 256, 2), dim3(256), 0, s, a.m_ptr, a.n_ptr, a.ridx, a.rval, a.cbest,
-                       a.threshold, a.ind0, a.ind1, a.out_m0, a.out_m1, a.out_s0, a.out_s1);
+    hipLaunchKernelGGL(filter_scatter_kernel, dim3((kk + 255) / 256, 2, P), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
@@ -676,6 +705,10 @@ __global__ __launch_bounds__(256) void pack_record_kernel(const int* __restrict_
                                                            const float* __restrict__ mscores0, const int* __restrict__ info,
                                                            int epoch, int K, int* __restrict__ rec) {
     __shared__ int red[4];
+    {   // pair blockIdx.x of a batch: n [2P], matches / scores [2P][K] (row 2p = matches0 of pair p), info [P][4], rec [P][8 + 2K]
+        const int p = blockIdx.x;
+        n += 2 * p; matches0 += (long)2 * p * K; mscores0 += (long)2 * p * K; info += 4 * p; rec += (long)p * (8 + 2 * K); epoch += p;
+    }
     int cnt = 0;
     for (int i = threadIdx.x; i < K; i += 256) {
         const int m = matches0[i];
@@ -693,13 +726,13 @@ __global__ __launch_bounds__(256) void pack_record_kernel(const int* __restrict_
 }
 
 hipError_t launch_pack_record(const int* n, const int* matches0, const float* mscores0, const int* info, int epoch, int K,
-                              int* rec, hipStream_t s) {
-    hipLaunchKernelGGL(pack_record_kernel, dim3(1), dim3(256), 0, s, n, matches0, mscores0, info, epoch, K, rec);
+                              int* rec, int n_pairs, hipStream_t s) {
+    hipLaunchKernelGGL(pack_record_kernel, dim3(n_pairs), dim3(256), 0, s, n, matches0, mscores0, info, epoch, K, rec);
     return hipGetLastError();
 }
 
-hipError_t launch_logsig(const float* z, long bstride, const LGState* st, int n_max, float* lz, hipStream_t s) {
-    hipLaunchKernelGGL(logsig_kernel, dim3((n_max + 255) / 256, 2), dim3(256), 0, s, z, bstride, st, lz);
+hipError_t launch_logsig(const float* z, long bstride, const LGState* st, int n_images, int n_max, float* lz, hipStream_t s) {
+    hipLaunchKernelGGL(logsig_kernel, dim3((n_max + 255) / 256, n_images), dim3(256), 0, s, z, bstride, st, lz);
     return hipGetLastError();
 }
 

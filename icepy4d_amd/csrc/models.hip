@@ -305,28 +305,34 @@ int im_ctx_reserve(im_ctx* ctx, int max_h, int max_w, int max_images, int max_kp
     A(ws->kpsel.keys, (size_t)B * H8 * W8);
     A(ws->kpsel.ties, (size_t)B * H8 * W8);
     A(ws->kpsel.chosen, (size_t)B * K);
+    // matcher buffers: NP pairs = 2 NP images side by side (batch over pairs: one launch serves every pair)
+    const size_t NP = (size_t)(B + 1) / 2, NI = 2 * NP;
     for (int i = 0; i < 2; ++i) {
-        A(ws->x[i], (size_t)2 * K * 256);
-        A(ws->cs[i], (size_t)2 * K * 32);
-        A(ws->sn[i], (size_t)2 * K * 32);
-        A(ws->ind[i], (size_t)2 * K);
+        A(ws->x[i], NI * K * 256);
+        A(ws->cs[i], NI * K * 32);
+        A(ws->sn[i], NI * K * 32);
+        A(ws->ind[i], NI * K);
     }
-    A(ws->q, (size_t)2 * K * 256); A(ws->k, (size_t)2 * K * 256); A(ws->v, (size_t)2 * K * 256);
-    A(ws->att, (size_t)2 * K * 256); A(ws->msg, (size_t)2 * K * 256); A(ws->h, (size_t)2 * K * 512);
-    A(ws->attn_part, attn_part_floats((int)K, 2, 4)); A(ws->attn_cnt, attn_counter_ints((int)K, 2, 4));
+    A(ws->q, NI * K * 256); A(ws->k, NI * K * 256); A(ws->v, NI * K * 256);
+    A(ws->att, NI * K * 256); A(ws->msg, NI * K * 256); A(ws->h, NI * K * 512);
+    A(ws->attn_part, attn_part_floats((int)K, (int)NI, 4)); A(ws->attn_cnt, attn_counter_ints((int)K, (int)NI, 4));
     if (getenv("IM_ATTN_BF16X3")) {   // experiment, opt-in: planes for the bf16 x 3 attention
-        const size_t xe = attn_x3_plane_elems((int)K, 2, 4);
+        const size_t xe = attn_x3_plane_elems((int)K, (int)NI, 4);
         A(ws->x3_q, xe); A(ws->x3_k, xe); A(ws->x3_vt, xe);
     }
-    A(ws->conf, (size_t)2 * K); A(ws->msc, (size_t)2 * K); A(ws->keep_idx, (size_t)2 * K); A(ws->prune, (size_t)2 * K);
-    A(ws->md, (size_t)2 * K * 256); A(ws->z, (size_t)2 * K); A(ws->lz, (size_t)2 * K);
-    A(ws->sim, (size_t)(K + 1) * (K + 1));
+    A(ws->conf, NI * K); A(ws->msc, NI * K); A(ws->keep_idx, NI * K); A(ws->prune, NI * K);
+    A(ws->md, NI * K * 256); A(ws->z, NI * K); A(ws->lz, NI * K);
+    ws->sim_ps = (((size_t)K * K + (size_t)K + 4) + 3) & ~(size_t)3;     // floats between the score matrices of consecutive pairs
+    ws->vec_ps = ((size_t)K + 4 + 3) & ~(size_t)3;
+    ws->part_ps = (size_t)((K + 15) / 16 + 1) * (K + 4);
+    A(ws->sim, NP * ws->sim_ps + (size_t)K + 8);
     A(ws->sim2, (size_t)1);
-    A(ws->rmax, (size_t)K + 1); A(ws->rlog, (size_t)K + 1); A(ws->cmax, (size_t)K + 1); A(ws->clog, (size_t)K + 1);
-    A(ws->part, (size_t)((K + 15) / 16 + 1) * (K + 4));
-    A(ws->ridx, (size_t)K + 1); A(ws->rval, (size_t)K + 1); A(ws->cbest, (size_t)K + 1);
-    A(ws->st, (size_t)1); A(ws->sel, (size_t)4);
+    A(ws->rmax, NP * ws->vec_ps); A(ws->rlog, NP * ws->vec_ps); A(ws->cmax, NP * ws->vec_ps); A(ws->clog, NP * ws->vec_ps);
+    A(ws->part, NP * ws->part_ps);
+    A(ws->ridx, NP * ws->vec_ps); A(ws->rval, NP * ws->vec_ps); A(ws->cbest, NP * ws->vec_ps);
+    A(ws->st, NP); A(ws->sel, NP + 3);
     A(ws->uv, (size_t)4 * (K + 8));
+    ws->n_pairs = (int)NP;
     if (!ok) {
         for (void* p : ws->allocs) hipFree(p);
         delete ws;
@@ -334,9 +340,9 @@ int im_ctx_reserve(im_ctx* ctx, int max_h, int max_w, int max_images, int max_kp
     }
     ctx->ws = ws;
     ctx->max_h = max_h; ctx->max_w = max_w; ctx->max_images = max_images; ctx->max_kpts = max_kpts;
-    IM_HIP(ctx, hipMemset(ws->st, 0, sizeof(LGState)));
-    IM_HIP(ctx, hipMemset(ws->sel, 0, 4 * sizeof(int)));
-    IM_HIP(ctx, hipMemset(ws->attn_cnt, 0, attn_counter_ints((int)K, 2, 4) * sizeof(int)));
+    IM_HIP(ctx, hipMemset(ws->st, 0, sizeof(LGState) * NP));
+    IM_HIP(ctx, hipMemset(ws->sel, 0, (NP + 3) * sizeof(int)));
+    IM_HIP(ctx, hipMemset(ws->attn_cnt, 0, attn_counter_ints((int)K, (int)NI, 4) * sizeof(int)));
     IM_HIP(ctx, hipDeviceSynchronize());
     return 0;
 }
@@ -417,7 +423,9 @@ int im_superpoint_candidates(im_ctx* ctx, int n_images, int32_t* h_counts, void*
 }
 
 // ------------------------------------------------------------------------------------------------ LightGlue
-static int lg_block(im_ctx* ctx, hipStream_t s, int layer, bool cross, float* x, const float* cs, const float* sn) {
+static constexpr int ST_INTS = (int)(sizeof(LGState) / sizeof(int));   // ints between the states of consecutive pairs
+
+static int lg_block(im_ctx* ctx, hipStream_t s, int NI, int layer, bool cross, float* x, const float* cs, const float* sn) {
     Workspace* ws = ctx->ws;
     const LightGlueW& W = ctx->lg;
     const int K = ctx->max_kpts;
@@ -425,10 +433,10 @@ static int lg_block(im_ctx* ctx, hipStream_t s, int layer, bool cross, float* x,
     const int* n_ptr = ws->st->n;
     const int* active = &ws->st->active;
     GemmArgs base;
-    base.m_max = K; base.m_ptr = n_ptr; base.active = active; base.batch = 2;
+    base.m_max = K; base.m_ptr = n_ptr; base.active = active; base.pstride = ST_INTS; base.batch = NI;
     AttnArgs at;
     at.q = ws->q; at.k = cross ? ws->q : ws->k; at.v = ws->v; at.hstride = (long)K * 64; at.bstride = (long)K * 256;
-    at.out = ws->att; at.out_bstride = xb; at.ldo = 256; at.n_ptr = n_ptr; at.n_max = K; at.batch = 2; at.heads = 4;
+    at.out = ws->att; at.out_bstride = xb; at.ldo = 256; at.n_ptr = n_ptr; at.pstride = ST_INTS; at.n_max = K; at.batch = NI; at.heads = 4;
     at.cross = cross ? 1 : 0; at.active = active; at.part = ws->attn_part; at.counters = ws->attn_cnt;
     if (!cross) {
         GemmArgs g = base;
@@ -461,8 +469,8 @@ static int lg_block(im_ctx* ctx, hipStream_t s, int layer, bool cross, float* x,
         g.C = ws->h; g.c_bstride = (long)K * 512; g.ldc = 512; g.epi = EPI_BIAS;
         IM_LAUNCH(ctx, "lg_ffn0_gemm", s, launch_gemm(g, s));
     }
-    IM_LAUNCH(ctx, "lg_layernorm_gelu", s, launch_layernorm_gelu(ws->h, (long)K * 512, n_ptr, K, (cross ? W.cln_g : W.sln_g) + (long)layer * 512,
-                                                               (cross ? W.cln_b : W.sln_b) + (long)layer * 512, active, s));
+    IM_LAUNCH(ctx, "lg_layernorm_gelu", s, launch_layernorm_gelu(ws->h, (long)K * 512, ws->st, NI, K, (cross ? W.cln_g : W.sln_g) + (long)layer * 512,
+                                                               (cross ? W.cln_b : W.sln_b) + (long)layer * 512, s));
     {   // x += ffn.3(h)
         GemmArgs g = base;
         g.A = ws->h; g.a_bstride = (long)K * 512; g.lda = 512;
@@ -474,67 +482,69 @@ static int lg_block(im_ctx* ctx, hipStream_t s, int layer, bool cross, float* x,
     return 0;
 }
 
-int im_lightglue_forward(im_ctx* ctx, const float* d_kpts, const float* d_desc, const int32_t* d_n, const float* h_size,
-                         const im_lightglue_conf* conf, int32_t* d_matches, float* d_mscores, int32_t* d_prune,
-                         int32_t* d_info, void* stream) {
+static int lightglue_forward(im_ctx* ctx, int n_pairs, const float* d_kpts, const float* d_desc, const int32_t* d_n, const float* h_size,
+                             const im_lightglue_conf* conf, int32_t* d_matches, float* d_mscores, int32_t* d_prune, int32_t* d_info,
+                             void* stream) {
     IM_CHECK_CTX(ctx);
     if (!ctx->lg.ready) return ctx->fail(-50, "im_lightglue_forward: weights not finalized");
     Workspace* ws = ctx->ws;
     if (!ws) return ctx->fail(-51, "im_lightglue_forward: call im_ctx_reserve first");
+    if (n_pairs < 1 || n_pairs > ws->n_pairs || n_pairs > 64)
+        return ctx->fail(-53, "im_lightglue_forward: %d pairs, the workspace was reserved for %d (max_images / 2)", n_pairs, ws->n_pairs);
     hipStream_t s = (hipStream_t)stream;
     const LightGlueW& W = ctx->lg;
     const int K = ctx->max_kpts;
     const int L = conf->n_layers;
+    const int NP = n_pairs, NI = 2 * n_pairs;
     if (L < 1 || L > 9) return ctx->fail(-52, "im_lightglue_forward: n_layers must be 1..9");
     const bool do_stop = conf->depth_confidence > 0, do_prune = conf->width_confidence > 0;
     const long xb = (long)K * 256, eb = (long)K * 32;
     LGState* st = ws->st;
 
-    IM_HIP(ctx, launch_lg_init(st, d_n, ws->ind[0], ws->prune, K, K, d_matches, d_mscores, K, s));
-    IM_HIP(ctx, hipMemcpyAsync(ws->x[0], d_desc, sizeof(float) * 2 * xb, hipMemcpyDeviceToDevice, s));
-    IM_HIP(ctx, launch_posenc(d_kpts, (long)K * 2, st->n, K, W.wr, h_size, ws->cs[0], ws->sn[0], eb, s));
+    IM_HIP(ctx, launch_lg_init(st, NI, d_n, ws->ind[0], ws->prune, K, K, d_matches, d_mscores, K, s));
+    IM_HIP(ctx, hipMemcpyAsync(ws->x[0], d_desc, sizeof(float) * NI * xb, hipMemcpyDeviceToDevice, s));
+    IM_HIP(ctx, launch_posenc(d_kpts, (long)K * 2, st, NI, K, W.wr, h_size, ws->cs[0], ws->sn[0], eb, s));
     int cur = 0;
     for (int i = 0; i < L; ++i) {
-        int rc = lg_block(ctx, s, i, false, ws->x[cur], ws->cs[cur], ws->sn[cur]);
+        int rc = lg_block(ctx, s, NI, i, false, ws->x[cur], ws->cs[cur], ws->sn[cur]);
         if (rc) return rc;
-        rc = lg_block(ctx, s, i, true, ws->x[cur], ws->cs[cur], ws->sn[cur]);
+        rc = lg_block(ctx, s, NI, i, true, ws->x[cur], ws->cs[cur], ws->sn[cur]);
         if (rc) return rc;
         if (i == L - 1) break;
         if (!do_stop && !do_prune) continue;
-        IM_LAUNCH(ctx, "lg_adapt", s, launch_rowdot(ws->x[cur], xb, st->n, K, do_stop ? W.tc_w + (long)i * 256 : nullptr, W.tc_b + i, 1,
+        IM_LAUNCH(ctx, "lg_adapt", s, launch_rowdot(ws->x[cur], xb, st, NI, K, do_stop ? W.tc_w + (long)i * 256 : nullptr, W.tc_b + i, 1,
                                   do_prune ? W.ma_w + (long)i * 256 : nullptr, W.ma_b + i, nullptr, ws->conf, ws->msc, K,
-                                  W.thr[i], do_stop ? &st->cnt[i] : nullptr, &st->active, s));
+                                  W.thr[i], do_stop ? i : -1, 1, s));
         // keep threshold: `scores > (1 - width_confidence)` evaluated in double, compared in fp32 (`lightglue.py:566`)
         const float keep_thr = (float)(1.0 - (double)conf->width_confidence);
-        IM_LAUNCH(ctx, "lg_adapt", s, launch_stop_prune(st, i, do_stop, do_prune, (float)conf->depth_confidence, keep_thr, W.thr[i], ws->conf,
+        IM_LAUNCH(ctx, "lg_adapt", s, launch_stop_prune(st, NP, i, do_stop, do_prune, (float)conf->depth_confidence, keep_thr, W.thr[i], ws->conf,
                                                       ws->msc, K, ws->ind[cur], ws->ind[1 - cur], ws->keep_idx, ws->prune, K,
                                                       conf->pruning_min_kpts, s));
         if (do_prune) {
-            IM_LAUNCH(ctx, "lg_adapt", s, launch_gather_rows(st, K, ws->keep_idx, K, ws->x[cur], ws->x[1 - cur], xb, ws->cs[cur], ws->cs[1 - cur],
+            IM_LAUNCH(ctx, "lg_adapt", s, launch_gather_rows(st, NI, K, ws->keep_idx, K, ws->x[cur], ws->x[1 - cur], xb, ws->cs[cur], ws->cs[1 - cur],
                                                            ws->sn[cur], ws->sn[1 - cur], eb, s));
             cur = 1 - cur;
         }
     }
     ctx->dbg_cur = cur;
-    // ---- assignment with log_assignment[last executed layer]
-    IM_HIP(ctx, launch_lg_select_layer(st, L, ws->sel, d_info, s));
+    // ---- assignment with log_assignment[last executed layer] (per pair: a device-side layer index)
+    IM_HIP(ctx, launch_lg_select_layer(st, NP, L, ws->sel, d_info, s));
     {
         GemmArgs g;
-        g.m_max = K; g.m_ptr = st->n; g.batch = 2;
+        g.m_max = K; g.m_ptr = st->n; g.pstride = ST_INTS; g.batch = NI;
         g.A = ws->x[cur]; g.a_bstride = xb; g.lda = 256; g.W = W.fp_w; g.ldw = 256; g.bias = W.fp_b;
         g.sel = ws->sel; g.w_sel_stride = 65536; g.bias_sel_stride = 256; g.N = 256; g.K = 256;
         g.C = ws->md; g.c_bstride = xb; g.ldc = 256; g.alpha = 0.25f;  // / 256**0.25 (`lightglue.py:279`)
         g.epi = EPI_BIAS;
         IM_LAUNCH(ctx, "lg_proj_gemm", s, launch_gemm(g, s));
     }
-    IM_HIP(ctx, launch_rowdot(ws->x[cur], xb, st->n, K, W.ma_w, W.ma_b, 0, nullptr, nullptr, ws->sel, ws->z, nullptr, K, 0.f,
-                              nullptr, nullptr, s));
-    IM_HIP(ctx, launch_logsig(ws->z, K, st, K, ws->lz, s));
-    {
+    IM_HIP(ctx, launch_rowdot(ws->x[cur], xb, st, NI, K, W.ma_w, W.ma_b, 0, nullptr, nullptr, ws->sel, ws->z, nullptr, K, 0.f, -1, 0, s));
+    IM_HIP(ctx, launch_logsig(ws->z, K, st, NI, K, ws->lz, s));
+    {   // one score matrix per pair: md of image 2p against md of image 2p + 1
         GemmArgs g;
-        g.m_max = K; g.m_ptr = &st->n[0]; g.n_ptr = &st->n[1]; g.batch = 1;
-        g.A = ws->md; g.lda = 256; g.W = ws->md + xb; g.ldw = 256; g.N = K; g.K = 256;
-        g.C = ws->sim; g.ldc = K; g.epi = EPI_BIAS; g.big_tile = 1;
+        g.m_max = K; g.m_ptr = &st->n[0]; g.n_ptr = &st->n[1]; g.pstride = ST_INTS; g.pair_batched = 1; g.batch = NP;
+        g.A = ws->md; g.a_bstride = 2 * xb; g.lda = 256; g.W = ws->md + xb; g.w_bstride = 2 * xb; g.ldw = 256; g.N = K; g.K = 256;
+        g.C = ws->sim; g.c_bstride = (long)ws->sim_ps; g.ldc = K; g.epi = EPI_BIAS; g.big_tile = 1;
         IM_LAUNCH(ctx, "score_gemm", s, launch_gemm(g, s));
     }
     AssignArgs a;
@@ -544,16 +554,38 @@ int im_lightglue_forward(im_ctx* ctx, const float* d_kpts, const float* d_desc, 
     a.ridx = ws->ridx; a.rval = ws->rval; a.cbest = ws->cbest; a.threshold = (float)conf->filter_threshold;
     a.ind0 = ws->ind[cur]; a.ind1 = ws->ind[cur] + K;
     a.out_m0 = d_matches; a.out_m1 = d_matches + K; a.out_s0 = d_mscores; a.out_s1 = d_mscores + K;
+    a.n_pairs = NP; a.sim_ps = (long)ws->sim_ps; a.vec_ps = (long)ws->vec_ps; a.part_ps = (long)ws->part_ps; a.lz_ps = 2L * K;
+    a.out_ps = 2L * K; a.state_ps = ST_INTS;
     IM_LAUNCH(ctx, "assign", s, launch_assign(a, s));
-    IM_HIP(ctx, hipMemcpyAsync(d_prune, ws->prune, sizeof(int) * 2 * K, hipMemcpyDeviceToDevice, s));
+    IM_HIP(ctx, hipMemcpyAsync(d_prune, ws->prune, sizeof(int) * NI * K, hipMemcpyDeviceToDevice, s));
     return 0;
+}
+
+int im_lightglue_forward(im_ctx* ctx, const float* d_kpts, const float* d_desc, const int32_t* d_n, const float* h_size,
+                         const im_lightglue_conf* conf, int32_t* d_matches, float* d_mscores, int32_t* d_prune,
+                         int32_t* d_info, void* stream) {
+    return lightglue_forward(ctx, 1, d_kpts, d_desc, d_n, h_size, conf, d_matches, d_mscores, d_prune, d_info, stream);
+}
+
+int im_lightglue_forward_pairs(im_ctx* ctx, int n_pairs, const float* d_kpts, const float* d_desc, const int32_t* d_n, const float* h_size,
+                               const im_lightglue_conf* conf, int32_t* d_matches, float* d_mscores, int32_t* d_prune,
+                               int32_t* d_info, void* stream) {
+    return lightglue_forward(ctx, n_pairs, d_kpts, d_desc, d_n, h_size, conf, d_matches, d_mscores, d_prune, d_info, stream);
 }
 
 int im_pack_record(im_ctx* ctx, const int32_t* d_n, const int32_t* d_matches0, const float* d_mscores0, const int32_t* d_info,
                    int epoch, int32_t* d_record, void* stream) {
     IM_CHECK_CTX(ctx);
     if (!ctx->ws) return ctx->fail(-51, "im_pack_record: call im_ctx_reserve first");
-    IM_HIP(ctx, launch_pack_record(d_n, d_matches0, d_mscores0, d_info, epoch, ctx->max_kpts, d_record, (hipStream_t)stream));
+    IM_HIP(ctx, launch_pack_record(d_n, d_matches0, d_mscores0, d_info, epoch, ctx->max_kpts, d_record, 1, (hipStream_t)stream));
+    return 0;
+}
+
+int im_pack_records(im_ctx* ctx, int n_pairs, const int32_t* d_n, const int32_t* d_matches, const float* d_mscores, const int32_t* d_info,
+                    int first_epoch, int32_t* d_records, void* stream) {
+    IM_CHECK_CTX(ctx);
+    if (!ctx->ws || n_pairs < 1) return ctx->fail(-51, "im_pack_records: call im_ctx_reserve first");
+    IM_HIP(ctx, launch_pack_record(d_n, d_matches, d_mscores, d_info, first_epoch, ctx->max_kpts, d_records, n_pairs, (hipStream_t)stream));
     return 0;
 }
 
@@ -572,7 +604,7 @@ int im_debug_read(im_ctx* ctx, const char* name, float* d_dst, size_t nfloats, v
     if (nm == "lg_x") { src = ws->x[ctx->dbg_cur]; avail = 2 * K * 256; }
     else if (nm == "lg_cos") { src = ws->cs[ctx->dbg_cur]; avail = 2 * K * 32; }
     else if (nm == "lg_sin") { src = ws->sn[ctx->dbg_cur]; avail = 2 * K * 32; }
-    else if (nm == "sim") { src = ws->sim; avail = K * K; }
+    else if (nm == "sim") { src = ws->sim; avail = K * K; }   // pair 0
     else if (nm == "md") { src = ws->md; avail = 2 * K * 256; }
     else if (nm == "sp_smap") { src = ws->smap; avail = (size_t)ctx->max_images * ((ctx->max_h / 8) * 8) * ((ctx->max_w / 8) * 8); }
     else if (nm == "sp_nms") { src = ws->nms; avail = (size_t)ctx->max_images * ((ctx->max_h / 8) * 8) * ((ctx->max_w / 8) * 8); }
@@ -625,13 +657,14 @@ int im_assign_from_sim(im_ctx* ctx, const float* d_sim, int m, int n, int ld, co
     IM_HIP(ctx, hipStreamSynchronize(s));
     IM_HIP(ctx, hipMemcpyAsync(ws->z, d_z0, sizeof(float) * m, hipMemcpyDeviceToDevice, s));
     IM_HIP(ctx, hipMemcpyAsync(ws->z + K, d_z1, sizeof(float) * n, hipMemcpyDeviceToDevice, s));
-    IM_HIP(ctx, launch_logsig(ws->z, K, ws->st, K, ws->lz, s));
+    IM_HIP(ctx, launch_logsig(ws->z, K, ws->st, 2, K, ws->lz, s));
     AssignArgs a;
     a.sim = d_sim; a.ld = ld; a.m_ptr = &ws->st->n[0]; a.n_ptr = &ws->st->n[1]; a.m_max = m; a.n_max = n;
     a.lz0 = ws->lz; a.lz1 = ws->lz + K;
     a.rmax = ws->rmax; a.rlog = ws->rlog; a.cmax = ws->cmax; a.clog = ws->clog; a.part = ws->part;
     a.ridx = ws->ridx; a.rval = ws->rval; a.cbest = ws->cbest; a.threshold = threshold;
     a.out_m0 = d_m0; a.out_m1 = d_m1; a.out_s0 = d_ms0; a.out_s1 = d_ms1;
+    a.n_pairs = 1;
     IM_HIP(ctx, launch_assign(a, s));
     return 0;
 }

@@ -315,10 +315,10 @@ int im_superglue_forward(im_ctx* ctx, const float* d_kpts, const float* d_scores
     if (L < 0 || L > 18) return ctx->fail(-52, "im_superglue_forward: n_layers must be 0..18");
     const long xb = (long)K * 256;
     LGState* st = ws->st;
-    IM_HIP(ctx, launch_lg_init(st, d_n, ws->ind[0], ws->prune, K, K, d_matches, d_mscores, K, s));
+    IM_HIP(ctx, launch_lg_init(st, 2, d_n, ws->ind[0], ws->prune, K, K, d_matches, d_mscores, K, s));
     float* x = ws->x[0];
     GemmArgs base;
-    base.m_max = K; base.m_ptr = st->n; base.batch = 2;
+    base.m_max = K; base.m_ptr = st->n; base.batch = 2;   // one pair: pstride is irrelevant for z < 2
     {   // keypoint encoder; the last layer adds the visual descriptors: x = desc + kenc(kpts, scores) (`superglue.py:269-270`)
         float* inp = ws->h;  // [2][K][32]
         const float4 shapes = make_float4(h_shape[0], h_shape[1], h_shape[2], h_shape[3]);
@@ -377,7 +377,7 @@ int im_superglue_forward(im_ctx* ctx, const float* d_kpts, const float* d_scores
         g.C = ws->md; g.c_bstride = xb; g.ldc = 256; g.epi = EPI_BIAS;
         IM_LAUNCH(ctx, "sg_proj_gemm", s, launch_gemm(g, s));
         GemmArgs sgm;
-        sgm.m_max = K; sgm.m_ptr = &st->n[0]; sgm.n_ptr = &st->n[1]; sgm.batch = 1;
+        sgm.m_max = K; sgm.m_ptr = &st->n[0]; sgm.n_ptr = &st->n[1]; sgm.batch = 1; sgm.pair_batched = 1;
         sgm.A = ws->md; sgm.lda = 256; sgm.W = ws->md + xb; sgm.ldw = 256; sgm.N = K; sgm.K = 256;
         sgm.C = ws->sim; sgm.ldc = K; sgm.alpha = 0.0625f;  // / 256 ** .5 (`superglue.py:280`)
         sgm.epi = EPI_BIAS; sgm.big_tile = 1;
@@ -400,12 +400,13 @@ int im_superglue_forward(im_ctx* ctx, const float* d_kpts, const float* d_scores
     }
     AssignArgs a;
     a.mode = 1;
+    a.n_pairs = 1;
     a.sim = ws->sim; a.ld = K; a.m_ptr = &st->n[0]; a.n_ptr = &st->n[1]; a.m_max = K; a.n_max = K;
     a.rmax = u; a.cmax = v; a.rlog = norm; a.clog = ws->clog; a.part = ws->part;
     a.ridx = ws->ridx; a.rval = ws->rval; a.cbest = ws->cbest; a.threshold = (float)conf->match_threshold;
     a.out_m0 = d_matches; a.out_m1 = d_matches + K; a.out_s0 = d_mscores; a.out_s1 = d_mscores + K;
     IM_LAUNCH(ctx, "assign", s, launch_assign(a, s));
-    IM_HIP(ctx, launch_lg_select_layer(st, 0, ws->sel, d_info, s));
+    IM_HIP(ctx, launch_lg_select_layer(st, 1, 0, ws->sel, d_info, s));
     return 0;
 }
 

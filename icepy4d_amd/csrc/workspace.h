@@ -32,4 +32,6 @@ struct Workspace {
     float2* part = nullptr; int* ridx = nullptr; float* rval = nullptr; unsigned long long* cbest = nullptr;
     im::LGState* st = nullptr; int* sel = nullptr;
     float* uv = nullptr;  // Sinkhorn potentials
+    int n_pairs = 1;      // pair capacity of the matcher buffers (reserved max_images / 2)
+    size_t sim_ps = 0, vec_ps = 0, part_ps = 0;   // element strides between consecutive pairs (score matrix, per-row vectors, strip partials)
 };

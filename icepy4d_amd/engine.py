@@ -89,10 +89,11 @@ class Engine:
         self.scores = torch.zeros(B, K, device=d)
         self.desc = torch.zeros(B, K, 256, device=d)
         self.n = torch.zeros(B, dtype=torch.int32, device=d)
-        self.matches = torch.zeros(2, K, dtype=torch.int32, device=d)
-        self.mscores = torch.zeros(2, K, device=d)
-        self.prune = torch.zeros(2, K, dtype=torch.int32, device=d)
-        self.info = torch.zeros(4, dtype=torch.int32, device=d)
+        NI = 2 * ((B + 1) // 2)          # matcher outputs: rows 2p, 2p + 1 = image 0 / 1 of pair p
+        self.matches = torch.zeros(NI, K, dtype=torch.int32, device=d)
+        self.mscores = torch.zeros(NI, K, device=d)
+        self.prune = torch.zeros(NI, K, dtype=torch.int32, device=d)
+        self.info = torch.zeros(NI // 2, 4, dtype=torch.int32, device=d)
 
     # ------------------------------------------------------------------ forwards (enqueue only)
     def superpoint(self, gray_u8: torch.Tensor, nms_radius: int = 4, threshold: float = 0.0005, border: int = 4,
@@ -121,18 +122,20 @@ class Engine:
     def lightglue(self, size0: Tuple[float, float], size1: Tuple[float, float], depth_confidence: float = 0.95,
                   width_confidence: float = 0.99, filter_threshold: float = 0.1, n_layers: int = 9,
                   kpts: Optional[torch.Tensor] = None, desc: Optional[torch.Tensor] = None,
-                  n: Optional[torch.Tensor] = None, pruning_min_kpts: int = -1) -> None:
+                  n: Optional[torch.Tensor] = None, pruning_min_kpts: int = -1, n_pairs: int = 1) -> None:
         """Matches image 0 and 1 of (kpts, desc, n) (default: the SuperPoint outputs held by the engine).
         size = (W, H). Fills self.matches / mscores / prune / info. pruning_min_kpts: -1 = the reference's CPU-path
         semantics (pruning evaluated after every layer; what the golden vectors pin), 1024 / 1536 = its CUDA path without /
-        with FlashAttention (`lightglue.py:326-331`)."""
+        with FlashAttention (`lightglue.py:326-331`). n_pairs > 1: images 2p, 2p + 1 of the inputs are pair p, all pairs go
+        through one sequence of launches (reserve max_images >= 2 n_pairs; every pair has the sizes size0 / size1)."""
         kpts = self.kpts if kpts is None else kpts
         desc = self.desc if desc is None else desc
         n = self.n if n is None else n
         conf = LightGlueConf(float(depth_confidence), float(width_confidence), float(filter_threshold), int(n_layers),
                              int(pruning_min_kpts))
         size = np.array([size0[0], size0[1], size1[0], size1[1]], dtype=np.float32)
-        self.ctx.call("im_lightglue_forward", ptr(kpts), ptr(desc), ptr(n), size.ctypes.data, C.byref(conf),
+        assert 1 <= n_pairs and 2 * n_pairs <= self.matches.shape[0], (n_pairs, self.matches.shape)
+        self.ctx.call("im_lightglue_forward_pairs", int(n_pairs), ptr(kpts), ptr(desc), ptr(n), size.ctypes.data, C.byref(conf),
                       ptr(self.matches), ptr(self.mscores), ptr(self.prune), ptr(self.info), _lib.stream_ptr())
 
     def superglue(self, shape0: Tuple[int, int], shape1: Tuple[int, int], sinkhorn_iterations: int = 20,
@@ -157,11 +160,12 @@ class Engine:
             d = d.T.contiguous()
         return (self.kpts[image, :n].cpu().numpy(), d.cpu().numpy(), self.scores[image, :n].cpu().numpy())
 
-    def matches_to_host(self, n0: int, n1: int):
-        m = self.matches.cpu().numpy().astype(np.int64)
-        s = self.mscores.cpu().numpy()
-        p = self.prune.cpu().numpy()
-        info = self.info.cpu().numpy()
+    def matches_to_host(self, n0: int, n1: int, pair: int = 0):
+        a = 2 * pair
+        m = self.matches[a:a + 2].cpu().numpy().astype(np.int64)
+        s = self.mscores[a:a + 2].cpu().numpy()
+        p = self.prune[a:a + 2].cpu().numpy()
+        info = self.info[pair].cpu().numpy()
         return dict(matches0=m[0, :n0], matches1=m[1, :n1], matching_scores0=s[0, :n0], matching_scores1=s[1, :n1],
                     prune0=p[0, :n0], prune1=p[1, :n1], stop=int(info[0]))
 

@@ -414,11 +414,22 @@ class ImageMatcherBase:
         DE = torch.stack([cache[k]["desc"] for k in keys])          # [T, K, 256]
         NN = torch.cat([cache[k]["n"] for k in keys])               # [T] int32
         P = len(tile_pairs)
-        M = torch.empty(P, K, dtype=torch.int32, device=dev)
+        # tile pairs of equal shapes share their launches (a batch dimension over pairs inside the matcher's kernels): the
+        # reference's loop (`matchers.py:367-394`) becomes one forward per group of up to `tile_pairs_per_launch` pairs
+        groups: Dict[tuple, List[int]] = {}
         for p, (tidx0, tidx1) in enumerate(tile_pairs):
-            logger.info(f" - Matching tile pair ({tidx0}, {tidx1})")
-            self._enqueue_cached(cache[(0, tidx0)], cache[(1, tidx1)], **config)
-            M[p].copy_(eng.matches[0])
+            groups.setdefault((cache[(0, tidx0)]["shape"], cache[(1, tidx1)]["shape"]), []).append(p)
+        per_launch = max(1, min(int(self._opt.get("tile_pairs_per_launch", 8)), self._max_pairs_per_launch()))
+        biggest = min(per_launch, max(len(v) for v in groups.values()))
+        eng.reserve(eng.max_h, eng.max_w, 2 * biggest, K)
+        M = torch.empty(P, K, dtype=torch.int32, device=dev)
+        for plist in groups.values():
+            for i in range(0, len(plist), per_launch):
+                chunk = plist[i:i + per_launch]
+                logger.info(f" - Matching tile pairs {[tile_pairs[p] for p in chunk]}")
+                self._enqueue_cached_group([(cache[(0, tile_pairs[p][0])], cache[(1, tile_pairs[p][1])]) for p in chunk], **config)
+                for j, p in enumerate(chunk):
+                    M[p].copy_(eng.matches[2 * j])
         # one library call for the whole tail of the loop (`im_merge_tile_matches`): selection of the valid matches of every
         # pair, the two fp32 origin shifts, `np.unique(axis=0, return_index=True)` (lexicographic order, first occurrence) by
         # counting ranks on the device; then row gathers of descriptors / scores for the surviving matches only
@@ -452,9 +463,19 @@ class ImageMatcherBase:
         logger.info("Matching by tile completed.")
         return features0, features1, matches0, mconf
 
-    def _load_cached_pair(self, c0: dict, c1: dict) -> None:
+    def _max_pairs_per_launch(self) -> int:
+        return 1
+
+    def _enqueue_cached_group(self, pairs: list, **config) -> None:
+        """Enqueue the matcher on a group of cached tile pairs of equal shapes; pair j's matches land in rows 2j, 2j + 1 of
+        the engine's output buffers. Default: one pair per call."""
+        assert len(pairs) == 1
+        self._enqueue_cached(pairs[0][0], pairs[0][1], **config)
+
+    def _load_cached_pair(self, c0: dict, c1: dict, pair: int = 0) -> None:
         eng = self.engine
         for slot, c in enumerate((c0, c1)):
+            slot += 2 * pair
             eng.kpts[slot].copy_(c["kpts"]); eng.scores[slot].copy_(c["scores"]); eng.desc[slot].copy_(c["desc"])
             eng.n[slot:slot + 1].copy_(c["n"])
 
@@ -573,6 +594,15 @@ class LightGlueMatcher(ImageMatcherBase):
         self._load_cached_pair(c0, c1)
         (h0, w0), (h1, w1) = c0["shape"], c1["shape"]
         self.engine.lightglue((w0, h0), (w1, h1), **self._lg_conf)
+
+    def _max_pairs_per_launch(self) -> int:
+        return 16
+
+    def _enqueue_cached_group(self, pairs: list, **config) -> None:
+        for j, (c0, c1) in enumerate(pairs):
+            self._load_cached_pair(c0, c1, pair=j)
+        (h0, w0), (h1, w1) = pairs[0][0]["shape"], pairs[0][1]["shape"]
+        self.engine.lightglue((w0, h0), (w1, h1), n_pairs=len(pairs), **self._lg_conf)
 
     def _match_cached(self, c0: dict, c1: dict, **config):
         self._enqueue_cached(c0, c1, **config)

@@ -38,6 +38,15 @@ def new_table(n_rows: int, max_kpts: int, device) -> torch.Tensor:
     return t
 
 
+def write_records(table: torch.Tensor, row: int, first_epoch: int, n_pairs: int, engine) -> None:
+    """Rows row .. row + n_pairs - 1 of `table` from the outputs of the engine's last `lightglue(n_pairs=...)`: one kernel."""
+    from ._lib import ptr, stream_ptr
+    K = engine.max_kpts
+    assert table.shape[1] == HEADER + 2 * K and table.is_contiguous() and row + n_pairs <= table.shape[0]
+    engine.ctx.call("im_pack_records", int(n_pairs), ptr(engine.n), ptr(engine.matches), ptr(engine.mscores), ptr(engine.info),
+                    int(first_epoch), table[row].data_ptr(), stream_ptr())
+
+
 def write_record(table: torch.Tensor, row: int, epoch: int, n: torch.Tensor, matches0: torch.Tensor,
                  mscores0: torch.Tensor, info: torch.Tensor, engine=None) -> None:
     """Device-side (no host sync): fill one row from the engine's output buffers. With an engine the row is packed
@@ -53,7 +62,7 @@ def write_record(table: torch.Tensor, row: int, epoch: int, n: torch.Tensor, mat
     r[0:1].fill_(epoch)   # a fill kernel (a scalar assignment would be a host->device copy: not capturable)
     r[1:3] = n[:2]
     r[3] = (matches0 > -1).sum().to(torch.int32)
-    r[4] = info[0]
+    r[4] = info.reshape(-1)[0]
     r[HEADER:HEADER + K] = matches0
     r[HEADER + K:HEADER + 2 * K] = mscores0.view(torch.int32)
 
@@ -124,39 +133,51 @@ class SequenceMatcher:
     A pair is ~200 kernel launches, none of which needs the host (counts, early stop and pruning are device state),
     so the whole pair is captured once into a HIP graph and replayed per epoch: the input pair is copied into a
     static device buffer, the graph runs, the record row is copied out. `use_graph=False` enqueues the launches
-    directly (same results bit for bit)."""
+    directly (same results bit for bit).
+
+    `pairs_per_launch = P > 1` (LightGlue): P pairs share every launch (a batch dimension over pairs inside the kernels,
+    `im_lightglue_forward_pairs`): `match_pair` collects pairs and runs the group when it is full; `flush()` runs a partial
+    group. Records are bit-identical to P = 1."""
 
     def __init__(self, engine, height: int, width: int, max_keypoints: int = 4096, nms_radius: int = 4,
                  detection_threshold: float = 0.0005, remove_borders: int = 4, depth_confidence: float = 0.95,
                  width_confidence: float = 0.99, filter_threshold: float = 0.1, use_graph: bool = True,
                  matcher: str = "lightglue", sinkhorn_iterations: int = 20, match_threshold: float = 0.3,
-                 pruning_min_kpts: int = -1, channels: int = 1):
+                 pruning_min_kpts: int = -1, channels: int = 1, pairs_per_launch: int = 1):
         self.e = engine
         self.h, self.w, self.k = height, width, max_keypoints
         self.matcher = matcher
         if matcher == "superglue":   # icepy4d's SuperGlue defaults (`matchers.py:854-867`)
             nms_radius = 3 if nms_radius == 4 else nms_radius
             detection_threshold = 0.001 if detection_threshold == 0.0005 else detection_threshold
+            if pairs_per_launch != 1:
+                raise NotImplementedError("pairs_per_launch > 1 is implemented for the LightGlue matcher")
         elif matcher != "lightglue":
             raise ValueError(f"unknown matcher {matcher!r}")
+        self.P = int(pairs_per_launch)
         self.sp = (nms_radius, detection_threshold, remove_borders)
         self.lg = dict(depth_confidence=depth_confidence, width_confidence=width_confidence, filter_threshold=filter_threshold,
                        pruning_min_kpts=pruning_min_kpts)
         self.sg = dict(sinkhorn_iterations=sinkhorn_iterations, match_threshold=match_threshold)
-        engine.reserve(height, width, 2, max_keypoints)
+        engine.reserve(height, width, 2 * self.P, max_keypoints)
         self.use_graph = use_graph
         self._graph = None
-        self._inp = torch.zeros((2, height, width) if channels == 1 else (2, height, width, 3), dtype=torch.uint8, device=engine.device)
-        self._rec = new_table(1, engine.max_kpts, engine.device)
+        shape = (2 * self.P, height, width) if channels == 1 else (2 * self.P, height, width, 3)
+        self._inp = torch.zeros(shape, dtype=torch.uint8, device=engine.device)
+        self._rec = new_table(self.P, engine.max_kpts, engine.device)
+        self._pending = []           # (epoch, table, row) of the pairs waiting in self._inp
 
-    def _enqueue(self, pair_u8: torch.Tensor) -> None:
+    def _enqueue(self, pairs_u8: torch.Tensor) -> None:
         e = self.e
         if self.matcher == "superglue":
-            e.superpoint(pair_u8, self.sp[0], self.sp[1], self.sp[2], self.k, flavour=1)
+            e.superpoint(pairs_u8, self.sp[0], self.sp[1], self.sp[2], self.k, flavour=1)
             e.superglue((self.h, self.w), (self.h, self.w), **self.sg)
             return
-        e.superpoint(pair_u8, self.sp[0], self.sp[1], self.sp[2], self.k)
-        e.lightglue((self.w, self.h), (self.w, self.h), **self.lg)
+        e.superpoint(pairs_u8, self.sp[0], self.sp[1], self.sp[2], self.k)
+        e.lightglue((self.w, self.h), (self.w, self.h), n_pairs=pairs_u8.shape[0] // 2, **self.lg)
+
+    def _record(self, table: torch.Tensor, row: int, epoch: int, n_pairs: int) -> None:
+        write_records(table, row, epoch, n_pairs, self.e)
 
     def _capture(self) -> None:
         cur = torch.cuda.current_stream()
@@ -165,33 +186,56 @@ class SequenceMatcher:
         with torch.cuda.stream(side):  # warm-up outside capture: lazy kernel attributes, allocator pools
             for _ in range(2):
                 self._enqueue(self._inp)
-                write_record(self._rec, 0, 0, self.e.n, self.e.matches[0], self.e.mscores[0], self.e.info, self.e)
+                self._record(self._rec, 0, 0, self.P)
         cur.wait_stream(side)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             self._enqueue(self._inp)
-            write_record(self._rec, 0, 0, self.e.n, self.e.matches[0], self.e.mscores[0], self.e.info, self.e)
+            self._record(self._rec, 0, 0, self.P)
         self._graph = g
 
-    def match_pair(self, pair_u8: torch.Tensor, epoch: int, table: torch.Tensor, row: int) -> None:
-        """pair_u8: device uint8 [2, H, W]. Enqueues the whole pair and its record; never synchronises."""
-        if not self.use_graph:
-            self._enqueue(pair_u8)
-            write_record(table, row, epoch, self.e.n, self.e.matches[0], self.e.mscores[0], self.e.info, self.e)
+    def _run_group(self) -> None:
+        pend, self._pending = self._pending, []
+        if not pend:
             return
-        if self._graph is None:
+        if not self.use_graph:
+            self._enqueue(self._inp[:2 * len(pend)] if self.P > 1 else self._inp)
+            self._record(self._rec, 0, 0, len(pend))
+        else:
+            if self._graph is None:
+                self._capture()
+            self._graph.replay()
+        for j, (epoch, table, row) in enumerate(pend):
+            table[row].copy_(self._rec[j], non_blocking=True)
+            table[row, 0:1].fill_(epoch)
+
+    def match_pair(self, pair_u8: torch.Tensor, epoch: int, table: torch.Tensor, row: int) -> None:
+        """pair_u8: device uint8 [2, H, W]. Enqueues the pair (or, with pairs_per_launch > 1, parks it until its group is
+        full) and its record; never synchronises."""
+        if self.P == 1 and not self.use_graph:
+            self._enqueue(pair_u8)
+            self._record(table, row, epoch, 1)
+            return
+        if self.use_graph and self._graph is None:
             self._capture()
-        self._inp.copy_(pair_u8, non_blocking=True)
-        self._graph.replay()
-        table[row].copy_(self._rec[0], non_blocking=True)
-        table[row, 0:1].fill_(epoch)
+        j = len(self._pending)
+        self._inp[2 * j:2 * j + 2].copy_(pair_u8, non_blocking=True)
+        self._pending.append((epoch, table, row))
+        if len(self._pending) == self.P:
+            self._run_group()
+
+    def flush(self) -> None:
+        """Run a partially filled group (the remaining slots of the static input still hold earlier pairs: their results are
+        computed and dropped)."""
+        self._run_group()
 
     def run(self, pairs: Sequence[torch.Tensor], epochs: Sequence[int], table: Optional[torch.Tensor] = None) -> torch.Tensor:
         if table is None:
             table = new_table(len(epochs), self.e.max_kpts, self.e.device)
         for row, (p, ep) in enumerate(zip(pairs, epochs)):
             self.match_pair(p, ep, table, row)
+        self.flush()
         return table
 
 
@@ -206,14 +250,13 @@ class PairPipeline:
 
     def __init__(self, make_engine, height: int, width: int, max_keypoints: int = 4096, n_streams: int = 2,
                  use_graph: bool = True, pairs_per_launch: int = 1, **matcher_conf):
-        if pairs_per_launch != 1:
-            raise NotImplementedError("pairs_per_launch > 1")
         self.slots = []
         for _ in range(max(1, n_streams)):
             eng = make_engine()
             stream = torch.cuda.Stream(device=eng.device)
             with torch.cuda.stream(stream):
-                sm = SequenceMatcher(eng, height, width, max_keypoints, use_graph=use_graph, **matcher_conf)
+                sm = SequenceMatcher(eng, height, width, max_keypoints, use_graph=use_graph, pairs_per_launch=pairs_per_launch,
+                                     **matcher_conf)
                 if use_graph:
                     sm._capture()  # capture now, while nothing else is running on the device
             stream.synchronize()
@@ -224,12 +267,16 @@ class PairPipeline:
 
     def match_pair(self, pair_u8: torch.Tensor, epoch: int, table: torch.Tensor, row: int) -> None:
         eng, stream, sm = self.slots[self._next]
-        self._next = (self._next + 1) % len(self.slots)
         with torch.cuda.stream(stream):
             sm.match_pair(pair_u8, epoch, table, row)
+        if not sm._pending:                       # the slot's launch group went out: the next pair goes to the next slot
+            self._next = (self._next + 1) % len(self.slots)
 
     def flush(self) -> None:
         """Enqueue whatever is still waiting for a full launch group (nothing with one pair per launch)."""
+        for eng, stream, sm in self.slots:
+            with torch.cuda.stream(stream):
+                sm.flush()
 
     def synchronize(self) -> None:
         for _, stream, _ in self.slots:

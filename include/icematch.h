@@ -89,6 +89,15 @@ int im_lightglue_forward(im_ctx* ctx, const float* d_kpts, const float* d_desc, 
                          const float* h_size, const im_lightglue_conf* conf,
                          int32_t* d_matches, float* d_mscores, int32_t* d_prune, int32_t* d_info, void* stream);
 
+/* The same for n_pairs independent pairs in ONE sequence of launches (a batch dimension over pairs inside every kernel):
+ * image 2p / 2p + 1 of the inputs are pair p; all pairs share h_size (equal-shape tile pairs of an epoch, `matchers.py:367-394`;
+ * the epochs of a sequence, `main_dev.py:60`). Needs im_ctx_reserve(max_images >= 2 n_pairs). Outputs: d_matches / d_mscores /
+ * d_prune [2 n_pairs][max_kpts] (rows 2p, 2p + 1 = matches0, matches1 of pair p), d_info [n_pairs][4]. Results are
+ * bit-identical to n_pairs single calls. */
+int im_lightglue_forward_pairs(im_ctx* ctx, int n_pairs, const float* d_kpts, const float* d_desc, const int32_t* d_n,
+                               const float* h_size, const im_lightglue_conf* conf, int32_t* d_matches, float* d_mscores,
+                               int32_t* d_prune, int32_t* d_info, void* stream);
+
 /* ---- SuperGlue: `SuperGlue.forward` (`SuperGlue/models/superglue.py:250-305`) ---------------------------
  * d_desc rows are [max_kpts][256] (the transposed view of the reference's [256, K]); h_shape: host [2][2] = (H, W)
  * of the image tensors (`data['image0'].shape`). Outputs as for LightGlue (d_info = {0, n0, n1, 0}). */
@@ -105,6 +114,10 @@ int im_superglue_forward(im_ctx* ctx, const float* d_kpts, const float* d_scores
  * `main_dev.py:160-173`): int32 [8 + 2 * max_kpts] = {epoch, n0, n1, n_matches, stop, 0, 0, 0}, matches0, scores0 bits. */
 int im_pack_record(im_ctx* ctx, const int32_t* d_n, const int32_t* d_matches0, const float* d_mscores0,
                    const int32_t* d_info, int epoch, int32_t* d_record, void* stream);
+/* n_pairs records at once from the outputs of im_lightglue_forward_pairs (epochs first_epoch .. first_epoch + n_pairs - 1);
+ * d_records [n_pairs][8 + 2 * max_kpts]. */
+int im_pack_records(im_ctx* ctx, int n_pairs, const int32_t* d_n, const int32_t* d_matches, const float* d_mscores,
+                    const int32_t* d_info, int first_epoch, int32_t* d_records, void* stream);
 /* Copies an internal buffer of the last forward ("lg_x", "lg_cos", "lg_sin", "sim", "md", "sp_smap", "sp_nms") for
  * stage-level parity tests. */
 int im_debug_read(im_ctx* ctx, const char* name, float* d_dst, size_t nfloats, void* stream);

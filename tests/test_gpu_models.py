@@ -219,7 +219,7 @@ def run_lightglue(e, f, **conf):
     e.kpts.zero_(); e.desc.zero_()
     e.kpts[0, :m] = torch.from_numpy(f["kpts0"]).cuda(); e.kpts[1, :n] = torch.from_numpy(f["kpts1"]).cuda()
     e.desc[0, :m] = torch.from_numpy(f["desc0"]).cuda(); e.desc[1, :n] = torch.from_numpy(f["desc1"]).cuda()
-    e.n[:] = torch.tensor([m, n], dtype=torch.int32)
+    e.n[:2] = torch.tensor([m, n], dtype=torch.int32)
     e.lightglue(tuple(f["size0"]), tuple(f["size1"]), **conf)
     torch.cuda.synchronize()
     return e.matches_to_host(m, n)
@@ -866,3 +866,54 @@ def test_preselection_selects_the_oracle_tile_pairs():
             if int(inside.sum()) > min_matches:
                 want.append((t0, t1))
         assert got == want and 0 < len(want) < 36, (got, want)
+
+
+# ------------------------------------------------------------------------------------------- batch over pairs
+def test_lightglue_pairs_share_launches_bit_identically():
+    """`im_lightglue_forward_pairs`: P pairs of DIFFERENT sizes (keypoint counts 300/257, 128/128, 96/160) and behaviours
+    (passthrough weights: pruning after some layers, different numbers of matches) in one sequence of launches give, pair by
+    pair, exactly the outputs of single-pair calls - matches, scores, prune counters, stop layer."""
+    from icepy4d_amd.engine import Engine
+    e = Engine(0)
+    e.load_state_dict("lightglue", synthetic.lightglue_state_dict(0, "passthrough"))
+    e.reserve(64, 64, 6, 320)
+    feats = [synthetic.synthetic_features(s, m, n) for s, m, n in ((2, 300, 257), (1, 128, 128), (5, 96, 160))]
+    singles = []
+    for f in feats:
+        singles.append(run_lightglue(e, f))
+    e.kpts.zero_(); e.desc.zero_()
+    for p, f in enumerate(feats):
+        m, n = f["kpts0"].shape[0], f["kpts1"].shape[0]
+        e.kpts[2 * p, :m] = torch.from_numpy(f["kpts0"]).cuda(); e.kpts[2 * p + 1, :n] = torch.from_numpy(f["kpts1"]).cuda()
+        e.desc[2 * p, :m] = torch.from_numpy(f["desc0"]).cuda(); e.desc[2 * p + 1, :n] = torch.from_numpy(f["desc1"]).cuda()
+        e.n[2 * p] = m; e.n[2 * p + 1] = n
+    e.lightglue(tuple(feats[0]["size0"]), tuple(feats[0]["size1"]), n_pairs=3)
+    torch.cuda.synchronize()
+    for p, (f, ref) in enumerate(zip(feats, singles)):
+        out = e.matches_to_host(f["kpts0"].shape[0], f["kpts1"].shape[0], pair=p)
+        assert out["stop"] == ref["stop"]
+        for k in ("matches0", "matches1", "matching_scores0", "matching_scores1", "prune0", "prune1"):
+            assert np.array_equal(out[k], ref[k]), (p, k)
+    assert (singles[0]["matches0"] > -1).sum() > 50
+    e.close()
+
+
+def test_sequence_pairs_per_launch_equals_one_by_one():
+    """SequenceMatcher / PairPipeline with pairs_per_launch = 2 (graph and direct): records bit-identical to one pair per
+    launch, including a partial last group (5 pairs)."""
+    from icepy4d_amd.engine import Engine
+    from icepy4d_amd import sequence as sq
+    lg_sd = synthetic.lightglue_state_dict(0, "passthrough")
+    pairs = [torch.from_numpy(np.stack(synthetic.translated_pair(s, 136, 200))).cuda() for s in (1, 2, 3, 4, 5)]
+    epochs = [20, 21, 22, 23, 24]
+    tabs = []
+    for P, use_graph in ((1, False), (2, False), (2, True)):
+        e = Engine(0)
+        e.load_state_dict("superpoint", SP_SD)
+        e.load_state_dict("lightglue", lg_sd)
+        sm = sq.SequenceMatcher(e, 136, 200, 256, use_graph=use_graph, pairs_per_launch=P)
+        tabs.append(sm.run(pairs, epochs).cpu())
+        torch.cuda.synchronize()
+        e.close()
+    assert torch.equal(tabs[0], tabs[1]) and torch.equal(tabs[0], tabs[2])
+    assert tabs[0][:, 0].tolist() == epochs and (tabs[0][:, 3] > 20).all()
