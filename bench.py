@@ -115,8 +115,10 @@ def main():
                     help="stereo = SURVEY §8d homography-warped pair (seeded weights find almost no matches on it: full-depth worst "
                          "case); translated = pure translation by (40, 8) px, ~2500 matches per pair")
     ap.add_argument("--no-graph", action="store_true", help="enqueue launches directly instead of replaying a HIP graph")
-    ap.add_argument("--streams", type=int, default=3, help="pairs in flight per GPU (independent contexts on separate HIP streams)")
-    ap.add_argument("--batch", type=int, default=1, help="pairs per launch (batch dimension over pairs inside the kernels)")
+    ap.add_argument("--streams", type=int, default=2, help="launch groups in flight per GPU (independent contexts on separate HIP streams)")
+    ap.add_argument("--batch", type=int, default=2, help="pairs per launch (batch dimension over pairs inside the kernels); measured on "
+                                                         "one MI355X: 1 x 3 streams 98.6, 2 x 2 streams 103.0, 4 x 2 streams 95.1 pairs/s")
+    ap.add_argument("--no-side-measurements", action="store_true", help="skip the short untimed-side runs (other launch mode, translated pairs)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: spawn / rendezvous / sharding / gather / JSON only")
     ap.add_argument("--attn-bf16x3", action="store_true",
                     help="EXPERIMENT (DESIGN.md), not the reported configuration: attention with fp32 products emulated "
@@ -127,6 +129,8 @@ def main():
     if args.warmup is None:
         args.warmup = {2: 6, 3: 6, 5: 2}[args.config]
 
+    if args.config == 5:
+        args.batch = 1
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn(args)   # does not return
     if args.attn_bf16x3:
@@ -159,7 +163,10 @@ def main():
         local_rank = 0
     if not args.dry_run:
         torch.cuda.set_device(local_rank)
-    if world > 1:
+    # IM_BENCH_FORCE_DIST=1: initialise the process group even for one rank (RCCL rehearsal on a 1-GPU box: the same
+    # init / all-gather / barrier calls the N > 1 run makes, through the nccl backend)
+    force_dist = os.environ.get("IM_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if cpu_group:
             dist.init_process_group("gloo")
@@ -197,7 +204,7 @@ def main():
     def barrier():
         sm.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -237,7 +244,7 @@ def main():
     full = all_gather_tables(table.cpu() if one_dev else table)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if world > 1 or force_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if one_dev else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -268,6 +275,33 @@ def main():
                    "mean_keypoints": n0, "mean_matches": nm},
         "host_enqueue_ms_per_step": 1e3 * t_enq / args.steps, "untimed_pairs_before_timing": warm_pairs,
     }
+
+    def quick_rate(pipe, inputs, n):
+        """Untimed-warm, short side measurement on this rank: pairs/s of `pipe` over n pairs of `inputs`."""
+        side = new_table(n, kpts, eng.device)
+        for j in range(min(n, 12)):
+            pipe.match_pair(inputs[j % len(inputs)], j, side, j)
+        pipe.flush(); pipe.synchronize()
+        t = time.perf_counter()
+        for j in range(n):
+            pipe.match_pair(inputs[j % len(inputs)], j, side, j)
+        pipe.flush(); pipe.synchronize()
+        return n / (time.perf_counter() - t), side[:, 3].float().mean().item()
+
+    if rank == 0 and world == 1 and not cfg5 and not args.no_side_measurements:
+        # side measurements (not `value`): the other launch mode, and a pool of pairs on which the seeded weights DO find matches
+        alt_b, alt_s = (1, 3) if args.batch > 1 else (2, 2)
+        alt = PairPipeline(make_engine, h, w, kpts, n_streams=alt_s, use_graph=not args.no_graph, matcher=m_name, pairs_per_launch=alt_b)
+        r_alt, _ = quick_rate(alt, pool, 48)
+        alt.close()
+        tr_pool = [torch.from_numpy(np.stack(synthetic.translated_pair(j, h, w, 40, 8))).cuda().contiguous() for j in range(2)]
+        r_tr, m_tr = quick_rate(sm, tr_pool, 48)
+        result["side_measurements"] = {
+            "other_launch_mode": {"pairs_per_launch": alt_b, "pairs_in_flight": alt_s, "pairs_per_s": r_alt, "pairs": 48},
+            "translated_pairs": {"pairs_per_s": r_tr, "mean_matches": m_tr, "pairs": 48,
+                                 "note": "pairs related by a pure (40, 8) px translation: the seeded weights match ~1000 keypoints "
+                                         "per pair on them (8 on the homography-warped pairs of `value`); same launches, no pruning or "
+                                         "early exit triggers with seeded weights either way"}}
 
     if rank == 0:
         # ---- roofline of the dominant kernel: HIP events around every launch (library-side, on the launch stream)
@@ -342,7 +376,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and not cfg5:
             result["cpu_baseline"] = cpu_baseline(epochs)
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -23,6 +23,7 @@
 // (tools/mfma_peak.hip), so everything next to the MFMAs is written for instruction count - see softmax_tile.
 #include "common.h"
 #include "kernels.h"
+#include "sp_post.h"
 
 #include <cstdlib>
 
@@ -425,13 +426,8 @@ __global__ __launch_bounds__(256 * G, 2 / G) void flash_attn_f32_kernel(AttnArgs
 template <int G>
 static hipError_t launch_g(const AttnArgs& a, hipStream_t s) {
     const size_t lds = G * ATTN_LDS_FLOATS * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_f32_kernel<G>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static size_t lds_optin[IM_MAX_DEVICES] = {0};   // per device: a process may hold contexts on several GPUs
+    if (hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(&flash_attn_f32_kernel<G>), lds, lds_optin); e != hipSuccess) return e;
     dim3 grid(((a.n_max + 127) / 128) * a.heads * a.batch * (a.part ? ATTN_MAX_SPLIT : 1)), block(256 * G);
     hipLaunchKernelGGL(flash_attn_f32_kernel<G>, grid, block, lds, s, a);
     return hipGetLastError();

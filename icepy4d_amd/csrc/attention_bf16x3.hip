@@ -13,6 +13,7 @@
 #include "ctx.h"
 #include "common.h"
 #include "kernels.h"
+#include "sp_post.h"
 
 namespace im {
 
@@ -320,13 +321,8 @@ hipError_t launch_flash_attn_bf16x3(const AttnArgs& a, unsigned short* qp, unsig
     if (resplit)
         hipLaunchKernelGGL(attn_split3_kernel, dim3(npad / 64, a.heads, a.batch), dim3(256), 0, s, a.q, a.k, a.v, a.bstride, a.hstride,
                            a.n_ptr, a.n_max, npad, a.scale * 1.4426950408889634f, qp, kp, vtp);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_bf16x3_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)X_LDS_BYTES);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static size_t lds_optin[IM_MAX_DEVICES] = {0};
+    if (hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(&flash_attn_bf16x3_kernel), X_LDS_BYTES, lds_optin); e != hipSuccess) return e;
     hipLaunchKernelGGL(flash_attn_bf16x3_kernel, dim3(((a.n_max + 127) / 128) * a.heads * a.batch), dim3(512), X_LDS_BYTES, s, a, qp, kp,
                        vtp, npad);
     return hipGetLastError();

@@ -19,6 +19,7 @@
 // full-resolution 64-channel conv1a activation (1 GB per 1080p pair) never exists in HBM.
 #include "common.h"
 #include "kernels.h"
+#include "sp_post.h"
 
 namespace im {
 
@@ -204,13 +205,8 @@ static hipError_t launch_conv_variant(const ConvArgs& a, hipStream_t s) {
     const int ntile = ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH) * a.B;
     dim3 grid(((ntile + 7) / 8) * 8 * (a.Cout / 64)), block(256);
     const size_t lds = (CONV_LDS_FLOATS + (FUSE ? FUSE_LDS_FLOATS : 0)) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_kernel<POOL, FUSE>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static size_t lds_optin[IM_MAX_DEVICES] = {0};   // per device: a process may hold contexts on several GPUs
+    if (hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(&conv3x3_mfma_kernel<POOL, FUSE>), lds, lds_optin); e != hipSuccess) return e;
     hipLaunchKernelGGL((conv3x3_mfma_kernel<POOL, FUSE>), grid, block, lds, s, a);
     return hipGetLastError();
 }

@@ -37,6 +37,7 @@
 
 #include "common.h"
 #include "kernels.h"
+#include "sp_post.h"
 
 namespace im {
 
@@ -282,13 +283,8 @@ static hipError_t launch_wino(const ConvArgs& a, hipStream_t s) {
     const int ntile = ((a.W + S_TW - 1) / S_TW) * ((a.H + S_TH - 1) / S_TH) * a.B;
     dim3 grid(((ntile + 7) / 8) * 8 * (a.Cout / 64)), block(256);
     const size_t lds = (S_LDS_FLOATS + (FUSE ? S_FUSE : 0)) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<POOL, FUSE>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static size_t lds_optin[IM_MAX_DEVICES] = {0};   // per device: a process may hold contexts on several GPUs
+    if (hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(&conv3x3_wino_kernel<POOL, FUSE>), lds, lds_optin); e != hipSuccess) return e;
     hipLaunchKernelGGL((conv3x3_wino_kernel<POOL, FUSE>), grid, block, lds, s, a);
     return hipGetLastError();
 }

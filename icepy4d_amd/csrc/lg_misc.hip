@@ -98,11 +98,15 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ x
     if (w0) { wa = *reinterpret_cast<const float4*>(w0 + (long)l * 256 + lane * 4); ba = b0[l]; }
     if (w1) { wb = *reinterpret_cast<const float4*>(w1 + (long)l * 256 + lane * 4); bb = b1[l]; }
     int cnt = 0;
+    float4 vr[RD_ROWS];      // all rows of the wave in flight before the first reduction
+#pragma unroll
+    for (int i = 0; i < RD_ROWS; ++i)
+        vr[i] = row0 + i < n ? *reinterpret_cast<const float4*>(x + (long)b * bstride + (long)(row0 + i) * 256 + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int i = 0; i < RD_ROWS; ++i) {
         const int row = row0 + i;
         if (row >= n) break;  // wave-uniform
-        const float4 v = *reinterpret_cast<const float4*>(x + (long)b * bstride + (long)row * 256 + lane * 4);
+        const float4 v = vr[i];
         if (w0) {
             float d = wave_sum(v.x * wa.x + v.y * wa.y + v.z * wa.z + v.w * wa.w) + ba;
             if (act0) d = sigmoidf(d);
@@ -145,7 +149,7 @@ __global__ __launch_bounds__(1024) void stop_prune_kernel(LGState* __restrict__ 
     __shared__ int part[1024];
     __shared__ int sh_active;
     const int tid = threadIdx.x;
-    const int pair = blockIdx.x;
+    const int pair = blockIdx.x, b = blockIdx.y;     // one block per image; both blocks of a pair take the same stop decision
     st += pair;
     conf += 2 * pair * vec_bstride; msc += 2 * pair * vec_bstride;
     ind_cur += 2 * pair * idx_bstride; ind_next += 2 * pair * idx_bstride; keep_idx += 2 * pair * idx_bstride; prune += 2 * pair * idx_bstride;
@@ -153,16 +157,12 @@ __global__ __launch_bounds__(1024) void stop_prune_kernel(LGState* __restrict__ 
         int act = st->active;
         if (act && do_stop) {
             const float ratio = 1.0f - (float)st->cnt[layer] / (float)(st->n_orig[0] + st->n_orig[1]);
-            if (ratio > depth_conf) {
-                act = 0;
-                st->active = 0;
-                st->stop_layer = layer;
-            }
+            if (ratio > depth_conf) act = 0;
         }
         sh_active = act;
     }
     __syncthreads();
-    for (int b = 0; b < 2; ++b) {
+    {
         const int n = st->n[b];
         // `if do_point_pruning and desc.shape[-2] > pruning_th` (`lightglue.py:495, 503`): per image, on its live count
         const bool live = sh_active != 0 && do_prune && n > prune_min;
@@ -209,15 +209,26 @@ __global__ __launch_bounds__(1024) void stop_prune_kernel(LGState* __restrict__ 
         }
         __syncthreads();
         if (tid == 0) st->n[b] = total;
-        __syncthreads();
+    }
+}
+
+// the stop decision itself, published after both image blocks of every pair have read the old state (next launch on the stream)
+__global__ void stop_commit_kernel(LGState* __restrict__ st, int n_pairs, int layer, float depth_conf) {
+    const int p = threadIdx.x;
+    if (p >= n_pairs) return;
+    st += p;
+    if (st->active) {
+        const float ratio = 1.0f - (float)st->cnt[layer] / (float)(st->n_orig[0] + st->n_orig[1]);
+        if (ratio > depth_conf) { st->active = 0; st->stop_layer = layer; }
     }
 }
 
 hipError_t launch_stop_prune(LGState* st, int n_pairs, int layer, int do_stop, int do_prune, float depth_conf, float keep_thr,
                              float conf_thr, const float* conf, const float* msc, long vec_bstride, const int* ind_cur,
                              int* ind_next, int* keep_idx, int* prune, long idx_bstride, int prune_min, hipStream_t s) {
-    hipLaunchKernelGGL(stop_prune_kernel, dim3(n_pairs), dim3(1024), 0, s, st, layer, do_stop, do_prune, depth_conf, keep_thr, conf_thr,
+    hipLaunchKernelGGL(stop_prune_kernel, dim3(n_pairs, 2), dim3(1024), 0, s, st, layer, do_stop, do_prune, depth_conf, keep_thr, conf_thr,
                        conf, msc, vec_bstride, ind_cur, ind_next, keep_idx, prune, idx_bstride, prune_min);
+    if (do_stop) hipLaunchKernelGGL(stop_commit_kernel, dim3(1), dim3(64), 0, s, st, n_pairs, layer, depth_conf);
     return hipGetLastError();
 }
 

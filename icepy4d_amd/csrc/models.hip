@@ -497,6 +497,7 @@ static int lightglue_forward(im_ctx* ctx, int n_pairs, const float* d_kpts, cons
     const int L = conf->n_layers;
     const int NP = n_pairs, NI = 2 * n_pairs;
     if (L < 1 || L > 9) return ctx->fail(-52, "im_lightglue_forward: n_layers must be 1..9");
+    if (ws->x3_q && n_pairs > 1) return ctx->fail(-54, "im_lightglue_forward: the bf16x3 attention experiment handles one pair per call");
     const bool do_stop = conf->depth_confidence > 0, do_prune = conf->width_confidence > 0;
     const long xb = (long)K * 256, eb = (long)K * 32;
     LGState* st = ws->st;

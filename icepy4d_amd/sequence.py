@@ -20,6 +20,7 @@ import numpy as np
 import torch
 
 HEADER = 8
+_FORCE_COLLECTIVE = __import__("os").environ.get("IM_BENCH_FORCE_DIST") == "1"   # rehearsal: run the all-gather at world size 1 too
 
 
 def record_words(max_kpts: int) -> int:
@@ -71,7 +72,7 @@ def all_gather_tables(local: torch.Tensor, group=None) -> torch.Tensor:
     """One all-gather of the fixed-size per-rank tables; returns the global table sorted by epoch
     (rows of ranks that own fewer epochs are padded with epoch = -1 and dropped)."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not _FORCE_COLLECTIVE):
         out = local
     else:
         world = dist.get_world_size(group)

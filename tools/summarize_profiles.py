@@ -1,0 +1,76 @@
+"""Condenses the rocprofv3 outputs of tools/collect_profiles.sh (gpurun_out/<tag>/) into the small files kept under profiles/:
+per-kernel duration tables (median / mean over the launches of the kernel trace) and PMC-derived HBM traffic per launch."""
+import collections, csv, glob, json, os, statistics, sys
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src, dst = os.path.join(root, "gpurun_out", tag), os.path.join(root, "profiles")
+
+
+def short(name):
+    name = name.replace("void ", "")
+    return name.split("(")[0][:70]
+
+
+def durations(sub):
+    fns = glob.glob(f"{src}/{sub}/**/*kernel_trace.csv", recursive=True)
+    d = collections.defaultdict(list)
+    for fn in fns:
+        for r in csv.DictReader(open(fn)):
+            d[short(r["Kernel_Name"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    return d
+
+
+for sub, outname in (("stats1", f"{tag}_kernel_stats_streams1_batch1.csv"), ("stats_default", f"{tag}_kernel_stats_default.csv"),
+                     ("stats_config5", f"{tag}_kernel_stats_config5.csv")):
+    d = durations(sub)
+    if not d:
+        continue
+    tot = sum(sum(v) for v in d.values())
+    with open(os.path.join(dst, outname), "w") as fh:
+        fh.write("kernel,calls,median_us,mean_us,min_us,max_us,total_ms,percent\n")
+        for k, v in sorted(d.items(), key=lambda kv: -sum(kv[1])):
+            if len(v) < 3:
+                continue
+            fh.write(f"\"{k}\",{len(v)},{statistics.median(v)/1e3:.2f},{statistics.mean(v)/1e3:.2f},{min(v)/1e3:.2f},{max(v)/1e3:.2f},"
+                     f"{sum(v)/1e6:.3f},{100*sum(v)/tot:.2f}\n")
+
+
+def counters(sub):
+    agg = collections.defaultdict(list)
+    for fn in glob.glob(f"{src}/{sub}/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(fn)):
+            agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    return agg
+
+
+traffic = {"_comment": "HBM-side traffic per launch from separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of "
+                       "tools/run_pair_once.py (one 1080p / 4096-keypoint LightGlue pair; one 12 MP / 16384-keypoint SuperGlue pair, "
+                       "keys suffixed @16384). bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: FETCH_SIZE under-counts wide coalesced "
+                       "reads by 2x on gfx950 (MI355X_MICROARCH.md, HBM section; calibrated there for 16-byte-per-lane streaming), "
+                       "WRITE_SIZE is exact. Medians over the launches of each kernel."}
+for mode, suffix in (("lg", ""), ("sg", "@16384")):
+    f, w = counters(f"pmc_{mode}_FETCH_SIZE"), counters(f"pmc_{mode}_WRITE_SIZE")
+    for k in sorted(set(f) | set(w)):
+        if not (k.startswith("im::") or "im::" in k):
+            continue
+        fk = statistics.median(f[k]) if k in f else 0.0
+        wk = statistics.median(w[k]) if k in w else 0.0
+        traffic[k + suffix] = {"launches": len(f.get(k, w.get(k, []))), "FETCH_SIZE_KB": round(fk, 1), "WRITE_SIZE_KB": round(wk, 1),
+                               "traffic_bytes": int((2 * fk + wk) * 1024)}
+json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+sq = counters("pmc_attn_sq")
+for fn in glob.glob(f"{src}/pmc_attn_sq/**/*counter_collection.csv", recursive=True):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(fn)):
+        if "flash_attn" in r["Kernel_Name"]:
+            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    with open(os.path.join(dst, f"{tag}_attn_pmc_sq.csv"), "w") as fh:
+        fh.write("counter,mean,launches\n")
+        for k, v in agg.items():
+            fh.write(f"{k},{sum(v)/len(v):.1f},{len(v)}\n")
+for name in ("bench.json", "bench_streams1_under_rocprof.json", "bench_default_under_rocprof.json", "bench_config5.json",
+             "bench_config5_under_rocprof.json"):
+    p = os.path.join(src, name)
+    if os.path.exists(p) and os.path.getsize(p):
+        open(os.path.join(dst, f"{tag}_{name}"), "w").write(open(p).read())
+print(open(os.path.join(dst, f"{tag}_bench.json")).read()[:3000] if os.path.exists(os.path.join(dst, f"{tag}_bench.json")) else "no bench.json")
