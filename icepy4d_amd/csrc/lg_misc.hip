@@ -677,7 +677,7 @@ __global__ __launch_bounds__(256) void filter_scatter_kernel(AssignArgs aa) {
 
 // Zero-fill by a kernel, not hipMemsetAsync: a memset NODE inside a captured HIP graph (ROCm 7.2) faulted when that graph
 // was replayed after other graphs had been captured on the same buffers (reproduced with three whole-pair graphs of
-// different image shapes, `tools/dbg`); kernel nodes do not have the problem.
+// different image shapes: the 4th call, a replay of the first graph, took a GPU memory fault); kernel nodes do not have the problem.
 __global__ void zero_words_kernel(unsigned* __restrict__ p, long n) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = 0u;
 }
