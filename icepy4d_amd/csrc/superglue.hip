@@ -4,6 +4,7 @@
 // (projection rows and merge columns are permuted to head-major once at load), BatchNorm (eval) is folded into
 // the preceding 1x1 convolution. The Sinkhorn sweeps never materialise the (M+1) x (N+1) coupling matrix:
 // the similarity matrix stays read-only in HBM and the dustbin row / column are the scalar `bin_score`.
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 
@@ -152,6 +153,180 @@ __global__ __launch_bounds__(256) void sinkhorn_col_combine_kernel(const float2*
     if (j == 0) *norm_out = norm;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// One Sinkhorn iteration with ONE read of the coupling matrix (the two-sweep form above reads it twice): a block walks its
+// rows one at a time; the row lives in REGISTERS (512 threads x 32 columns = 16384), so after the row's log-sum-exp has
+// produced u_i the same registers feed the column statistics of that row (online (max, sum) per column, carried in registers
+// over all rows of the block). The next row's loads are in flight while the current one is reduced. Per element: one
+// exponential for the row sum, two for the online column update (v_exp_f32: the sweep stays bound by HBM, 1.07 GB per
+// iteration at 16384 x 16384 instead of 2.15 GB). Per-block column partials are merged by sinkhorn_col_combine_kernel.
+static constexpr int SKF_T = 512, SKF_Q = 8, SKF_MAXN = SKF_T * 4 * SKF_Q;   // 16384 columns
+static constexpr float SKF_NEG = -3.0e38f;
+__device__ __forceinline__ float sk_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+
+__global__ __launch_bounds__(SKF_T, 2) void sinkhorn_fused_kernel(const float* __restrict__ sim, int ld, const int* __restrict__ m_ptr,
+                                                                  const int* __restrict__ n_ptr, float alpha, const float* __restrict__ v,
+                                                                  float* __restrict__ u, float2* __restrict__ part, int pstride) {
+    extern __shared__ __attribute__((aligned(16))) float sk_lds[];     // v of this iteration: [SKF_MAXN] (64 KB), then red[2][8]
+    float4* sv = reinterpret_cast<float4*>(sk_lds);
+    float2* red = reinterpret_cast<float2*>(sk_lds + SKF_MAXN);
+    const int m = *m_ptr, n = *n_ptr;
+    if (m <= 0 || n <= 0 || (int)blockIdx.x > m) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int G = gridDim.x;
+    float cM[4 * SKF_Q], cS[4 * SKF_Q];
+#pragma unroll
+    for (int q = 0; q < SKF_Q; ++q) {
+        const int j = q * (SKF_T * 4) + tid * 4;
+        // masked columns carry v = -3e38: z + v stays hugely negative, exp() of it is 0
+        sv[q * SKF_T + tid] = make_float4(j < n ? v[j] : SKF_NEG, j + 1 < n ? v[j + 1] : SKF_NEG, j + 2 < n ? v[j + 2] : SKF_NEG,
+                                          j + 3 < n ? v[j + 3] : SKF_NEG);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { cM[4 * q + e] = SKF_NEG; cS[4 * q + e] = 0.f; }
+    }
+    const float v_bin = v[n];
+    float bM = SKF_NEG, bS = 0.f;                 // dustbin column (thread 0): alpha + u_i over this block's rows
+    const float norm = sg_norm(m, n);
+    float4 ra[SKF_Q], rb[SKF_Q];
+    // (each thread reads back only the v entries it wrote: no barrier needed for sv)
+
+    auto load_row = [&](int row, float4 (&buf)[SKF_Q]) {
+        const float* p = sim + (long)row * ld;
+#pragma unroll
+        for (int q = 0; q < SKF_Q; ++q) {
+            const int j = q * (SKF_T * 4) + tid * 4;
+            float4 x = make_float4(alpha, alpha, alpha, alpha);        // the dustbin row is a row of alpha
+            if (row < m) {
+                x = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (j + 3 < n) x = *reinterpret_cast<const float4*>(p + j);
+                else {
+                    if (j < n) x.x = p[j];
+                    if (j + 1 < n) x.y = p[j + 1];
+                    if (j + 2 < n) x.z = p[j + 2];
+                }
+            }
+            buf[q] = x;
+        }
+    };
+    auto step = [&](int i, const float4 (&buf)[SKF_Q], int parity) {
+        const bool bin_row = i == m;
+        // ---- u_i = log_mu - logsumexp_j(z + v): lane-local (max, sum), wave, block
+        float mx = SKF_NEG;
+#pragma unroll
+        for (int q = 0; q < SKF_Q; ++q) {
+            const float4 w = sv[q * SKF_T + tid];
+            mx = fmaxf(fmaxf(mx, fmaxf(buf[q].x + w.x, buf[q].y + w.y)), fmaxf(buf[q].z + w.z, buf[q].w + w.w));
+        }
+        if (tid == 0) mx = fmaxf(mx, alpha + v_bin);
+        float sm = 0.f;
+#pragma unroll
+        for (int q = 0; q < SKF_Q; ++q) {
+            const float4 w = sv[q * SKF_T + tid];
+            sm += (sk_exp((buf[q].x + w.x) - mx) + sk_exp((buf[q].y + w.y) - mx)) + (sk_exp((buf[q].z + w.z) - mx) + sk_exp((buf[q].w + w.w) - mx));
+        }
+        if (tid == 0) sm += sk_exp((alpha + v_bin) - mx);
+        const float wM = wave_max(mx);
+        const float wS = wave_sum(sm * sk_exp(mx - wM));
+        if (lane == 0) red[parity * (SKF_T / 64) + wave] = make_float2(wM, wS);
+        __syncthreads();
+        float M = red[parity * (SKF_T / 64)].x;
+#pragma unroll
+        for (int w = 1; w < SKF_T / 64; ++w) M = fmaxf(M, red[parity * (SKF_T / 64) + w].x);
+        float S = 0.f;
+#pragma unroll
+        for (int w = 0; w < SKF_T / 64; ++w) S += red[parity * (SKF_T / 64) + w].y * sk_exp(red[parity * (SKF_T / 64) + w].x - M);
+        const float log_mu = bin_row ? logf((float)n) + norm : norm;
+        const float ui = log_mu - (logf(S) + M);
+        if (tid == 0) u[i] = ui;
+        // ---- column statistics of this row with the fresh u_i (the dustbin ROW is added by the combine kernel)
+        if (!bin_row) {
+#pragma unroll
+            for (int q = 0; q < SKF_Q; ++q) {
+                const float zz[4] = {buf[q].x, buf[q].y, buf[q].z, buf[q].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float y = zz[e] + ui;
+                    const float nm = fmaxf(cM[4 * q + e], y);
+                    cS[4 * q + e] = cS[4 * q + e] * sk_exp(cM[4 * q + e] - nm) + sk_exp(y - nm);
+                    cM[4 * q + e] = nm;
+                }
+            }
+            if (tid == 0) {
+                const float y = alpha + ui;
+                const float nm = fmaxf(bM, y);
+                bS = bS * sk_exp(bM - nm) + sk_exp(y - nm);
+                bM = nm;
+            }
+        }
+    };
+
+    int i = blockIdx.x;
+    load_row(i, ra);
+    for (;;) {
+        if (i + G <= m) load_row(i + G, rb);
+        step(i, ra, 0);
+        i += G;
+        if (i > m) break;
+        if (i + G <= m) load_row(i + G, ra);
+        step(i, rb, 1);
+        i += G;
+        if (i > m) break;
+    }
+    float2* pp = part + (long)blockIdx.x * pstride;
+#pragma unroll
+    for (int q = 0; q < SKF_Q; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int j = q * (SKF_T * 4) + tid * 4 + e;
+            if (j < n) pp[j] = make_float2(cM[4 * q + e], cS[4 * q + e]);
+        }
+    if (tid == 0) pp[n] = make_float2(bM, bS);
+}
+
+// v from the per-block column partials of sinkhorn_fused_kernel: 32 columns x 8 partial groups per block
+__global__ __launch_bounds__(256) void sinkhorn_fused_combine_kernel(const float2* __restrict__ part, int pstride, int n_parts,
+                                                                      const int* __restrict__ m_ptr, const int* __restrict__ n_ptr,
+                                                                      float alpha, const float* __restrict__ u, float* __restrict__ v,
+                                                                      float* __restrict__ norm_out) {
+    __shared__ float2 red[8][32];
+    const int m = *m_ptr, n = *n_ptr;
+    if (m <= 0 || n <= 0 || (int)blockIdx.x * 32 > n) return;
+    const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int j = blockIdx.x * 32 + c;
+    const int ns = min(n_parts, m + 1);
+    float M = SKF_NEG, S = 0.f;
+    if (j <= n)
+        for (int s0 = g; s0 < ns; s0 += 64) {
+            float2 p[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) p[k] = (s0 + 8 * k < ns) ? part[(long)(s0 + 8 * k) * pstride + j] : make_float2(SKF_NEG, 0.f);
+            float mx = p[0].x;
+#pragma unroll
+            for (int k = 1; k < 8; ++k) mx = fmaxf(mx, p[k].x);
+            const float nm = fmaxf(M, mx);
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc += p[k].y * sk_exp(p[k].x - nm);
+            S = S * sk_exp(M - nm) + acc;
+            M = nm;
+        }
+    red[g][c] = make_float2(M, S);
+    __syncthreads();
+    if (g == 0 && j <= n) {
+        const float bin = alpha + u[m];                 // dustbin row
+        float Mx = bin;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) Mx = fmaxf(Mx, red[k][c].x);
+        float Sx = sk_exp(bin - Mx);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) Sx += red[k][c].y * sk_exp(red[k][c].x - Mx);
+        const float norm = sg_norm(m, n);
+        const float log_nu = (j == n) ? logf((float)m) + norm : norm;
+        v[j] = log_nu - (logf(Sx) + Mx);
+        if (j == 0) *norm_out = norm;
+    }
+}
+
 // full (m+1) x (n+1) transport matrix, only for the stage entry point / tests
 __global__ __launch_bounds__(256) void ot_materialize_kernel(const float* __restrict__ sim, int ld, int m, int n, float alpha,
                                                               const float* __restrict__ u, const float* __restrict__ v,
@@ -173,6 +348,23 @@ static int sinkhorn(im_ctx* ctx, hipStream_t s, const float* sim, int ld, const 
     IM_HIP(ctx, launch_zero_words(v, n_max + 1, s));
     const int nstrips = (m_max + SK_STRIP - 1) / SK_STRIP;
     const int pstride = n_max + 1;
+    // single-read form: needs the row in the registers of one block (n <= 16384), 16-byte aligned rows, and as many partial
+    // strips as blocks (the workspace holds (K + 15) / 16 + 1 of them)
+    static const bool two_sweep = getenv("IM_SINKHORN_TWO_SWEEP") && getenv("IM_SINKHORN_TWO_SWEEP")[0] == '1';   // A/B switch
+    const int max_parts = (ctx->max_kpts + 15) / 16;
+    if (!two_sweep && n_max <= SKF_MAXN && (ld % 4) == 0 && (reinterpret_cast<uintptr_t>(sim) % 16) == 0 && max_parts >= 1 && iters > 0) {
+        const int G = std::min(std::min(256, max_parts), m_max + 1);
+        const size_t skf_lds = (SKF_MAXN + 2 * 2 * (SKF_T / 64)) * sizeof(float);
+        static size_t lds_optin[IM_MAX_DEVICES] = {0};
+        IM_HIP(ctx, ensure_dyn_lds(reinterpret_cast<const void*>(&sinkhorn_fused_kernel), skf_lds, lds_optin));
+        for (int it = 0; it < iters; ++it) {
+            hipLaunchKernelGGL(sinkhorn_fused_kernel, dim3(G), dim3(SKF_T), skf_lds, s, sim, ld, m_ptr, n_ptr, alpha, v, u, ws->part, pstride);
+            hipLaunchKernelGGL(sinkhorn_fused_combine_kernel, dim3((n_max + 1 + 31) / 32), dim3(256), 0, s, ws->part, pstride, G, m_ptr, n_ptr,
+                               alpha, u, v, norm_out);
+        }
+        IM_HIP(ctx, hipGetLastError());
+        return 0;
+    }
     for (int it = 0; it < iters; ++it) {
         hipLaunchKernelGGL(sinkhorn_row_kernel, dim3((m_max + 1 + 3) / 4), dim3(256), 0, s, sim, ld, m_ptr, n_ptr, alpha, v, u);
         hipLaunchKernelGGL(sinkhorn_col_partial_kernel, dim3((n_max + 1 + 255) / 256, nstrips), dim3(256), 0, s, sim, ld, m_ptr, n_ptr,

@@ -101,3 +101,22 @@ def test_config2_full_size_exact_or_explained(eng, kind):
     assert rep["images"][0]["n_keypoints"] == 4096
     if kind == "translated":
         assert rep["end_to_end"]["pairs_oracle"] > 500
+
+
+@pytest.mark.parametrize("variant,conf", [("earlystop", {}), ("prune", {"depth_confidence": -1}), ("passthrough", {"pruning_min_kpts": 200})])
+def test_adaptive_depth_and_width_from_pixels(variant, conf):
+    """Early stop (token-confidence weights that satisfy the stop criterion after a few layers), point pruning (matchability
+    weights that prune) and the CUDA-path pruning gate, end to end from pixels: stop layer, prune counters and match indices
+    against the oracle on the device's features, exact or margin-explained."""
+    from icepy4d_amd.engine import Engine
+    g = load_golden("g4_wrappers")
+    lg_sd = synthetic.lightglue_state_dict(0, variant)
+    e = Engine(0)
+    e.load_state_dict("superpoint", SP_SD)
+    e.load_state_dict("lightglue", lg_sd)
+    rep = parity_report.run_case(e, g["image0"], g["image1"], SP_SD, lg_sd, 256, lg_conf=conf)
+    assert_exact_or_explained(rep)
+    c = rep["matching_same_features"]
+    if variant == "earlystop":
+        assert c["stop_device"] < 9
+    e.close()
