@@ -170,6 +170,27 @@ __device__ __forceinline__ void softmax_tile(f32x16& sa, f32x16& sb, int kb, int
 // O^T += V^T . P^T for one 64-key tile: register r of P is key acc_row(r, hh) of its half. V fragments are read
 // from LDS in groups of four key rows, one group ahead of the MFMAs that consume them.
 __device__ __forceinline__ void pv_tile(const float* __restrict__ sV, int c, int hh, const f32x16& pa, const f32x16& pb, f32x16& o0, f32x16& o1) {
+#ifdef IM_ABL_PV_WIDE   // timing-only ablation: the instruction mix of a transposed V image (two 16-byte reads per 8 MFMAs)
+    {
+        const float* vt = sV + c * 68 + 4 * hh;      // stride 68: conflict-free 16-byte reads (what a transposed image would use)
+        float4 a4 = *reinterpret_cast<const float4*>(vt), b4 = *reinterpret_cast<const float4*>(vt + 1900);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            float4 na4 = a4, nb4 = b4;
+            if (g < 7) { na4 = *reinterpret_cast<const float4*>(vt + 8 * ((g + 1) & 3) + 32 * ((g + 1) >> 2)); nb4 = *reinterpret_cast<const float4*>(vt + 1900 + 8 * ((g + 1) & 3) + 32 * ((g + 1) >> 2)); }
+            const float av[4] = {a4.x, a4.y, a4.z, a4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = 4 * (g & 3) + q;
+                const float p = (g < 4) ? pa[r] : pb[r];
+                o0 = mfma32(av[q], p, o0);
+                o1 = mfma32(bv[q], p, o1);
+            }
+            a4 = na4; b4 = nb4;
+        }
+        return;
+    }
+#endif
     const float* vbase = sV + (4 * hh) * VS + c;   // acc_row(r, hh) = (r & 3) + 8 * (r >> 2) + 4 * hh
     float va[4], vb[4], na[4], nb[4];
 #pragma unroll

@@ -39,9 +39,9 @@ hipError_t launch_rowdot(const float* x, long bstride, LGState* st, int n_images
 hipError_t launch_stop_prune(LGState* st, int n_pairs, int layer, int do_stop, int do_prune, float depth_conf, float keep_thr,
                              float conf_thr, const float* conf, const float* msc, long vec_bstride, const int* ind_cur,
                              int* ind_next, int* keep_idx, int* prune, long idx_bstride, int prune_min, hipStream_t s);
-hipError_t launch_gather_rows(const LGState* st, int n_images, int n_max, const int* keep_idx, long idx_bstride, const float* x_src,
+hipError_t launch_gather_rows(LGState* st, int n_images, int n_max, const int* keep_idx, long idx_bstride, const float* x_src,
                               float* x_dst, long x_bstride, const float* cs_src, float* cs_dst, const float* sn_src,
-                              float* sn_dst, long enc_bstride, hipStream_t s);
+                              float* sn_dst, long enc_bstride, int commit_layer, float depth_conf, hipStream_t s);
 hipError_t launch_lg_init(LGState* st, int n_images, const int* n_in, int* ind, int* prune, long idx_bstride, int n_max, int* out_m,
                           float* out_s, long out_bstride, hipStream_t s);
 hipError_t launch_lg_select_layer(LGState* st, int n_pairs, int n_layers, int* sel, int* info, hipStream_t s);

@@ -223,12 +223,14 @@ __global__ void stop_commit_kernel(LGState* __restrict__ st, int n_pairs, int la
     }
 }
 
+// do_stop without do_prune: the stop decision is committed by its own tiny launch; with pruning the gather kernel that follows
+// commits it (launch_gather_rows(commit_layer = layer))
 hipError_t launch_stop_prune(LGState* st, int n_pairs, int layer, int do_stop, int do_prune, float depth_conf, float keep_thr,
                              float conf_thr, const float* conf, const float* msc, long vec_bstride, const int* ind_cur,
                              int* ind_next, int* keep_idx, int* prune, long idx_bstride, int prune_min, hipStream_t s) {
     hipLaunchKernelGGL(stop_prune_kernel, dim3(n_pairs, 2), dim3(1024), 0, s, st, layer, do_stop, do_prune, depth_conf, keep_thr, conf_thr,
                        conf, msc, vec_bstride, ind_cur, ind_next, keep_idx, prune, idx_bstride, prune_min);
-    if (do_stop) hipLaunchKernelGGL(stop_commit_kernel, dim3(1), dim3(64), 0, s, st, n_pairs, layer, depth_conf);
+    if (do_stop && !do_prune) hipLaunchKernelGGL(stop_commit_kernel, dim3(1), dim3(64), 0, s, st, n_pairs, layer, depth_conf);
     return hipGetLastError();
 }
 
@@ -238,8 +240,18 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const LGState* __restr
                                                            float* __restrict__ x_dst, long x_bstride,
                                                            const float* __restrict__ cs_src, float* __restrict__ cs_dst,
                                                            const float* __restrict__ sn_src, float* __restrict__ sn_dst,
-                                                           long enc_bstride) {
+                                                           long enc_bstride, LGState* __restrict__ st_commit, int n_pairs, int layer,
+                                                           float depth_conf) {
     const int b = blockIdx.y, lane = threadIdx.x & 63;
+    // the early-stop decision of this layer is published here (every stop_prune block has read the old flag by now: it ran
+    // in the previous launch of the stream; nothing in this kernel reads it)
+    if (st_commit && blockIdx.x == 0 && b == 0 && (int)threadIdx.x < n_pairs) {
+        LGState* sp = st_commit + threadIdx.x;
+        if (sp->active) {
+            const float ratio = 1.0f - (float)sp->cnt[layer] / (float)(sp->n_orig[0] + sp->n_orig[1]);
+            if (ratio > depth_conf) { sp->active = 0; sp->stop_layer = layer; }
+        }
+    }
     const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (p >= st[b >> 1].n[b & 1]) return;
     const int e = keep_idx[(long)b * idx_bstride + p];
@@ -253,11 +265,12 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const LGState* __restr
             *reinterpret_cast<const float4*>(sn_src + (long)b * enc_bstride + (long)e * 32 + (lane - 8) * 4);
 }
 
-hipError_t launch_gather_rows(const LGState* st, int n_images, int n_max, const int* keep_idx, long idx_bstride, const float* x_src,
+hipError_t launch_gather_rows(LGState* st, int n_images, int n_max, const int* keep_idx, long idx_bstride, const float* x_src,
                               float* x_dst, long x_bstride, const float* cs_src, float* cs_dst, const float* sn_src,
-                              float* sn_dst, long enc_bstride, hipStream_t s) {
+                              float* sn_dst, long enc_bstride, int commit_layer, float depth_conf, hipStream_t s) {
     hipLaunchKernelGGL(gather_rows_kernel, dim3((n_max + 3) / 4, n_images), dim3(256), 0, s, st, keep_idx, idx_bstride, x_src, x_dst,
-                       x_bstride, cs_src, cs_dst, sn_src, sn_dst, enc_bstride);
+                       x_bstride, cs_src, cs_dst, sn_src, sn_dst, enc_bstride, commit_layer >= 0 ? st : nullptr, n_images / 2, commit_layer,
+                       depth_conf);
     return hipGetLastError();
 }
 

@@ -523,7 +523,7 @@ static int lightglue_forward(im_ctx* ctx, int n_pairs, const float* d_kpts, cons
                                                       conf->pruning_min_kpts, s));
         if (do_prune) {
             IM_LAUNCH(ctx, "lg_adapt", s, launch_gather_rows(st, NI, K, ws->keep_idx, K, ws->x[cur], ws->x[1 - cur], xb, ws->cs[cur], ws->cs[1 - cur],
-                                                           ws->sn[cur], ws->sn[1 - cur], eb, s));
+                                                           ws->sn[cur], ws->sn[1 - cur], eb, do_stop ? i : -1, (float)conf->depth_confidence, s));
             cur = 1 - cur;
         }
     }
