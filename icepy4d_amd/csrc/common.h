@@ -44,9 +44,11 @@ __device__ __forceinline__ int wave_sum_i(int v) {
 //     separate tensor multiplies and two adds, each rounded to fp32 (`lightglue/utils.py:35-36`): no fused multiply-add here
 //   3 channels, gray_mode 1 (SuperGlue flavour): cv2.cvtColor(RGB2GRAY) on the uint8 image (`matchers.py:911-914`): OpenCV's
 //     fixed-point form with 14 fractional bits, (4899 R + 9617 G + 1868 B + 8192) >> 14, then x / 255
+//   4 "channels" = 4 bytes per pixel: a float32 gray image the host has already scaled (and resized: `lightglue/utils.py:30-33`)
 // kornia and cv2 are un-vendored: both formulas restate their published code (parity unpinned at these two call sites).
 __device__ __forceinline__ float image_value(const uint8_t* __restrict__ img, long pix, int channels, int gray_mode) {
     if (channels == 1) return (float)img[pix] / 255.0f;
+    if (channels == 4) return reinterpret_cast<const float*>(img)[pix];   // float32 gray, already scaled (the `resize` path)
     const uint8_t* p = img + pix * 3;
     const unsigned r = p[0], g = p[1], b = p[2];
     if (gray_mode == 1) return (float)((r * 4899u + g * 9617u + b * 1868u + 8192u) >> 14) / 255.0f;

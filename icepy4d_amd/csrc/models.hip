@@ -354,7 +354,8 @@ int im_superpoint_forward(im_ctx* ctx, const uint8_t* d_img, int n_images, int h
     IM_CHECK_CTX(ctx);
     // flavour: both select the same candidate set (the border test commutes with the threshold for thr >= 0, tested); it
     // only picks the gray conversion of 3-channel input
-    if (channels != 1 && channels != 3) return ctx->fail(-44, "im_superpoint_forward: channels must be 1 (gray) or 3 (RGB), got %d", channels);
+    if (channels != 1 && channels != 3 && channels != 4)
+        return ctx->fail(-44, "im_superpoint_forward: channels must be 1 (uint8 gray), 3 (uint8 RGB) or 4 (float32 gray), got %d", channels);
     if (!ctx->sp.ready) return ctx->fail(-40, "im_superpoint_forward: weights not finalized");
     Workspace* ws = ctx->ws;
     if (!ws || h > ctx->max_h || w > ctx->max_w || n_images > ctx->max_images)

@@ -101,10 +101,15 @@ class Engine:
         """gray_u8: device uint8 [B, H, W] (gray) or [B, H, W, 3] (RGB: converted per pixel inside the first convolution,
         `flavour` picks the reference's conversion). Fills self.kpts / scores / desc / n for images slot .. slot + B - 1
         (two images of different size are two calls with slot 0 and 1)."""
-        assert gray_u8.dtype == torch.uint8 and gray_u8.is_cuda and gray_u8.is_contiguous()
-        assert gray_u8.dim() == 3 or (gray_u8.dim() == 4 and gray_u8.shape[3] == 3), gray_u8.shape
+        assert gray_u8.is_cuda and gray_u8.is_contiguous()
+        if gray_u8.dtype == torch.float32:           # float gray [B, H, W], already in [0, 1] (the resize path)
+            assert gray_u8.dim() == 3
+            C_ = 4
+        else:
+            assert gray_u8.dtype == torch.uint8
+            assert gray_u8.dim() == 3 or (gray_u8.dim() == 4 and gray_u8.shape[3] == 3), gray_u8.shape
+            C_ = 1 if gray_u8.dim() == 3 else 3
         B, H, W = gray_u8.shape[:3]
-        C_ = 1 if gray_u8.dim() == 3 else 3
         assert 0 <= slot and slot + B <= self.max_images
         k = -1 if max_kpts is None else int(max_kpts)
         self._last_sp = (slot, B)

@@ -89,6 +89,45 @@ def _as_device_image(image: np.ndarray) -> np.ndarray:
     raise ValueError(f"Not an image: {image.shape}")
 
 
+def _resized_gray(image: np.ndarray, resize: int) -> Tuple[np.ndarray, np.ndarray]:
+    """`ImagePreprocessor.__call__` with `resize` given (`lightglue/utils.py:26-39`, called by `SuperPoint.extract`
+    `lightglue/superpoint.py:217-231`): u8 -> float / 255 (`matchers.py:1212-1220`), kornia `resize(img, resize, side="long",
+    antialias=True, align_corners=None, interpolation="bilinear")`, then kornia `rgb_to_grayscale`. kornia is un-vendored and
+    absent: its published algorithm is restated here with torch CPU ops (Gaussian blur with sigma = (factor - 1) / 2 per axis,
+    kernel size int(max(4 sigma, 3)) made odd, reflect border, before a bilinear `F.interpolate` when downscaling) -
+    parity unpinned. Returns (float32 gray [H', W'] in [0, 1], scales = [W' / W, H' / H] float32). icepy4d itself never passes
+    `resize` (`matchers.py:1247-1248` reads it from **config, `main_dev.py:115-132` does not set it)."""
+    import torch.nn.functional as F
+    x = torch.tensor(image / 255.0, dtype=torch.float)
+    x = x.permute(2, 0, 1) if x.dim() == 3 else x[None]
+    h, w = x.shape[-2:]
+    aspect = w / h
+    size = (int(resize / aspect), int(resize)) if aspect > 1 else (int(resize), int(resize * aspect))
+    if size != (h, w):
+        factors = (h / size[0], w / size[1])
+        x = x[None]
+        if max(factors) > 1:
+            sig = [max((f - 1.0) / 2.0, 0.001) for f in factors]
+            ks = [int(max(2.0 * 2 * s_, 3)) for s_ in sig]
+            ks = [k + 1 if k % 2 == 0 else k for k in ks]
+
+            def gauss(k, s_):
+                t = torch.arange(k, dtype=torch.float) - k // 2
+                g = torch.exp(-t ** 2 / (2.0 * s_ ** 2))
+                return g / g.sum()
+
+            ky, kx = gauss(ks[0], sig[0]), gauss(ks[1], sig[1])
+            c = x.shape[1]
+            x = F.pad(x, (ks[1] // 2, ks[1] // 2, ks[0] // 2, ks[0] // 2), mode="reflect")
+            x = F.conv2d(x, kx.view(1, 1, 1, -1).repeat(c, 1, 1, 1), groups=c)
+            x = F.conv2d(x, ky.view(1, 1, -1, 1).repeat(c, 1, 1, 1), groups=c)
+        x = F.interpolate(x, size=size, mode="bilinear", align_corners=None)[0]
+    scales = np.array([x.shape[-1] / w, x.shape[-2] / h], dtype=np.float32)
+    if x.shape[0] == 3:
+        x = (0.299 * x[0:1] + 0.587 * x[1:2]) + 0.114 * x[2:3]
+    return np.ascontiguousarray(x[0].numpy()), scales
+
+
 def _load_state_dict(opt: dict, model: str, filenames: List[str]) -> Dict[str, torch.Tensor]:
     sds = opt.get("state_dicts") or {}
     if model in sds:
@@ -617,7 +656,7 @@ class LightGlueMatcher(ImageMatcherBase):
         (FeaturesBase, FeaturesBase, matches0 [K] int64, mconf [S] = scores of the valid matches)."""
         max_keypoints = config.get("max_keypoints", 10240)
         if config.get("resize", None) is not None:
-            raise NotImplementedError("resize is not supported: icepy4d always calls extract(resize=None)")
+            return self._match_images_resized(image0, image1, int(config["resize"]), int(max_keypoints))
         g0, g1 = _as_device_image(image0), _as_device_image(image1)
         eng = self.engine
         eng.reserve(max(g0.shape[0], g1.shape[0]), max(g0.shape[1], g1.shape[1]), 2, int(max_keypoints))
@@ -654,6 +693,25 @@ class LightGlueMatcher(ImageMatcherBase):
         mconf = out["matching_scores0"][matches0 > -1]
         self._last = out
         return features0, features1, matches0, mconf
+
+    def _match_images_resized(self, image0: np.ndarray, image1: np.ndarray, resize: int, max_keypoints: int):
+        """`extract(image, resize=resize)` (`lightglue/superpoint.py:217-231`): the images are resized (long side = `resize`) and
+        converted to gray on the HOST (kornia's algorithm restated, `_resized_gray`), extraction runs on the float gray images,
+        keypoints go back to the original frame as `(k + 0.5) / scales - 0.5` before matching, `image_size` stays the
+        original (W, H)."""
+        eng = self.engine
+        g, sc = zip(*(_resized_gray(im, resize) for im in (image0, image1)))
+        eng.reserve(max(x.shape[0] for x in g), max(x.shape[1] for x in g), 2, max_keypoints)
+        for slot in (0, 1):
+            eng.superpoint(torch.from_numpy(g[slot][None]).to(eng.device), 4, 0.0005, 4, max_keypoints, flavour=0, slot=slot)
+            s_ = torch.from_numpy(sc[slot]).to(eng.device)
+            eng.kpts[slot] = (eng.kpts[slot] + 0.5) / s_[None, :] - 0.5
+        eng.lightglue((image0.shape[1], image0.shape[0]), (image1.shape[1], image1.shape[0]), **self._lg_conf)
+        torch.cuda.synchronize()
+        f0, f1, out = self._features_from_engine()
+        matches0 = out["matches0"]
+        self._last = out
+        return f0, f1, matches0, out["matching_scores0"][matches0 > -1]
 
     def _store_features(self, features0: FeaturesBase, features1: FeaturesBase, matches0: np.ndarray,
                         force_overwrite: bool = True) -> bool:

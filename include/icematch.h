@@ -59,6 +59,8 @@ int im_finalize_weights(im_ctx* ctx, const char* model);
  *               border := -1 before the threshold (`lightglue/superpoint.py:177-184`)
  *   flavour 1 = SuperGlue: cv2.cvtColor(RGB2GRAY) on the UINT8 image (fixed point), then scale (`matchers.py:911-917`);
  *               threshold, then the coordinate border mask (`SuperGlue/models/superpoint.py:176-189`)
+ * channels = 4 is a float32 gray image [n_images][h][w] (4 bytes per pixel) the caller has already scaled to [0, 1]: the
+ * `resize` option of `SuperPoint.extract` (`lightglue/utils.py:30-33`), whose kornia resize runs on the host.
  * max_kpts <= 0 means unlimited (bounded by the reserved max_kpts: see im_superpoint_candidates).
  * Outputs (row stride = reserved max_kpts): d_kpts [n_images][max_kpts][2] (x, y), d_scores [n_images][max_kpts],
  * d_desc [n_images][max_kpts][256] (L2-normalised), d_n [n_images]. */

@@ -917,3 +917,33 @@ def test_sequence_pairs_per_launch_equals_one_by_one():
         e.close()
     assert torch.equal(tabs[0], tabs[1]) and torch.equal(tabs[0], tabs[2])
     assert tabs[0][:, 0].tolist() == epochs and (tabs[0][:, 3] > 20).all()
+
+
+def test_resize_option_of_extract():
+    """`_match_images(..., resize=R)` (`matchers.py:1247-1248`, `lightglue/superpoint.py:217-231`): extraction on the image resized
+    to long side R (float gray path of the device, channels = 4), keypoints mapped back by `(k + .5) / scales - .5`, matching
+    with the ORIGINAL image sizes. Against the oracle run on the same resized float images (the kornia resize itself is a
+    restatement, parity unpinned)."""
+    from icepy4d_amd.matching import LightGlueMatcher
+    from icepy4d_amd.matching.matchers import _resized_gray
+    o = oracle()
+    g = load_golden("g6_colour")
+    rgb0 = g["rgb"]
+    rgb1 = np.ascontiguousarray(np.roll(rgb0, (8, 16), axis=(0, 1)))
+    lg_sd = synthetic.lightglue_state_dict(0, "passthrough")
+    m = LightGlueMatcher({"state_dicts": {"superpoint": SP_SD, "lightglue": lg_sd}})
+    f0, f1, matches0, mconf = m._match_images(rgb0, rgb1, max_keypoints=256, resize=200)
+    feats = []
+    for im in (rgb0, rgb1):
+        gray, sc = _resized_gray(im, 200)
+        assert gray.shape == (131, 200) and gray.dtype == np.float32
+        with torch.inference_mode():
+            r = o.superpoint_lg(torch.from_numpy(gray)[None], SP_SD, 256)
+        r["keypoints"] = (r["keypoints"] + 0.5) / torch.from_numpy(sc)[None] - 0.5
+        r["image_size"] = torch.tensor([im.shape[1], im.shape[0]], dtype=torch.float)
+        feats.append(r)
+    with torch.inference_mode():
+        out = o.lightglue(feats[0], feats[1], lg_sd)
+    assert_same_matches(f0.keypoints, f1.keypoints, matches0, feats[0]["keypoints"].numpy(), feats[1]["keypoints"].numpy(),
+                        out["matches0"].numpy(), feats[0]["keypoint_scores"].numpy(), feats[1]["keypoint_scores"].numpy())
+    assert f0.keypoints[:, 0].max() > 200 and (matches0 > -1).sum() > 10       # keypoints live in the original 304 x 200 frame
