@@ -675,6 +675,8 @@ class LightGlueMatcher(ImageMatcherBase):
                 key = key[:3] + (eng.generation,)       # the constructor may have grown the workspace
                 for k in [k for k in eng.graphs if k[3] != eng.generation]:
                     del eng.graphs[k]                   # stale captures
+                while len(eng.graphs) >= int(self._opt.get("max_cached_graphs", 16)):
+                    del eng.graphs[next(iter(eng.graphs))]   # oldest first: a long run over many image shapes stays bounded
                 sm._capture()
                 eng.graphs[key] = sm
             sm._inp.copy_(torch.from_numpy(np.stack([g0, g1])), non_blocking=True)
