@@ -244,8 +244,10 @@ def test_match_table_checkpoint_and_resume(tmp_path):
 def test_committed_bench_line_has_the_contract_fields():
     """The bench line committed under profiles/ (produced by `python bench.py` on the GPU box) carries every field the
     measurement contract names; guards bench.py against silently dropping one."""
+    import glob
     import json
-    line = open(os.path.join(ROOT, "profiles", "r01_bench.json")).read().strip().splitlines()[-1]
+    latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_bench.json")))[-1]
+    line = open(latest).read().strip().splitlines()[-1]
     d = json.loads(line)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
