@@ -41,6 +41,43 @@ int im_gemm_nt(im_ctx* ctx, const float* d_a, const float* d_w, const float* d_b
     return 0;
 }
 
+int im_ffn_fused(im_ctx* ctx, int act, float* d_x, const float* d_att, const float* h_w0, const float* h_b0, const float* h_ln_g,
+                   const float* h_ln_b, const float* h_w3, const float* h_b3, int n_images, int n_rows, const int32_t* d_n, void* stream) {
+    IM_CHECK_CTX(ctx);
+    if (n_images < 1 || n_rows < 1 || act < 0 || act > 1 || (act == 0 && (!h_ln_g || !h_ln_b))) return ctx->fail(-12, "im_ffn_fused: bad arguments");
+    if (act == 1) h_ln_g = h_ln_b = h_b0;   // unused by the ReLU form
+    const std::vector<float> p0 = pack_frag_weights(h_w0, 512, 512), p3 = pack_frag_weights(h_w3, 256, 512);
+    const size_t sizes[6] = {p0.size(), 512, 512, 512, p3.size(), 256};
+    const float* src[6] = {p0.data(), h_b0, h_ln_g, h_ln_b, p3.data(), h_b3};
+    float* d[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < 6 && e == hipSuccess; ++i) {
+        e = hipMalloc(&d[i], sizes[i] * sizeof(float));
+        if (e == hipSuccess) e = hipMemcpy(d[i], src[i], sizes[i] * sizeof(float), hipMemcpyHostToDevice);
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (e == hipSuccess) {
+        FfnArgs f;
+        f.act = act; f.x = d_x; f.x_bstride = (long)n_rows * 256; f.att = d_att; f.att_bstride = (long)n_rows * 256;
+        f.w0p = d[0]; f.b0 = d[1]; f.ln_g = d[2]; f.ln_b = d[3]; f.w3p = d[4]; f.b3 = d[5];
+        f.m_max = n_rows; f.batch = n_images; f.m_ptr = d_n; f.pstride = 2;
+        if (ctx->prof_on) {
+            im_ctx::ProfEntry pe{"ffn_fused", ctx->prof_event(), ctx->prof_event()};
+            hipEventRecord(pe.e0, st);
+            e = launch_ffn_fused(f, st);
+            hipEventRecord(pe.e1, st);
+            ctx->prof.push_back(pe);
+        } else {
+            e = launch_ffn_fused(f, st);
+        }
+    }
+    const hipError_t e2 = hipStreamSynchronize(st);
+    for (int i = 0; i < 6; ++i) hipFree(d[i]);
+    IM_HIP(ctx, e);
+    IM_HIP(ctx, e2);
+    return 0;
+}
+
 static int conv3x3_entry(im_ctx* ctx, bool wino, const float* d_in, const float* h_weight, const float* h_bias, float* d_out,
                          int b, int h, int w, int cin, int cout, int relu, int pool, void* stream);
 

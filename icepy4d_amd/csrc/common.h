@@ -37,6 +37,21 @@ __device__ __forceinline__ int wave_sum_i(int v) {
     return v;
 }
 
+
+// Raw buffer access: a descriptor sized to the live bytes (reads past it return zero, stores past it are dropped), lane
+// offsets in a VGPR, the wave-uniform part of the address in an SGPR - no 64-bit address arithmetic on the VALU.
+typedef unsigned int gu32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 gbuf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+    const gu32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t gmake_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long b = reinterpret_cast<unsigned long long>(base);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    void* p = reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo);
+    return __builtin_amdgcn_make_buffer_rsrc(p, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+
 // Image value fed to conv1a for pixel `pix` of a uint8 image with 1 or 3 interleaved channels.
 //   1 channel : x / 255 (`matchers.py:1212-1220`, `:263-274`; true fp32 division == float64 divide then round, for all 256 inputs)
 //   3 channels, gray_mode 0 (LightGlue flavour): the reference scales the HWC image to float first and converts on the float

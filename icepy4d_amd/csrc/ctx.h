@@ -44,6 +44,8 @@ struct LightGlueW {
     float* cf0_w = nullptr; float* cf0_b = nullptr;      // cross ffn.0 with to_out folded in
     float* cln_g = nullptr; float* cln_b = nullptr;
     float* cf3_w = nullptr; float* cf3_b = nullptr;
+    float* sf0_wp = nullptr; float* sf3_wp = nullptr;    // the four FFN matrices again in MFMA-fragment order (ffn_fused.hip)
+    float* cf0_wp = nullptr; float* cf3_wp = nullptr;
     float* fp_w = nullptr;  float* fp_b = nullptr;       // log_assignment.final_proj [L][256][256], [L][256]
     float* ma_w = nullptr;  float* ma_b = nullptr;       // matchability [L][256], [L]
     float* tc_w = nullptr;  float* tc_b = nullptr;       // token_confidence [L-1][256], [L-1]
@@ -56,6 +58,7 @@ struct SuperGlueW {
     float* proj_w = nullptr; float* proj_b = nullptr;    // [18][3][256][256] head-major output rows, [18][3][256]
     float* mlp0_w = nullptr; float* mlp0_b = nullptr;    // [18][512][512] BN folded, second half of K head-major-agnostic
     float* mlp3_w = nullptr; float* mlp3_b = nullptr;    // [18][256][512]
+    float* mlp0_wp = nullptr; float* mlp3_wp = nullptr;  // the same matrices in MFMA-fragment order (ffn_fused.hip)
     float* fp_w = nullptr; float* fp_b = nullptr;        // final_proj [256][256]
     float bin_score = 1.f;
 };

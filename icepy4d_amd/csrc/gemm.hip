@@ -18,18 +18,6 @@
 
 namespace im {
 
-typedef unsigned int gu32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float4 gbuf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
-    const gu32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
-    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-}
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t gmake_rsrc(const void* base, unsigned bytes) {
-    const unsigned long long b = reinterpret_cast<unsigned long long>(base);
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
-    void* p = reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo);
-    return __builtin_amdgcn_make_buffer_rsrc(p, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
-}
-
 template <int BM, int BN, int BK, int EPI>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
     constexpr int LDS_LD = BK + 4;

@@ -5,6 +5,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <vector>
 
 namespace im {
 
@@ -44,6 +45,23 @@ struct GemmArgs {
     int big_tile = 0;              // 128x128 block tile (score GEMM) instead of 64x64
 };
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
+
+// ------------------------------------------------------------------ ffn_fused.hip
+struct FfnArgs {
+    // x_z[m][0..256) += W3 . act(W0 . [x_z[m] | att_z[m]] + b0) + b3   for the live rows of every image z
+    int act = 0;                                       // 0: gelu(layernorm(.)) (LightGlue), 1: relu(.) (SuperGlue, BatchNorm folded)
+    float* x = nullptr; long x_bstride = 0;            // [z][row][256], updated in place
+    const float* att = nullptr; long att_bstride = 0;  // [z][row][256]
+    const float* w0p = nullptr; const float* b0 = nullptr;      // W0 [512][512] packed by pack_frag_weights, bias [512]
+    const float* ln_g = nullptr; const float* ln_b = nullptr;   // LayerNorm(512) weight / bias
+    const float* w3p = nullptr; const float* b3 = nullptr;      // W3 [256][512] packed, bias [256]
+    int m_max = 0; int batch = 1;
+    const int* m_ptr = nullptr;    // live rows of image z: m_ptr[(z >> 1) * pstride + (z & 1)]; null => m_max
+    const int* active = nullptr;   // per-pair flag active[(z >> 1) * pstride]
+    int pstride = 2;
+};
+hipError_t launch_ffn_fused(const FfnArgs& a, hipStream_t s);
+std::vector<float> pack_frag_weights(const float* w, int n, int k);   // host: row-major W[n][k] -> MFMA-fragment order
 
 // ------------------------------------------------------------------ attention.hip
 struct AttnArgs {

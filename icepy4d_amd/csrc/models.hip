@@ -107,7 +107,16 @@ static int finalize_lightglue(im_ctx* ctx) {
     // out_proj / to_out are folded into the second half of ffn.0 (`lightglue.py:160-162, 212-216`: the message is used
     // only as ffn input): ffn.0([x | Wo a + bo]) = W0a x + (W0b Wo) a + (W0b bo + b0). Products accumulated in double;
     // one 256 -> 256 GEMM launch and the `message` round trip through HBM less per block.
-    auto fold = [&](const char* ow, const char* ob, const char* fw, const char* fb, float*& dw, float*& db) -> int {
+    auto pack_layers = [&](const std::vector<float>& src, int n, int k) -> float* {   // per layer: fragment order for ffn_fused_kernel
+        std::vector<float> packed;
+        packed.reserve(src.size());
+        for (int l = 0; l < L; ++l) {
+            const std::vector<float> one = pack_frag_weights(&src[(size_t)l * n * k], n, k);
+            packed.insert(packed.end(), one.begin(), one.end());
+        }
+        return ctx->upload(packed);
+    };
+    auto fold = [&](const char* ow, const char* ob, const char* fw, const char* fb, float*& dw, float*& db, float*& dwp) -> int {
         std::vector<float> o_w, o_b, f_w, f_b;
         if (cat(ow, 256 * 256, o_w, L) || cat(ob, 256, o_b, L) || cat(fw, 512 * 512, f_w, L) || cat(fb, 512, f_b, L)) return -20;
         std::vector<double> row(256);
@@ -130,14 +139,16 @@ static int finalize_lightglue(im_ctx* ctx) {
         }
         dw = ctx->upload(f_w);
         db = ctx->upload(f_b);
-        return (dw && db) ? 0 : -22;
+        dwp = pack_layers(f_w, 512, 512);
+        return (dw && db && dwp) ? 0 : -22;
     };
     if (int rc = fold("transformers.%d.self_attn.out_proj.weight", "transformers.%d.self_attn.out_proj.bias",
-                      "transformers.%d.self_attn.ffn.0.weight", "transformers.%d.self_attn.ffn.0.bias", w.sf0_w, w.sf0_b))
+                      "transformers.%d.self_attn.ffn.0.weight", "transformers.%d.self_attn.ffn.0.bias", w.sf0_w, w.sf0_b, w.sf0_wp))
         return ctx->fail(rc, "weights: self ffn.0 / out_proj");
     CAT_UP(w.sln_g, "transformers.%d.self_attn.ffn.1.weight", 512, L);
     CAT_UP(w.sln_b, "transformers.%d.self_attn.ffn.1.bias", 512, L);
     CAT_UP(w.sf3_w, "transformers.%d.self_attn.ffn.3.weight", 256 * 512, L);
+    if (!(w.sf3_wp = pack_layers(buf, 256, 512))) return ctx->fail(-22, "weights: upload failed");
     CAT_UP(w.sf3_b, "transformers.%d.self_attn.ffn.3.bias", 256, L);
     {   // [to_qk ; to_v] as one 256 -> 512 projection
         std::vector<float> qw, qb, vw, vb, pw((size_t)L * 512 * 256), pb((size_t)L * 512);
@@ -155,11 +166,12 @@ static int finalize_lightglue(im_ctx* ctx) {
         if (!w.cqv_w || !w.cqv_b) return ctx->fail(-22, "weights: upload failed");
     }
     if (int rc = fold("transformers.%d.cross_attn.to_out.weight", "transformers.%d.cross_attn.to_out.bias",
-                      "transformers.%d.cross_attn.ffn.0.weight", "transformers.%d.cross_attn.ffn.0.bias", w.cf0_w, w.cf0_b))
+                      "transformers.%d.cross_attn.ffn.0.weight", "transformers.%d.cross_attn.ffn.0.bias", w.cf0_w, w.cf0_b, w.cf0_wp))
         return ctx->fail(rc, "weights: cross ffn.0 / to_out");
     CAT_UP(w.cln_g, "transformers.%d.cross_attn.ffn.1.weight", 512, L);
     CAT_UP(w.cln_b, "transformers.%d.cross_attn.ffn.1.bias", 512, L);
     CAT_UP(w.cf3_w, "transformers.%d.cross_attn.ffn.3.weight", 256 * 512, L);
+    if (!(w.cf3_wp = pack_layers(buf, 256, 512))) return ctx->fail(-22, "weights: upload failed");
     CAT_UP(w.cf3_b, "transformers.%d.cross_attn.ffn.3.bias", 256, L);
     CAT_UP(w.fp_w, "log_assignment.%d.final_proj.weight", 256 * 256, L);
     CAT_UP(w.fp_b, "log_assignment.%d.final_proj.bias", 256, L);
@@ -461,6 +473,18 @@ static int lg_block(im_ctx* ctx, hipStream_t s, int NI, int layer, bool cross, f
         IM_LAUNCH(ctx, cross ? "flash_attn_cross" : "flash_attn_self", s, launch_flash_attn_bf16x3(at, ws->x3_q, ws->x3_k, ws->x3_vt, true, s));
     } else {
         IM_LAUNCH(ctx, cross ? "flash_attn_cross" : "flash_attn_self", s, launch_flash_attn(at, s));
+    }
+    // A/B switch: IM_FFN_UNFUSED=1 keeps the three-launch form (ffn.0 GEMM, LayerNorm + GELU, ffn.3 GEMM + residual)
+    static const bool unfused = getenv("IM_FFN_UNFUSED") && getenv("IM_FFN_UNFUSED")[0] == '1';
+    if (!unfused) {   // ffn.0 on cat([x, att]) (out_proj folded into the weights), LayerNorm, GELU, ffn.3, residual: one kernel
+        FfnArgs f;
+        f.x = x; f.x_bstride = xb; f.att = ws->att; f.att_bstride = xb;
+        f.w0p = (cross ? W.cf0_wp : W.sf0_wp) + (long)layer * 512 * 512; f.b0 = (cross ? W.cf0_b : W.sf0_b) + (long)layer * 512;
+        f.ln_g = (cross ? W.cln_g : W.sln_g) + (long)layer * 512; f.ln_b = (cross ? W.cln_b : W.sln_b) + (long)layer * 512;
+        f.w3p = (cross ? W.cf3_wp : W.sf3_wp) + (long)layer * 256 * 512; f.b3 = (cross ? W.cf3_b : W.sf3_b) + (long)layer * 256;
+        f.m_max = K; f.batch = NI; f.m_ptr = n_ptr; f.active = active; f.pstride = ST_INTS;
+        IM_LAUNCH(ctx, "lg_ffn_fused", s, launch_ffn_fused(f, s));
+        return 0;
     }
     {   // ffn.0 on cat([x, out_proj(att)]) with out_proj folded into the weights: the second source is the attention output
         GemmArgs g = base;

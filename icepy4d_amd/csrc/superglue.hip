@@ -6,6 +6,7 @@
 // the similarity matrix stays read-only in HBM and the dustbin row / column are the scalar `bin_score`.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "common.h"
@@ -481,6 +482,16 @@ int finalize_superglue(im_ctx* ctx) {
     W.proj_w = ctx->upload(qkv_w); W.proj_b = ctx->upload(qkv_b);
     W.mlp0_w = ctx->upload(m0_w); W.mlp0_b = ctx->upload(m0_b);
     W.mlp3_w = ctx->upload(m3_w); W.mlp3_b = ctx->upload(m3_b);
+    {
+        std::vector<float> p0, p3;
+        for (int l = 0; l < L; ++l) {
+            const std::vector<float> a0 = pack_frag_weights(&m0_w[(size_t)l * 512 * 512], 512, 512), a3 = pack_frag_weights(&m3_w[(size_t)l * 256 * 512], 256, 512);
+            p0.insert(p0.end(), a0.begin(), a0.end());
+            p3.insert(p3.end(), a3.begin(), a3.end());
+        }
+        W.mlp0_wp = ctx->upload(p0); W.mlp3_wp = ctx->upload(p3);
+        if (!W.mlp0_wp || !W.mlp3_wp) return ctx->fail(-22, "weights: upload failed");
+    }
     const auto* fw = sg_find(ctx, "final_proj.weight", 65536);
     const auto* fb = sg_find(ctx, "final_proj.bias", 256);
     const auto* bs = sg_find(ctx, "bin_score", 1);
@@ -547,6 +558,16 @@ int im_superglue_forward(im_ctx* ctx, const float* d_kpts, const float* d_scores
             at.cross = cross ? 1 : 0; at.scale = 0.125f;  // / dim ** .5, dim = 64 (`superglue.py:91`)
             at.part = ws->attn_part; at.counters = ws->attn_cnt;
             IM_LAUNCH(ctx, cross ? "flash_attn_cross" : "flash_attn_self", s, launch_flash_attn(at, s));
+        }
+        static const bool unfused = getenv("IM_FFN_UNFUSED") && getenv("IM_FFN_UNFUSED")[0] == '1';   // A/B switch: two GEMM launches
+        if (!unfused) {   // x += mlp.3(relu(bn(mlp.0([x | att])))) with merge and BatchNorm folded into mlp.0: one kernel (ffn_fused.hip)
+            FfnArgs f;
+            f.act = 1; f.x = x; f.x_bstride = xb; f.att = ws->att; f.att_bstride = xb;
+            f.w0p = W.mlp0_wp + (long)l * 512 * 512; f.b0 = W.mlp0_b + (long)l * 512;
+            f.w3p = W.mlp3_wp + (long)l * 256 * 512; f.b3 = W.mlp3_b + (long)l * 256;
+            f.m_max = base.m_max; f.batch = base.batch; f.m_ptr = base.m_ptr; f.active = base.active; f.pstride = base.pstride;
+            IM_LAUNCH(ctx, "sg_mlp_fused", s, launch_ffn_fused(f, s));
+            continue;
         }
         {
             GemmArgs g = base;

@@ -128,6 +128,14 @@ int im_debug_read(im_ctx* ctx, const char* name, float* d_dst, size_t nfloats, v
 /* C[m][n] = alpha * (sum_k A[m][k] W[n][k] + bias[n]); fp32 MFMA GEMM. bias may be NULL. big_tile: 128x128 tiles. */
 int im_gemm_nt(im_ctx* ctx, const float* d_a, const float* d_w, const float* d_bias, float* d_c,
                int m, int n, int k, float alpha, int big_tile, void* stream);
+/* The feed-forward tail of a transformer block / GNN layer in one kernel:
+ *   x[z][m][0..256) += W3 . act(W0 . [x[z][m] | att[z][m]] + b0) + b3   for the first d_n[z] (NULL: n_rows) rows of each image z
+ * act 0: gelu(layernorm(.)) = LightGlue's ffn (`lightglue/lightglue.py:144-149, 160-162, 212-216`); act 1: relu(.) = SuperGlue's
+ * mlp with its BatchNorm folded into W0 / b0 (`SuperGlue/models/superglue.py:51-61, 104-116`; h_ln_g / h_ln_b unused, may be NULL).
+ * d_x / d_att: [n_images][n_rows][256]; weights on the HOST in torch layout (W0 [512][512] acting on cat([x, att]), b0 [512],
+ * LayerNorm g / b [512], W3 [256][512], b3 [256]): packed + uploaded inside; synchronises. */
+int im_ffn_fused(im_ctx* ctx, int act, float* d_x, const float* d_att, const float* h_w0, const float* h_b0, const float* h_ln_g,
+                   const float* h_ln_b, const float* h_w3, const float* h_b3, int n_images, int n_rows, const int32_t* d_n, void* stream);
 /* 3x3 conv, NHWC fp32, weights in torch layout [cout][cin][3][3] on the HOST (packed + uploaded inside; synchronises) */
 int im_conv3x3(im_ctx* ctx, const float* d_in, const float* h_weight, const float* h_bias, float* d_out,
                int b, int h, int w, int cin, int cout, int relu, int pool, void* stream);
