@@ -49,6 +49,8 @@ SIGNATURES = {
     "im_superglue_forward": [_P, _P, _P, _P, _P, _P, C.POINTER(SuperGlueConf), _P, _P, _P, _P],
     "im_pack_record": [_P, _P, _P, _P, _P, _I, _P, _P],
     "im_debug_read": [_P, C.c_char_p, _P, C.c_size_t, _P],
+    "im_pyr_down": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "im_pyr_up": [_P, _P, _P, _I, _I, _I, _I, _P],
     "im_gemm_nt": [_P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _P],
     "im_ffn_fused": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P],
     "im_conv3x3": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],

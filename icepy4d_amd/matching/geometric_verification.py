@@ -130,41 +130,67 @@ def _magsac_weights(r: np.ndarray, sigma_max: float = MAGSAC_SIGMA_MAX, k: float
     return np.where(r <= k * sigma_max, np.maximum(w, 0.0), 0.0) / sigma_max
 
 
+def _dlt_rows(xa: np.ndarray, xb: np.ndarray) -> np.ndarray:
+    """The 2 n x 9 DLT system of homogeneous, normalised correspondences xa -> xb (leading batch dimensions allowed)."""
+    x, y = xa[..., 0], xa[..., 1]
+    u, v = xb[..., 0], xb[..., 1]
+    z, o = np.zeros_like(x), np.ones_like(x)
+    r0 = np.stack([z, z, z, -x, -y, -o, v * x, v * y, v], -1)
+    r1 = np.stack([x, y, o, z, z, z, -u * x, -u * y, -u], -1)
+    return np.concatenate([r0, r1], -2)
+
+
 def _homography_dlt(a: np.ndarray, b: np.ndarray) -> np.ndarray:
     xa, Ta = _normalise(a)
     xb, Tb = _normalise(b)
-    rows = []
-    for (x, y, _), (u, v, _) in zip(xa, xb):
-        rows.append([0, 0, 0, -x, -y, -1, v * x, v * y, v])
-        rows.append([x, y, 1, 0, 0, 0, -u * x, -u * y, -u])
-    _, _, vt = np.linalg.svd(np.asarray(rows))
+    _, _, vt = np.linalg.svd(_dlt_rows(xa, xb), full_matrices=len(a) < 5)
     return np.linalg.inv(Tb) @ vt[-1].reshape(3, 3) @ Ta
 
 
+def _apply3(M: np.ndarray, x: np.ndarray, y: np.ndarray, transpose: bool = False):
+    """Rows of M x for homogeneous points (x, y, 1) and a stack M [B, 3, 3] (M^T x with transpose): three [B, n] planes by
+    broadcasting (a K = 3 product is not worth a BLAS call)."""
+    if transpose:
+        M = np.swapaxes(M, -1, -2)
+    return [M[:, i, 0, None] * x + M[:, i, 1, None] * y + M[:, i, 2, None] for i in range(3)]
+
+
 def _transfer_error(H: np.ndarray, p0: np.ndarray, p1: np.ndarray) -> np.ndarray:
-    q = np.c_[p0, np.ones(len(p0))] @ H.T
-    q = q[:, :2] / np.where(np.abs(q[:, 2:]) < 1e-12, 1e-12, q[:, 2:])
-    return ((q - p1) ** 2).sum(1)
+    """Squared transfer error of H (or of a stack of H: [B, 3, 3] -> [B, n])."""
+    q0, q1, q2 = _apply3(H.reshape(-1, 3, 3), p0[:, 0], p0[:, 1])
+    q2 = np.where(np.abs(q2) < 1e-12, 1e-12, q2)
+    err = (q0 / q2 - p1[:, 0]) ** 2 + (q1 / q2 - p1[:, 1]) ** 2
+    return err[0] if H.ndim == 2 else err
+
+
+def _sampson_many(Fs: np.ndarray, p0: np.ndarray, p1: np.ndarray) -> np.ndarray:
+    """Sampson errors of a stack of fundamental matrices: [B, 3, 3] -> [B, n]."""
+    a0, a1, a2 = _apply3(Fs, p0[:, 0], p0[:, 1])                     # F x0
+    b0, b1, _ = _apply3(Fs, p1[:, 0], p1[:, 1], transpose=True)      # F^T x1
+    num = (p1[:, 0] * a0 + p1[:, 1] * a1 + a2) ** 2
+    return num / np.maximum(a0 ** 2 + a1 ** 2 + b0 ** 2 + b1 ** 2, 1e-24)
 
 
 def _degeneracy_check(p0, p1, F, mask, thr2, rng):
     """DEGENSAC's repair of a plane-dominated solution: when one homography explains most inliers of F, estimate
     F = [e']x H by plane-and-parallax (H from the planar inliers, e' from two matches off the plane) and keep it if it
-    explains more matches than F does."""
+    explains more matches than F does. The 64 plane hypotheses and the 200 epipole candidates are each scored as one stack."""
     inl = np.where(mask)[0]
     if len(inl) < 12:
         return F, mask
-    bestH, bestm = None, None
+    Hs = []
     for _ in range(64):
         idx = rng.choice(inl, 4, replace=False)
         try:
-            H = _homography_dlt(p0[idx], p1[idx])
+            Hs.append(_homography_dlt(p0[idx], p1[idx]))
         except np.linalg.LinAlgError:
             continue
-        hm = _transfer_error(H, p0, p1) < 4.0 * thr2
-        if bestm is None or hm.sum() > bestm.sum():
-            bestH, bestm = H, hm
-    if bestH is None or bestm[inl].sum() < 0.6 * len(inl):
+    if not Hs:
+        return F, mask
+    hms = _transfer_error(np.stack(Hs), p0, p1) < 4.0 * thr2             # [64, n]
+    b = int(np.argmax(hms.sum(1)))                                       # first of the best, like a running maximum
+    bestH, bestm = Hs[b], hms[b]
+    if bestm[inl].sum() < 0.6 * len(inl):
         return F, mask                                                     # no dominant plane
     try:
         bestH = _homography_dlt(p0[bestm], p1[bestm])
@@ -176,21 +202,23 @@ def _degeneracy_check(p0, p1, F, mask, thr2, rng):
     x1 = np.c_[p1, np.ones(len(p1))]
     hx0 = np.c_[p0, np.ones(len(p0))] @ bestH.T
     lines = np.cross(x1[off], hx0[off])                                    # each passes through the epipole e'
-    best = (int(mask.sum()), F, mask)
-    for _ in range(200):
-        i, j = rng.choice(len(off), 2, replace=False)
-        e = np.cross(lines[i], lines[j])
-        if np.linalg.norm(e) < 1e-12:
-            continue
-        ex = np.array([[0, -e[2], e[1]], [e[2], 0, -e[0]], [-e[1], e[0], 0]])
-        Fp = ex @ bestH
-        Fp = Fp / max(np.linalg.norm(Fp), 1e-12)
-        m = _sampson(Fp, p0, p1) < thr2
-        if int(m.sum()) > best[0]:
-            best = (int(m.sum()), Fp, m)
-    if best[1] is not F:
-        logger.info(f"Degeneracy check: plane-and-parallax model kept ({best[0]} inliers instead of {int(mask.sum())})")
-    return best[1], best[2]
+    ij = np.array([rng.choice(len(off), 2, replace=False) for _ in range(200)])
+    e = np.cross(lines[ij[:, 0]], lines[ij[:, 1]])                         # [200, 3]
+    ok = np.linalg.norm(e, axis=1) >= 1e-12
+    if not ok.any():
+        return F, mask
+    e = e[ok]
+    ex = np.zeros((len(e), 3, 3))
+    ex[:, 0, 1], ex[:, 0, 2], ex[:, 1, 0], ex[:, 1, 2], ex[:, 2, 0], ex[:, 2, 1] = -e[:, 2], e[:, 1], e[:, 2], -e[:, 0], -e[:, 1], e[:, 0]
+    Fps = ex @ bestH
+    Fps = Fps / np.maximum(np.linalg.norm(Fps, axis=(1, 2), keepdims=True), 1e-12)
+    ms = _sampson_many(Fps, p0, p1) < thr2                                 # [<= 200, n]
+    cnt = ms.sum(1)
+    k = int(np.argmax(cnt))
+    if int(cnt[k]) > int(mask.sum()):
+        logger.info(f"Degeneracy check: plane-and-parallax model kept ({int(cnt[k])} inliers instead of {int(mask.sum())})")
+        return Fps[k], ms[k]
+    return F, mask
 
 
 def _finish(p0, p1, best_mask, thr2, method, n, degeneracy_check=True, seed=0):

@@ -309,9 +309,7 @@ class ImageMatcherBase:
                 n_down = 2
             else:
                 n_down = 1
-            i0, i1 = deepcopy(image0), deepcopy(image1)
-            for _ in range(n_down):
-                i0, i1 = pyr_down(i0), pyr_down(i1)
+            i0, i1 = pyr_down(image0, self.engine, n_down), pyr_down(image1, self.engine, n_down)   # levels stay on the device
             f0, f1, mtc, _ = self._match_images(i0, i1, max_keypoints=4096)
             vld = mtc > -1
             kp0 = f0.keypoints[vld] * (2 ** n_down)
@@ -328,13 +326,13 @@ class ImageMatcherBase:
     def _resize_images(self, quality: Quality, image0: np.ndarray, image1: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
         """`matchers.py:583-610`: HIGHEST = pyrUp, HIGH = identity, MEDIUM = pyrDown, LOW = pyrDown twice."""
         if quality == Quality.HIGHEST:
-            return pyr_up(image0), pyr_up(image1)
+            return pyr_up(image0, self.engine), pyr_up(image1, self.engine)
         if quality == Quality.HIGH:
             return image0, image1
         if quality == Quality.MEDIUM:
-            return pyr_down(image0), pyr_down(image1)
+            return pyr_down(image0, self.engine), pyr_down(image1, self.engine)
         if quality == Quality.LOW:
-            return pyr_down(pyr_down(image0)), pyr_down(pyr_down(image1))
+            return pyr_down(image0, self.engine, 2), pyr_down(image1, self.engine, 2)
         raise ValueError(f"unknown quality {quality}")
 
     def _resize_features(self, quality: Quality, features0: FeaturesBase, features1: FeaturesBase):

@@ -162,6 +162,12 @@ int im_assign_from_sim(im_ctx* ctx, const float* d_sim, int m, int n, int ld, co
 int im_log_optimal_transport(im_ctx* ctx, const float* d_scores, int m, int n, int ld, float bin_score, int iters,
                              float* d_out, void* stream);
 
+/* ---- Gaussian pyramid steps on uint8 images [n_images][h][w][channels] (channels interleaved, 1..4), what `Quality` resizing and
+ * tile preselection call through OpenCV in the reference (`cv2.pyrDown` / `cv2.pyrUp`, `matchers.py:529-530, 599-609`):
+ * im_pyr_down -> [n_images][(h + 1) / 2][(w + 1) / 2][channels], im_pyr_up -> [n_images][2 h][2 w][channels]. Enqueue only. */
+int im_pyr_down(im_ctx* ctx, const uint8_t* d_in, uint8_t* d_out, int n_images, int h, int w, int channels, void* stream);
+int im_pyr_up(im_ctx* ctx, const uint8_t* d_in, uint8_t* d_out, int n_images, int h, int w, int channels, void* stream);
+
 /* ---- tile mode (`ImageMatcherBase._match_by_tile`, `matchers.py:304-469`) -----------------------------------------------
  * The tail of the tile loop for ALL tile pairs of an image pair in one call (`matchers.py:402-448`): valid matches of every
  * pair are shifted to image coordinates ((kpt + tile origin) + image origin, fp32), concatenated in tile-pair order, and

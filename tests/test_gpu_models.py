@@ -831,13 +831,29 @@ def test_select_topk_multiblock_with_ties_at_the_cut(k):
     e.close()
 
 
+@pytest.mark.parametrize("shape", [(37, 50), (64, 96, 3), (1, 7), (2, 2, 3), (481, 643, 3), (300, 401, 4)])
+def test_pyramid_kernels_bit_exact(shape):
+    """im_pyr_down / im_pyr_up (`cv2.pyrDown` / `cv2.pyrUp` of `matchers.py:529-530, 599-609`) against the numpy restatement:
+    odd sizes, 1 / 3 / 4 interleaved channels, degenerate sizes, several levels without leaving the device."""
+    from icepy4d_amd.matching import pyramid
+    from icepy4d_amd.matching.matchers import get_engine
+    from oracle import pyramid_cpu
+    eng = get_engine(0)
+    img = np.random.default_rng(sum(shape)).integers(0, 256, size=shape, dtype=np.uint8)
+    assert np.array_equal(pyramid.pyr_down(img, eng), pyramid_cpu.pyr_down(img))
+    assert np.array_equal(pyramid.pyr_up(img, eng), pyramid_cpu.pyr_up(img))
+    assert np.array_equal(pyramid.pyr_down(img, eng, 3), pyramid_cpu.pyr_down(pyramid_cpu.pyr_down(pyramid_cpu.pyr_down(img))))
+    assert np.array_equal(pyramid.pyr_up(img, eng, 2), pyramid_cpu.pyr_up(pyramid_cpu.pyr_up(img)))
+
+
 def test_preselection_selects_the_oracle_tile_pairs():
     """TileSelection.PRESELECTION (`matchers.py:513-560`): pyramid down, one low-resolution match with 4096 keypoints, keypoints
     scaled back by 2^n, a tile pair is kept when MORE than `min_matches_per_tile` matches fall strictly inside both tiles. The
-    matcher's selection against the same rule evaluated on the oracle's matches of the same pyramid images (the cv2.pyrDown
-    restatement is cross-checked on the CPU, tests/test_host_cpu.py::test_pyramid; parity with a cv2 build is unpinned)."""
+    matcher's selection (pyramid on the device) against the same rule evaluated on the oracle's matches of the oracle's pyramid
+    images (the cv2.pyrDown restatement is cross-checked on the CPU, tests/test_host_cpu.py::test_pyramid; parity with a cv2
+    build is unpinned)."""
     from icepy4d_amd.matching import LightGlueMatcher, TileSelection
-    from icepy4d_amd.matching.pyramid import pyr_down
+    from oracle.pyramid_cpu import pyr_down
     from icepy4d_amd.matching.tiling import Tiler
     from itertools import product
     o = oracle()

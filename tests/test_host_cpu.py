@@ -67,7 +67,9 @@ def test_enums_match_reference_values():
 
 
 def test_pyramid():
-    from icepy4d_amd.matching.pyramid import pyr_down, pyr_up
+    """The numpy restatement of cv2.pyrDown / pyrUp that the device kernels are held to (tests/test_gpu_models.py), against
+    hand-computed samples and an independent scipy formulation."""
+    from oracle.pyramid_cpu import pyr_down, pyr_up
     a = np.full((37, 50), 100, np.uint8)
     assert pyr_down(a).shape == (19, 25) and (pyr_down(a) == 100).all()
     assert pyr_up(a).shape == (74, 100) and (pyr_up(a) == 100).all()

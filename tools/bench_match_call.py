@@ -20,3 +20,16 @@ for name, sel, gv in cases:
                 max_keypoints=K, geometric_verification=gv, threshold=2)
         dt = time.perf_counter() - t0
         print(f"{name:38s} rep {r}: {dt * 1e3:.1f} ms, {len(m.mkpts0)} points", flush=True)
+
+if os.environ.get("IM_BENCH_TILES", "1") == "1":
+    # production-like call (`main_dev.py:115-132`): 12 MP RGB pair, 3 x 3 grid with overlap, 8192 keypoints per tile
+    a, b = synthetic.translated_pair(1, 3000, 4000, 48, 16)
+    a3, b3 = np.repeat(a[:, :, None], 3, 2), np.repeat(b[:, :, None], 3, 2)
+    for name, sel in (("12 MP RGB, GRID 3x3, 8192 kpts/tile", matching.TileSelection.GRID),
+                      ("12 MP RGB, PRESELECTION 3x3, 8192 kpts/tile", matching.TileSelection.PRESELECTION)):
+        for r in range(3):
+            t0 = time.perf_counter()
+            m.match(a3, b3, quality=matching.Quality.HIGH, tile_selection=sel, grid=[3, 3], overlap=200,
+                    max_keypoints=8192, geometric_verification=matching.GeometricVerification.NONE)
+            dt = time.perf_counter() - t0
+            print(f"{name:46s} rep {r}: {dt * 1e3:.1f} ms, {len(m.mkpts0)} points", flush=True)

@@ -11,6 +11,7 @@ python3 $root/bench.py > $out/bench.json 2> $out/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats1 -- python3 $root/bench.py --no-cpu-baseline --no-side-measurements --streams 1 --batch 1 > $out/bench_streams1_under_rocprof.json 2> /dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_default -- python3 $root/bench.py --no-cpu-baseline --no-side-measurements > $out/bench_default_under_rocprof.json 2> /dev/null
 python3 $root/bench.py --config 5 > $out/bench_config5.json 2> $out/bench_config5.err
+python3 $root/bench.py --config 3 --no-cpu-baseline > $out/bench_config3.json 2> $out/bench_config3.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_config5 -- python3 $root/bench.py --config 5 --steps 3 --warmup 1 > $out/bench_config5_under_rocprof.json 2> /dev/null
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_lg_$c -- python3 $root/tools/run_pair_once.py lightglue 2 > /dev/null 2>&1
