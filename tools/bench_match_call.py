@@ -33,3 +33,18 @@ if os.environ.get("IM_BENCH_TILES", "1") == "1":
                     max_keypoints=8192, geometric_verification=matching.GeometricVerification.NONE)
             dt = time.perf_counter() - t0
             print(f"{name:46s} rep {r}: {dt * 1e3:.1f} ms, {len(m.mkpts0)} points", flush=True)
+
+if os.environ.get("IM_BENCH_PRODUCTION", "1") == "1":
+    # the call of `main_dev.py:115-132` with its own parameters, on a synthetic 24 MP RGB pair whose texture survives the two
+    # pyramid levels of the preselection pass (a translated 1000 x 1500 pair, every pixel blown up to a 4 x 4 block)
+    ha, hb = synthetic.translated_pair(3, 1000, 1500, 24, 8, noise=0.0)
+    a3 = np.repeat(np.kron(ha, np.ones((4, 4), np.uint8))[:, :, None], 3, 2)
+    b3 = np.repeat(np.kron(hb, np.ones((4, 4), np.uint8))[:, :, None], 3, 2)
+    for r in range(3):
+        t0 = time.perf_counter()
+        m.match(a3, b3, quality=matching.Quality.HIGH, tile_selection=matching.TileSelection.PRESELECTION, grid=[2, 2], overlap=200,
+                origin=[0, 0], min_matches_per_tile=3, max_keypoints=8196,
+                geometric_verification=matching.GeometricVerification.PYDEGENSAC, threshold=2, confidence=0.9999)
+        dt = time.perf_counter() - t0
+        print(f"main_dev.py call, 24 MP RGB, PRESELECTION 2x2   rep {r}: {dt * 1e3:.1f} ms, {len(m.mkpts0)} points; "
+              + ", ".join(f"{k} {v * 1e3:.1f}" for k, v in m.timer.times.items()), flush=True)
