@@ -145,6 +145,79 @@ def run_case(eng, img0, img1, sp_sd, lg_sd, max_k, lg_conf=None, radius=4, thr=0
     return rep
 
 
+def run_case_superglue(eng, img0, img1, sp_sd, sg_sd, max_k, radius=3, thr=0.001, border=4, iters=20, match_thr=0.3):
+    """The same chain A-D for the SuperGlue flavour (`SuperGlueMatcher._match_images`, `matchers.py:892-940`): MagicLeap-flavour
+    SuperPoint selection, keypoint encoder + 18 GNN layers + optimal transport + mutual filter; C uses the oracle's optimal
+    transport matrix of the DEVICE's features for the arg-max / threshold margins. The engine must hold `sg_sd`."""
+    from oracle import ref_cpu as o
+    h, w = img0.shape
+    assert img1.shape == img0.shape
+    H8, W8 = (h // 8) * 8, (w // 8) * 8
+    eng.reserve(h, w, 2, max_k)
+    pair = torch.from_numpy(np.stack([img0, img1])).cuda()
+    eng.superpoint(pair, radius, thr, border, max_k, flavour=1)
+    torch.cuda.synchronize()
+    smap_d = _read(eng, "sp_smap", 2 * H8 * W8).view(2, H8, W8)
+    rep = {"shape": [h, w], "max_k": max_k, "flavour": "superglue", "images": []}
+    feats_d, feats_o = [], []
+    for b, img in enumerate((img0, img1)):
+        kp, desc, sc = eng.features_to_host(b)
+        with torch.inference_mode():
+            feat = o.sp_encoder(torch.tensor(img / 255.0, dtype=torch.float)[None, None], sp_sd)   # `matchers.py:263-274`
+            smap_o = o.sp_score_map(feat, sp_sd)
+            nms_o = o.simple_nms(smap_o, radius)
+            ref_kp_t, ref_sc_t = o.select_keypoints_sg(nms_o[0], border, thr, max_k)
+            ref_desc_t = o.sample_descriptors(ref_kp_t, o.sp_dense_descriptors(feat, sp_sd)[0])     # [256, K]
+            nms_on_d = o.simple_nms(smap_d[b][None], radius)[0]
+            kp_b, sc_b = o.select_keypoints_sg(nms_on_d, border, thr, max_k)
+        err = float((smap_d[b] - smap_o[0]).abs().max())
+        eps = min(max(4.0 * err, 1e-9), 1e-5)
+        ref_kp, ref_sc, ref_desc = ref_kp_t.numpy(), ref_sc_t.numpy(), ref_desc_t.numpy().T
+        ex = margins.explain_keypoint_diffs(smap_o[0], nms_o[0], kp, ref_kp, radius, border, thr, max_k, eps)
+        ours = {tuple(q): i for i, q in enumerate(kp)}
+        common = [(ours[tuple(q)], j) for j, q in enumerate(ref_kp) if tuple(q) in ours]
+        ii, jj = (np.array(common).T if common else (np.zeros(0, int), np.zeros(0, int)))
+        order = margins.explain_order_diffs(kp, ref_kp, ref_sc, eps)
+        rep["images"].append({
+            "score_map_max_abs_err": err, "eps": eps, "n_keypoints": int(len(kp)), "n_keypoints_oracle": int(len(ref_kp)),
+            "keypoint_set_diff": ex["n_diff"], "diff_reasons": ex["reasons"], "unexplained": ex["unexplained"],
+            "same_order": bool(kp.shape == ref_kp.shape and np.array_equal(kp, ref_kp)),
+            "ranks_moved": order["n_moved"], "ranks_moved_exact_ties": order["n_exact_ties"], "ranks_moved_max_score_gap": order["max_gap"],
+            "ranks_moved_unexplained": order["unexplained"],
+            "score_max_abs_err_common": float(np.abs(sc[ii] - ref_sc[jj]).max()) if len(ii) else 0.0,
+            "desc_max_abs_err_common": float(np.abs(desc[ii] - ref_desc[jj]).max()) if len(ii) else 0.0,
+            "integer_stages_exact_on_device_map": bool(_tie_groups_equal(kp, sc, kp_b.numpy(), sc_b.numpy()))})
+        feats_d.append((kp, desc, sc))
+        feats_o.append((ref_kp_t, ref_desc_t, ref_sc_t))
+    eng.superglue((h, w), (h, w), sinkhorn_iterations=iters, match_threshold=match_thr)
+    torch.cuda.synchronize()
+    (k0, d0, s0), (k1, d1, s1) = feats_d
+    out = eng.matches_to_host(len(k0), len(k1))
+
+    def data(f0, f1):
+        return dict(keypoints0=f0[0], keypoints1=f1[0], descriptors0=f0[1], descriptors1=f1[1], scores0=f0[2], scores1=f1[2],
+                    shape0=(h, w), shape1=(h, w))
+    with torch.inference_mode():
+        tr = {}
+        dev0 = (torch.from_numpy(k0), torch.from_numpy(d0).T.contiguous(), torch.from_numpy(s0))
+        dev1 = (torch.from_numpy(k1), torch.from_numpy(d1).T.contiguous(), torch.from_numpy(s1))
+        same = o.superglue(data(dev0, dev1), sg_sd, iters, match_thr, trace=tr)      # C: oracle matcher on the device's features
+        e2e = o.superglue(data(feats_o[0], feats_o[1]), sg_sd, iters, match_thr)     # D: oracle from pixels
+    m0_same = same["matches0"].numpy()
+    exm = margins.explain_match_diffs(tr["ot"], out["matches0"], m0_same, match_thr, 1e-4)
+    v = (out["matches0"] > -1) & (m0_same > -1)
+    rep["matching_same_features"] = {
+        "n0": int(len(k0)), "n1": int(len(k1)), "n_matches_device": int((out["matches0"] > -1).sum()),
+        "n_matches_oracle": int((m0_same > -1).sum()), "matches0_diff": exm["n_diff"], "diff_reasons": exm["reasons"],
+        "unexplained": exm["unexplained"], "stop_device": 0, "stop_oracle": 0, "prune0_equal": True, "prune1_equal": True,
+        "mscore_max_abs_err": float(np.abs(out["matching_scores0"][v] - same["matching_scores0"].numpy()[v]).max()) if v.any() else 0.0}
+    ours = margins.match_pairs(k0, k1, out["matches0"])
+    theirs = margins.match_pairs(feats_o[0][0].numpy(), feats_o[1][0].numpy(), e2e["matches0"].numpy())
+    rep["end_to_end"] = {"pairs_device": len(ours), "pairs_oracle": len(theirs), "pairs_common": len(ours & theirs),
+                         "identical": bool(ours == theirs)}
+    return rep
+
+
 def cases(full: bool):
     from conftest import load_golden
     g1a, g1b, g4, g5 = (load_golden(n) for n in ("g1_superpoint_a", "g1_superpoint_b", "g4_wrappers", "g5_assets"))
@@ -163,6 +236,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "parity.json"))
     ap.add_argument("--no-full", action="store_true")
+    ap.add_argument("--epochs", type=int, default=0, help="additional configs[1] bench pairs (epochs 1..N), LightGlue")
+    ap.add_argument("--superglue", action="store_true", help="SuperGlue-flavour cases (SuperPoint nms 3 + SuperGlue), incl. 1080p / 4096")
     args = ap.parse_args()
     from icepy4d_amd.engine import Engine
     torch.set_num_threads(min(32, os.cpu_count() or 1))
@@ -177,6 +252,43 @@ def main():
         report["cases"][name] = run_case(eng, a, b, sp_sd, lg_sd, k)
         report["cases"][name]["seconds"] = round(time.time() - t, 1)
         print(name, json.dumps(report["cases"][name]), flush=True)
+    for e in range(1, args.epochs + 1):
+        a, b = synthetic.stereo_pair(e, 1080, 1920)
+        name = f"config 2 bench pair, epoch {e} (1080x1920, K=4096)"
+        report["cases"][name] = run_case(eng, a, b, sp_sd, lg_sd, 4096)
+        print(name, json.dumps(report["cases"][name]), flush=True)
+    if args.superglue:
+        from conftest import load_golden
+        sg_sd = synthetic.superglue_state_dict(0, "passthrough")
+        eng.load_state_dict("superglue", sg_sd)
+        g4, g5 = load_golden("g4_wrappers"), load_golden("g5_assets")
+        sg_cases = [("superglue: g4 wrappers pair (200x304, K=256)", g4["image0"], g4["image1"], 256),
+                    ("superglue: g5 assets pair (800x1200, K=2048)", g5["gray0"], g5["gray1"], 2048)]
+        if not args.no_full:
+            a, b = synthetic.translated_pair(0, 1080, 1920, 40, 8)
+            sg_cases.append(("superglue: translated pair (1080x1920, K=4096)", a, b, 4096))
+        for name, a, b, k in sg_cases:
+            t = time.time()
+            report["cases"][name] = run_case_superglue(eng, a, b, sp_sd, sg_sd, k)
+            report["cases"][name]["seconds"] = round(time.time() - t, 1)
+            print(name, json.dumps(report["cases"][name]), flush=True)
+    tot = {"cases": len(report["cases"]), "images": 0, "keypoints": 0, "keypoint_set_diff": 0, "keypoint_unexplained": 0, "ranks_moved": 0,
+           "ranks_unexplained": 0, "matches0_compared": 0, "matches0_diff": 0, "matches0_unexplained": 0, "end_to_end_identical": 0}
+    for c in report["cases"].values():
+        for im in c["images"]:
+            tot["images"] += 1
+            tot["keypoints"] += im["n_keypoints"]
+            tot["keypoint_set_diff"] += im["keypoint_set_diff"]
+            tot["keypoint_unexplained"] += len(im["unexplained"])
+            tot["ranks_moved"] += im["ranks_moved"]
+            tot["ranks_unexplained"] += len(im["ranks_moved_unexplained"])
+        m = c["matching_same_features"]
+        tot["matches0_compared"] += m["n0"]
+        tot["matches0_diff"] += m["matches0_diff"]
+        tot["matches0_unexplained"] += len(m["unexplained"])
+        tot["end_to_end_identical"] += int(c["end_to_end"]["identical"])
+    report["totals"] = tot
+    print("totals", json.dumps(tot), flush=True)
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     with open(args.out, "w") as fh:
         json.dump(report, fh, indent=1)

@@ -103,6 +103,27 @@ def test_config2_full_size_exact_or_explained(eng, kind):
         assert rep["end_to_end"]["pairs_oracle"] > 500
 
 
+@pytest.mark.parametrize("case", ["g4", "assets"])
+def test_superglue_flavour_exact_or_explained(case):
+    """The SuperGlue path from pixels (`SuperGlueMatcher._match_images`, `matchers.py:892-940`): MagicLeap-flavour SuperPoint
+    (nms 3, threshold 0.001, border after threshold), keypoint encoder, 18 GNN layers, 20 Sinkhorn iterations, mutual filter at 0.3;
+    keypoints and match indices exact or margin-explained against the oracle, identical matched pairs."""
+    from icepy4d_amd.engine import Engine
+    sg_sd = synthetic.superglue_state_dict(0, "passthrough")
+    e = Engine(0)
+    e.load_state_dict("superpoint", SP_SD)
+    e.load_state_dict("superglue", sg_sd)
+    if case == "g4":
+        g = load_golden("g4_wrappers")
+        rep = parity_report.run_case_superglue(e, g["image0"], g["image1"], SP_SD, sg_sd, 256)
+    else:
+        g = load_golden("g5_assets")
+        rep = parity_report.run_case_superglue(e, g["gray0"], g["gray1"], SP_SD, sg_sd, 2048)
+    assert_exact_or_explained(rep)
+    assert rep["end_to_end"]["pairs_oracle"] > 0
+    e.close()
+
+
 @pytest.mark.parametrize("variant,conf", [("earlystop", {}), ("prune", {"depth_confidence": -1}), ("passthrough", {"pruning_min_kpts": 200})])
 def test_adaptive_depth_and_width_from_pixels(variant, conf):
     """Early stop (token-confidence weights that satisfy the stop criterion after a few layers), point pruning (matchability
