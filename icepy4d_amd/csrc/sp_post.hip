@@ -140,8 +140,11 @@ static hipError_t launch_nms_staged(const float* s, float* out, uint8_t* mask, u
 //   keep2 = keep1 | (rest2 == pool(rest2) & ~near2)  on the tile             -> out = keep2 ? S : 0
 // S therefore needs a halo of 5r <= 20 pixels (r <= 4). Geometry is fixed for every r: 32 x 56 output tile, region 72 x 96
 // = three 32-bit mask words per row. Pools are separable sliding maxima computed in registers (a thread takes 16 outputs
-// of a column, then 32 outputs of a row: ~0.2 LDS instructions per pixel and pass instead of 2 (2r+1)); keep / near are
-// BIT masks, their dilation is shifts and ORs on 96-bit rows.
+// of a column, then 16 outputs of a row, two v_max3 per output: ~0.2 LDS instructions per pixel and pass instead of
+// 2 (2r+1)); keep / near are BIT masks, their dilation is ORs of 96-bit rows and shifts, one (row, word) per thread.
+// Where the time goes (timing ablation on 2 x 1080p maps, kernel alone 44 us): launch + mask clear + tile stores 7, region
+// load 5, per round vertical pass 4 + horizontal pass 5.6, dilation + zeroing 6 per refinement round - every phase is a
+// barrier-separated latency chain of a few LDS round trips (the instruction-throughput bound of the whole kernel is ~14 us).
 // Epilogue (optional): the tile's keypoint candidates (score > threshold, outside the border frame; `superpoint.py:177-187`)
 // are appended to the image's key list (one global atomic per block; order does not matter: the selection stage ranks) and
 // counted into the first radix histogram of the top-k selection.
@@ -157,25 +160,31 @@ struct SelState {            // per image, zeroed by launch_* before every use
     int n_sel, n_eq, pad0, pad1;
 };
 
-// sliding maximum of width 2R+1 over v[0 .. N + 2R): out[i] = max(v[i .. i + 2R]), in place into v[0 .. N)
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+// sliding maximum of width 2R+1 over v[0 .. N + 2R): out[i] = max(v[i .. i + 2R]), in place into v[0 .. N).
+// Two v_max3 steps per output (R >= 2): w3[i] = max(v[i .. i + 2]), then three (two) w3 windows that tile the 2R+1 range.
 template <int R, int N>
 __device__ __forceinline__ void sliding_max(float (&v)[N + 8]) {
-    constexpr int Wd = 2 * R + 1;
-    constexpr int P = Wd >= 8 ? 8 : (Wd >= 4 ? 4 : 2);
+    static_assert(R >= 1 && R <= 4, "window 3 .. 9");
     constexpr int L = N + 2 * R;   // valid inputs
-    // doubling, in place (ascending i reads only entries not yet overwritten): after the step of width d, v[i] = max(v[i .. i + d))
+    if constexpr (R == 1) {
 #pragma unroll
-    for (int i = 0; i < L - 1; ++i) v[i] = fmaxf(v[i], v[i + 1]);                           // width 2
-    if constexpr (P >= 4) {
+        for (int i = 0; i < N; ++i) v[i] = vmax3(v[i], v[i + 1], v[i + 2]);
+    } else {
+        // in place, ascending i reads only entries not yet overwritten
 #pragma unroll
-        for (int i = 0; i < L - 3; ++i) v[i] = fmaxf(v[i], v[i + 2]);                       // width 4
+        for (int i = 0; i < L - 2; ++i) v[i] = vmax3(v[i], v[i + 1], v[i + 2]);
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            if constexpr (R == 2) v[i] = fmaxf(v[i], v[i + 2]);
+            else v[i] = vmax3(v[i], v[i + R - 1], v[i + 2 * R - 2]);
+        }
     }
-    if constexpr (P >= 8) {
-#pragma unroll
-        for (int i = 0; i < L - 7; ++i) v[i] = fmaxf(v[i], v[i + 4]);                       // width 8
-    }
-#pragma unroll
-    for (int i = 0; i < N; ++i) v[i] = fmaxf(v[i], v[i + Wd - P]);                          // width 2R+1 = two overlapping width-P windows
 }
 
 __device__ __forceinline__ unsigned long long cand_key(float v, unsigned flat_idx) {
@@ -193,7 +202,6 @@ __global__ __launch_bounds__(nf::NT, 4) void nms_fused_kernel(const float* __res
     float* T = lds + RH * PITCH;
     unsigned* keepm = reinterpret_cast<unsigned*>(lds + 2 * RH * PITCH);   // [RH][4]
     unsigned* nearm = keepm + RH * 4;                                        // [RH][4]
-    unsigned* hdil = reinterpret_cast<unsigned*>(T);                         // [RH][4], alive only while T is not
     const int tid = threadIdx.x;
     // XCD-aware block -> tile map: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8), each with its own L2. XCD x
     // takes the x-th contiguous eighth of the tile list (a band of tile rows), so the 20-pixel halos neighbouring tiles share are
@@ -239,26 +247,24 @@ __global__ __launch_bounds__(nf::NT, 4) void nms_fused_kernel(const float* __res
     for (int st = 0; st < 3; ++st) {
         const int inset = HALO - (2 - st) * 2 * R;       // keep_st is needed on rows / columns [inset, R? - inset)
         if (st > 0) {
-            // ---- near = dilate_r(keep) on [inset - R, ..): horizontal on 96-bit rows, then vertical OR
-            const int r_lo = inset - 2 * R, r_hi = RH - inset + 2 * R;       // rows of keep_{st-1}
-            if (tid >= r_lo && tid < r_hi) {
-                const unsigned k0 = keepm[tid * 4], k1 = keepm[tid * 4 + 1], k2 = keepm[tid * 4 + 2];
-                unsigned d0 = k0, d1 = k1, d2 = k2;                       // 96-bit row k2:k1:k0, bit x = column x
-#pragma unroll
-                for (int i = 1; i <= R; ++i) {
-                    d0 |= (k0 << i) | (k0 >> i) | (k1 << (32 - i));
-                    d1 |= (k1 << i) | (k0 >> (32 - i)) | (k1 >> i) | (k2 << (32 - i));
-                    d2 |= (k2 << i) | (k1 >> (32 - i)) | (k2 >> i);
-                }
-                hdil[tid * 4] = d0; hdil[tid * 4 + 1] = d1; hdil[tid * 4 + 2] = d2;
-            }
-            __syncthreads();
+            // ---- near = dilate_r(keep) on rows / columns [inset - R, ..): vertical OR of the 96-bit keep rows, then the horizontal
+            // dilation of the OR (the two commute), one (row, word) per thread, no intermediate buffer and no barrier in between
             const int n_lo = inset - R, n_rows = RH - 2 * (inset - R);
             if (tid < n_rows * NW) {
                 const int w = tid / n_rows, ry = n_lo + tid - w * n_rows;
-                unsigned m = 0;
+                unsigned k0 = 0, k1 = 0, k2 = 0;
 #pragma unroll
-                for (int dy = -R; dy <= R; ++dy) m |= hdil[(ry + dy) * 4 + w];
+                for (int dy = -R; dy <= R; ++dy) {
+                    const uint4 kr = *reinterpret_cast<const uint4*>(keepm + (ry + dy) * 4);
+                    k0 |= kr.x; k1 |= kr.y; k2 |= kr.z;
+                }
+                unsigned m = w == 0 ? k0 : (w == 1 ? k1 : k2);           // 96-bit row k2:k1:k0, bit x = column x
+#pragma unroll
+                for (int i = 1; i <= R; ++i) {
+                    if (w == 0) m |= (k0 << i) | (k0 >> i) | (k1 << (32 - i));
+                    else if (w == 1) m |= (k1 << i) | (k0 >> (32 - i)) | (k1 >> i) | (k2 << (32 - i));
+                    else m |= (k2 << i) | (k1 >> (32 - i)) | (k2 >> i);
+                }
                 nearm[ry * 4 + w] = m;
                 // rest = near ? 0 : S, in place (in-image pixels only: the padding stays -inf)
                 const int gy = y0 - HALO + ry;
@@ -301,38 +307,41 @@ __global__ __launch_bounds__(nf::NT, 4) void nms_fused_kernel(const float* __res
             }
         }
         __syncthreads();
-        // ---- horizontal pass + equality test: 32 outputs of one row per thread -> one mask word
+        // ---- horizontal pass + equality test: 16 outputs of one row per thread -> one half of a mask word (6 x nrow tasks keep
+        // most of the 512 threads busy; a thread owns its half word, so keep is updated without atomics)
         {
             const int r_lo = inset, nrow = RH - 2 * inset;
-            if (tid < nrow * NW) {
-                const int w = tid / nrow, ry = r_lo + tid - w * nrow;
-                const float4* tr = reinterpret_cast<const float4*>(T + ry * PITCH + PAD + 32 * w - 4);   // columns 32w-4 .. 32w+35
-                float v[32 + 8];
+            if (tid < nrow * 2 * NW) {
+                const int seg = tid / nrow, ry = r_lo + tid - seg * nrow;
+                const int w = seg >> 1, sh = 16 * (seg & 1);
+                const float4* tr = reinterpret_cast<const float4*>(T + ry * PITCH + PAD + 16 * seg - 4);   // columns 16 seg - 4 .. 16 seg + 19
+                float v[16 + 8];
 #pragma unroll
-                for (int q = 0; q < 10; ++q) { const float4 t4 = tr[q]; v[4 * q] = t4.x; v[4 * q + 1] = t4.y; v[4 * q + 2] = t4.z; v[4 * q + 3] = t4.w; }
-                // window of output i starts at column 32w + i - R = v index i + 4 - R
+                for (int q = 0; q < 6; ++q) { const float4 t4 = tr[q]; v[4 * q] = t4.x; v[4 * q + 1] = t4.y; v[4 * q + 2] = t4.z; v[4 * q + 3] = t4.w; }
+                // window of output i starts at column 16 seg + i - R = v index i + 4 - R
                 if constexpr (R < 4) {
 #pragma unroll
-                    for (int i = 0; i < 32 + 2 * R; ++i) v[i] = v[i + 4 - R];
+                    for (int i = 0; i < 16 + 2 * R; ++i) v[i] = v[i + 4 - R];
                 }
-                sliding_max<R, 32>(v);
-                const float4* cr = reinterpret_cast<const float4*>(S + ry * PITCH + PAD + 32 * w);
+                sliding_max<R, 16>(v);
+                const float4* cr = reinterpret_cast<const float4*>(S + ry * PITCH + PAD + 16 * seg);
                 unsigned eq = 0;
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
+                for (int q = 0; q < 4; ++q) {
                     const float4 c4 = cr[q];
                     eq |= (c4.x == v[4 * q] ? 1u : 0u) << (4 * q);
                     eq |= (c4.y == v[4 * q + 1] ? 1u : 0u) << (4 * q + 1);
                     eq |= (c4.z == v[4 * q + 2] ? 1u : 0u) << (4 * q + 2);
                     eq |= (c4.w == v[4 * q + 3] ? 1u : 0u) << (4 * q + 3);
                 }
-                // valid outputs: columns [inset, RW - inset) of this word, inside the image, not suppressed
-                const int lo = max(inset - 32 * w, 0), hi = min(RW - inset - 32 * w, 32);
-                unsigned vm = (hi > lo) ? ((hi - lo == 32 ? 0xFFFFFFFFu : ((1u << (hi - lo)) - 1u)) << lo) : 0u;
+                // valid outputs: columns [inset, RW - inset) of this half word, inside the image, not suppressed
+                const int lo = max(inset - 16 * seg, 0), hi = min(RW - inset - 16 * seg, 16);
+                unsigned vm = (hi > lo) ? (((1u << (hi - lo)) - 1u) << lo) : 0u;
                 const int gy = y0 - HALO + ry;
-                vm = (gy >= 0 && gy < H) ? (vm & colmask[w]) : 0u;
-                if (st > 0) vm &= ~nearm[ry * 4 + w];
-                keepm[ry * 4 + w] |= eq & vm;
+                vm = (gy >= 0 && gy < H) ? (vm & (colmask[w] >> sh)) : 0u;
+                if (st > 0) vm &= ~(nearm[ry * 4 + w] >> sh);
+                unsigned short* kh = reinterpret_cast<unsigned short*>(keepm) + ry * 8 + seg;
+                *kh = (unsigned short)(*kh | (eq & vm & 0xFFFFu));
             }
         }
         __syncthreads();
