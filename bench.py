@@ -216,6 +216,7 @@ def main():
     while i < args.warmup:
         sm.match_pair(pool[i % len(pool)], epochs[i % len(epochs)], scratch, i % scratch.shape[0])
         i += 1
+    sm.flush()                                  # an odd W must not leave a parked pair behind: it would join the first timed group
     sm.synchronize()
     t_w = time.perf_counter()
     prev, stable = None, 0
@@ -225,6 +226,7 @@ def main():
         for _ in range(nb):
             sm.match_pair(pool[i % len(pool)], epochs[i % len(epochs)], scratch, i % scratch.shape[0])
             i += 1
+        sm.flush()
         sm.synchronize()
         cur = time.perf_counter() - t_b
         stable = stable + 1 if prev is not None and abs(cur - prev) < 0.02 * prev else 0
@@ -313,7 +315,7 @@ def main():
         psm.P = 1
         with torch.cuda.stream(pstream):
             for i in range(prof_steps):
-                psm.match_pair(pool[i % len(pool)], epochs[i], scratch, 0)
+                psm.match_pair(pool[i % len(pool)], epochs[i % len(epochs)], scratch, 0)
             pstream.synchronize()
         buf = ctypes.create_string_buffer(1 << 16)
         lib.call("im_profile_end", buf, len(buf))

@@ -200,7 +200,9 @@ class SequenceMatcher:
         pend, self._pending = self._pending, []
         if not pend:
             return
-        if not self.use_graph:
+        if not self.use_graph or len(pend) < self.P:
+            # direct launches; also for a partially filled group (the tail of a sequence whose length is not a multiple of the
+            # pairs per launch): only the parked pairs are computed, the captured graph always runs all P
             self._enqueue(self._inp[:2 * len(pend)] if self.P > 1 else self._inp)
             self._record(self._rec, 0, 0, len(pend))
         else:
@@ -227,8 +229,7 @@ class SequenceMatcher:
             self._run_group()
 
     def flush(self) -> None:
-        """Run a partially filled group (the remaining slots of the static input still hold earlier pairs: their results are
-        computed and dropped)."""
+        """Run a partially filled group (direct launches for just the parked pairs)."""
         self._run_group()
 
     def run(self, pairs: Sequence[torch.Tensor], epochs: Sequence[int], table: Optional[torch.Tensor] = None) -> torch.Tensor:
