@@ -68,7 +68,7 @@ for fn in glob.glob(f"{src}/pmc_attn_sq/**/*counter_collection.csv", recursive=T
         fh.write("counter,mean,launches\n")
         for k, v in agg.items():
             fh.write(f"{k},{sum(v)/len(v):.1f},{len(v)}\n")
-for name in ("bench.json", "bench_streams1_under_rocprof.json", "bench_default_under_rocprof.json", "bench_config5.json", "bench_config3.json",
+for name in ("bench.json", "bench_streams1_under_rocprof.json", "bench_default_under_rocprof.json", "bench_config5.json", "bench_config3.json", "bench_steps20_warmup5.json",
              "bench_config5_under_rocprof.json", "parity_winograd.json", "parity_direct_conv.json"):
     p = os.path.join(src, name)
     if os.path.exists(p) and os.path.getsize(p):
