@@ -298,7 +298,32 @@ def main():
         alt.close()
         tr_pool = [torch.from_numpy(np.stack(synthetic.translated_pair(j, h, w, 40, 8))).cuda().contiguous() for j in range(2)]
         r_tr, m_tr = quick_rate(sm, tr_pool, 48)
+        adaptive = {}
+        for variant in ("earlystop", "prune"):   # weights whose token confidences stop early / whose matchabilities prune points
+            v_sd = synthetic.lightglue_state_dict(0, variant)
+
+            def make_variant_engine():
+                e = Engine(local_rank)
+                e.load_state_dict("superpoint", sp_sd)
+                e.load_state_dict("lightglue", v_sd)
+                return e
+            vp = PairPipeline(make_variant_engine, h, w, kpts, n_streams=n_streams, use_graph=not args.no_graph, matcher=m_name,
+                              pairs_per_launch=args.batch)
+            side = new_table(48, kpts, eng.device)
+            for j in range(12):
+                vp.match_pair(tr_pool[j % 2], j, side, j)
+            vp.flush(); vp.synchronize()
+            t_v = time.perf_counter()
+            for j in range(48):
+                vp.match_pair(tr_pool[j % 2], j, side, j)
+            vp.flush(); vp.synchronize()
+            adaptive[variant] = {"pairs_per_s": 48 / (time.perf_counter() - t_v), "mean_stop_layer": side[:, 4].float().mean().item(),
+                                 "mean_matches": side[:, 3].float().mean().item(), "pairs": 48}
+            vp.close()
         result["side_measurements"] = {
+            "adaptive_depth_and_width": dict(adaptive, note="the same launches with seeded weights built so that the early-stop criterion "
+                                             "(`lightglue.py:571-579`) resp. point pruning (`:563-568`) DO trigger on the translated pairs: the "
+                                             "device-side stop flag skips the remaining layers' kernels, pruned images run on the live rows only"),
             "other_launch_mode": {"pairs_per_launch": alt_b, "pairs_in_flight": alt_s, "pairs_per_s": r_alt, "pairs": 48},
             "translated_pairs": {"pairs_per_s": r_tr, "mean_matches": m_tr, "pairs": 48,
                                  "note": "pairs related by a pure (40, 8) px translation: the seeded weights match ~1000 keypoints "
