@@ -282,6 +282,12 @@ int im_finalize_weights(im_ctx* ctx, const char* model) {
 int im_ctx_reserve(im_ctx* ctx, int max_h, int max_w, int max_images, int max_kpts) {
     IM_CHECK_CTX(ctx);
     if (max_h < 8 || max_w < 8 || max_images < 1 || max_kpts < 1) return ctx->fail(-30, "im_ctx_reserve: bad sizes");
+    // the kernels address one image / one score matrix through 32-bit buffer offsets (range-checked descriptors): fail loudly
+    // instead of wrapping around. Larger inputs go through the tile modes of the matcher (`matchers.py:304-469`).
+    if ((long)(max_h / 2) * (max_w / 2) * 64 * 4 >= (1L << 32))
+        return ctx->fail(-33, "im_ctx_reserve: %d x %d exceeds 67 MP per image (32-bit offsets into the half-resolution activations): use a tile mode", max_h, max_w);
+    if (max_kpts >= 32768)
+        return ctx->fail(-34, "im_ctx_reserve: %d keypoints per image: the K x K score matrix is addressed with 32-bit byte offsets (K < 32768)", max_kpts);
     if (ctx->ws && max_h <= ctx->max_h && max_w <= ctx->max_w && max_images <= ctx->max_images && max_kpts <= ctx->max_kpts) return 0;
     IM_HIP(ctx, hipDeviceSynchronize());
     if (ctx->ws) {

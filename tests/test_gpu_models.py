@@ -935,6 +935,19 @@ def test_sequence_pairs_per_launch_equals_one_by_one():
     assert tabs[0][:, 0].tolist() == epochs and (tabs[0][:, 3] > 20).all()
 
 
+def test_reserve_refuses_sizes_beyond_32_bit_offsets():
+    """Images above 67 MP or 32768+ keypoints per image would wrap the 32-bit buffer offsets of the kernels: the library must
+    refuse them loudly (larger images go through the tile modes)."""
+    from icepy4d_amd.engine import Engine
+    e = Engine(0)
+    with pytest.raises(RuntimeError, match="67 MP"):
+        e.reserve(16000, 20000, 2, 1024)
+    with pytest.raises(RuntimeError, match="32768"):
+        e.reserve(480, 640, 2, 40000)
+    e.reserve(480, 640, 2, 1024)
+    e.close()
+
+
 def test_resize_option_of_extract():
     """`_match_images(..., resize=R)` (`matchers.py:1247-1248`, `lightglue/superpoint.py:217-231`): extraction on the image resized
     to long side R (float gray path of the device, channels = 4), keypoints mapped back by `(k + .5) / scales - .5`, matching
