@@ -15,18 +15,35 @@ from . import _lib
 from ._lib import LightGlueConf, SuperGlueConf, ptr
 
 
+_FP_MEMO: Dict[tuple, str] = {}
+
+
 def state_dict_fingerprint(state_dict: Dict[str, torch.Tensor]) -> str:
     """Identity of a weight set: SHA-1 over names, shapes and fp32 bytes (50 ms for LightGlue's 12 M parameters). Two
-    matcher objects built from equal state dicts share device weights; different ones never share a context."""
+    matcher objects built from equal state dicts share device weights; different ones never share a context.
+
+    The reference builds a fresh matcher per epoch (`main_dev.py:115-132`), so the hash of an UNCHANGED dict object is memoised
+    under a cheap key - (name, storage address, shape, dtype, in-place version counter) of every tensor - and a per-epoch
+    construction costs microseconds; any in-place edit bumps a version counter and the bytes are hashed again."""
+    keys = [k for k in sorted(state_dict) if not k.endswith("num_batches_tracked")]
+    cheap = None
+    if not any(state_dict[k].is_inference() for k in keys):     # inference tensors carry no version counter: always hashed
+        cheap = tuple((k, state_dict[k].data_ptr(), tuple(state_dict[k].shape), str(state_dict[k].dtype), state_dict[k]._version) for k in keys)
+        hit = _FP_MEMO.get(cheap)
+        if hit is not None:
+            return hit
     h = hashlib.sha1()
-    for key in sorted(state_dict):
-        if key.endswith("num_batches_tracked"):
-            continue
+    for key in keys:
         t = state_dict[key].detach().cpu().to(torch.float32).contiguous()
         h.update(key.encode())
         h.update(str(tuple(t.shape)).encode())
         h.update(t.numpy().tobytes())
-    return h.hexdigest()
+    if cheap is None:
+        return h.hexdigest()
+    if len(_FP_MEMO) > 64:
+        _FP_MEMO.clear()
+    _FP_MEMO[cheap] = h.hexdigest()
+    return _FP_MEMO[cheap]
 
 
 class Engine:

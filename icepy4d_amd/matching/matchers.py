@@ -128,6 +128,9 @@ def _resized_gray(image: np.ndarray, resize: int) -> Tuple[np.ndarray, np.ndarra
     return np.ascontiguousarray(x[0].numpy()), scales
 
 
+_WEIGHT_FILES: Dict[tuple, Dict[str, torch.Tensor]] = {}
+
+
 def _load_state_dict(opt: dict, model: str, filenames: List[str]) -> Dict[str, torch.Tensor]:
     sds = opt.get("state_dicts") or {}
     if model in sds:
@@ -137,7 +140,15 @@ def _load_state_dict(opt: dict, model: str, filenames: List[str]) -> Dict[str, t
         for fn in filenames:
             p = Path(wdir) / fn
             if p.exists():
-                return torch.load(str(p), map_location="cpu")
+                # one load per file version: a matcher per epoch (`main_dev.py:115-132`) re-uses the dict (and, through the
+                # fingerprint memo, the device weights and the captured graph)
+                st = p.stat()
+                key = (str(p.resolve()), st.st_mtime_ns, st.st_size)
+                if key not in _WEIGHT_FILES:
+                    if len(_WEIGHT_FILES) > 8:
+                        _WEIGHT_FILES.clear()
+                    _WEIGHT_FILES[key] = torch.load(str(p), map_location="cpu")
+                return _WEIGHT_FILES[key]
     raise FileNotFoundError(
         f"No weights for '{model}': pass opt['state_dicts']['{model}'] (official key names) or opt['weights_dir'] "
         f"containing one of {filenames}. (The reference downloads them; this build has no network access.)")

@@ -443,3 +443,27 @@ def test_geometric_verification_lo_degeneracy_and_magsac():
     assert gv._needed(0.9999, 0.5) > gv._needed(0.9, 0.5) > 0 and gv._needed(0.99, 0.9) < 10
     w = gv._magsac_weights(np.array([0.0, 0.5, 1.0, 1.81, 1.83, 5.0]))
     assert (np.diff(w[:4]) < 0).all() and w[4] == 0 and w[5] == 0
+
+
+def test_state_dict_fingerprint_memo_and_weight_file_cache(tmp_path):
+    """A matcher per epoch (`main_dev.py:115-132`) must not re-hash or re-load unchanged weights: the fingerprint of an unchanged
+    dict object is memoised, an in-place edit changes it, an equal copy hashes to the same value, and a weights file is loaded
+    once per (path, mtime, size)."""
+    import time
+    import torch
+    from icepy4d_amd import engine
+    from icepy4d_amd.matching import matchers
+    sd = synthetic.lightglue_state_dict(0, "passthrough")
+    f1 = engine.state_dict_fingerprint(sd)
+    t = time.perf_counter()
+    assert engine.state_dict_fingerprint(sd) == f1
+    assert time.perf_counter() - t < 0.02                      # memo hit: no bytes hashed
+    assert engine.state_dict_fingerprint({k: v.clone() for k, v in sd.items()}) == f1
+    k = next(iter(sd))
+    sd[k].add_(1.0)
+    assert engine.state_dict_fingerprint(sd) != f1
+    p = tmp_path / "superpoint_v1.pth"
+    torch.save(synthetic.superpoint_state_dict(0), str(p))
+    a = matchers._load_state_dict({"weights_dir": str(tmp_path)}, "superpoint", ["superpoint_v1.pth"])
+    b = matchers._load_state_dict({"weights_dir": str(tmp_path)}, "superpoint", ["superpoint_v1.pth"])
+    assert a is b

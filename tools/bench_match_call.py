@@ -21,6 +21,16 @@ for name, sel, gv in cases:
         dt = time.perf_counter() - t0
         print(f"{name:38s} rep {r}: {dt * 1e3:.1f} ms, {len(m.mkpts0)} points", flush=True)
 
+# the reference's own pattern: a fresh matcher object per epoch (`main_dev.py:115-132`)
+sds = {"superpoint": synthetic.superpoint_state_dict(0), "lightglue": synthetic.lightglue_state_dict(0, "passthrough")}
+for r in range(4):
+    t0 = time.perf_counter()
+    m2 = matching.LightGlueMatcher({"state_dicts": sds})
+    t1 = time.perf_counter()
+    m2.match(a, b, quality=matching.Quality.HIGH, tile_selection=matching.TileSelection.NONE, max_keypoints=K,
+             geometric_verification=matching.GeometricVerification.NONE)
+    print(f"fresh matcher per call                 rep {r}: construct {(t1 - t0) * 1e3:.2f} ms + match {(time.perf_counter() - t1) * 1e3:.1f} ms", flush=True)
+
 if os.environ.get("IM_BENCH_TILES", "1") == "1":
     # production-like call (`main_dev.py:115-132`): 12 MP RGB pair, 3 x 3 grid with overlap, 8192 keypoints per tile
     a, b = synthetic.translated_pair(1, 3000, 4000, 48, 16)
