@@ -42,6 +42,98 @@ def triangulate_points_linear(P1, P2, x1, x2) -> np.ndarray:
     return X / X[:, 3:4]
 
 
+# ---- five-point relative pose (what cv2.findEssentialMat runs on a minimal sample; restated from the published algorithm:
+# D. Nister, "An efficient solution to the five-point relative pose problem", PAMI 2004, in the action-matrix form of
+# H. Stewenius, C. Engels, D. Nister, "Recent developments on direct relative orientation", ISPRS J. 2006)
+_MONO = [(3, 0, 0), (2, 1, 0), (2, 0, 1), (1, 2, 0), (1, 1, 1), (1, 0, 2), (0, 3, 0), (0, 2, 1), (0, 1, 2), (0, 0, 3),
+         (2, 0, 0), (1, 1, 0), (1, 0, 1), (0, 2, 0), (0, 1, 1), (0, 0, 2), (1, 0, 0), (0, 1, 0), (0, 0, 1), (0, 0, 0)]
+_DEG = {d: [m for m in _MONO if sum(m) <= d] for d in (1, 2, 3)}
+
+
+def _pmul(a: np.ndarray, da: int, b: np.ndarray, db: int) -> np.ndarray:
+    """Product of two polynomials in (x, y, z) given as coefficient arrays [..., 4, 4, 4] (exponent of x, y, z) of total degree
+    da, db (da + db <= 3); leading batch dimensions broadcast."""
+    out = np.zeros(np.broadcast_shapes(a.shape, b.shape))
+    for ma in _DEG[da]:
+        ca = a[..., ma[0], ma[1], ma[2]]
+        for mb in _DEG[db]:
+            out[..., ma[0] + mb[0], ma[1] + mb[1], ma[2] + mb[2]] += ca * b[..., mb[0], mb[1], mb[2]]
+    return out
+
+
+def essential_five_point(x0: np.ndarray, x1: np.ndarray) -> np.ndarray:
+    """All real essential matrices (up to 10) consistent with FIVE correspondences in normalised image coordinates
+    (x1^T E x0 = 0): [m, 3, 3], each scaled to unit Frobenius norm; m = 0 for a degenerate sample."""
+    x0, x1 = np.asarray(x0, np.float64), np.asarray(x1, np.float64)
+    assert x0.shape == (5, 2) and x1.shape == (5, 2)
+    h0, h1 = np.c_[x0, np.ones(5)], np.c_[x1, np.ones(5)]
+    A = np.einsum("ni,nj->nij", h1, h0).reshape(5, 9)
+    nullv = np.linalg.svd(A)[2][5:]                                   # E = x E1 + y E2 + z E3 + E4
+    Eb = nullv.reshape(4, 3, 3)
+    E = np.zeros((3, 3, 4, 4, 4))                                     # entries of E as linear polynomials
+    for k, m in enumerate(((1, 0, 0), (0, 1, 0), (0, 0, 1), (0, 0, 0))):
+        E[:, :, m[0], m[1], m[2]] = Eb[k]
+    # det(E) = 0
+    def minor(r0, c0, r1, c1):
+        return _pmul(E[r0, c0], 1, E[r1, c1], 1)
+    det = (_pmul(E[0, 0], 1, minor(1, 1, 2, 2) - minor(1, 2, 2, 1), 2) - _pmul(E[0, 1], 1, minor(1, 0, 2, 2) - minor(1, 2, 2, 0), 2)
+           + _pmul(E[0, 2], 1, minor(1, 0, 2, 1) - minor(1, 1, 2, 0), 2))
+    # 2 E E^T E - trace(E E^T) E = 0
+    EEt = np.zeros((3, 3, 4, 4, 4))
+    for i in range(3):
+        for j in range(3):
+            EEt[i, j] = sum(_pmul(E[i, k], 1, E[j, k], 1) for k in range(3))
+    tr = EEt[0, 0] + EEt[1, 1] + EEt[2, 2]
+    eqs = [det]
+    for i in range(3):
+        for j in range(3):
+            eqs.append(2.0 * sum(_pmul(EEt[i, k], 2, E[k, j], 1) for k in range(3)) - _pmul(tr, 2, E[i, j], 1))
+    M = np.array([[e[m[0], m[1], m[2]] for m in _MONO] for e in eqs])         # 10 x 20
+    try:
+        B = np.linalg.solve(M[:, :10], M[:, 10:])                             # cubic monomials in terms of the lower ones
+    except np.linalg.LinAlgError:
+        return np.zeros((0, 3, 3))
+    # action matrix of multiplication by x on the basis [x^2, xy, xz, y^2, yz, z^2, x, y, z, 1]
+    At = np.zeros((10, 10))
+    At[0:6] = -B[[0, 1, 2, 3, 4, 5]]              # x * {x^2, xy, xz, y^2, yz, z^2} = {x^3, x^2 y, x^2 z, x y^2, xyz, x z^2}
+    At[6, 0] = At[7, 1] = At[8, 2] = At[9, 6] = 1.0    # x * {x, y, z, 1} = {x^2, xy, xz, x}
+    w, V = np.linalg.eig(At)                       # x * b(solution) = At b(solution): the monomial vector is an eigenvector
+    out = []
+    for k in range(10):
+        if abs(w[k].imag) > 1e-9 * max(1.0, abs(w[k])) or abs(V[9, k]) < 1e-14:
+            continue
+        v = (V[:, k] / V[9, k]).real
+        Em = v[6] * Eb[0] + v[7] * Eb[1] + v[8] * Eb[2] + Eb[3]
+        nrm = np.linalg.norm(Em)
+        if np.isfinite(nrm) and nrm > 0:
+            out.append(Em / nrm)
+    return np.array(out).reshape(-1, 3, 3)
+
+
+def _sampson_e(E: np.ndarray, x0: np.ndarray, x1: np.ndarray) -> np.ndarray:
+    h0, h1 = np.c_[x0, np.ones(len(x0))], np.c_[x1, np.ones(len(x1))]
+    Ex0, Etx1 = h0 @ E.T, h1 @ E
+    return (h1 * Ex0).sum(1) ** 2 / np.maximum(Ex0[:, 0] ** 2 + Ex0[:, 1] ** 2 + Etx1[:, 0] ** 2 + Etx1[:, 1] ** 2, 1e-24)
+
+
+def _estimate_pose_few(x0: np.ndarray, x1: np.ndarray, thr2: float):
+    """5 <= n < 8 matches: every 5-subset through the five-point solver, the candidate with most inliers (then the smallest
+    Sampson error sum, then the most points in front of both cameras) wins - what a RANSAC over minimal samples converges to."""
+    from itertools import combinations
+    best = None
+    for idx in combinations(range(len(x0)), 5):
+        for E in essential_five_point(x0[list(idx)], x1[list(idx)]):
+            err = _sampson_e(E, x0, x1)
+            mask = err < thr2
+            n_front, R, t, front = _recover_pose(E, x0, x1, mask)
+            key = (int(mask.sum()), n_front, -float(err[mask].sum()))
+            if R is not None and (best is None or key > best[0]):
+                inl = mask.copy()
+                inl[np.flatnonzero(mask)[~front]] = False
+                best = (key, R, t, inl)
+    return None if best is None else best[1:]
+
+
 def _essential_from_fundamental(F: np.ndarray) -> np.ndarray:
     u, _, vt = np.linalg.svd(F)
     return u @ np.diag([1.0, 1.0, 0.0]) @ vt
@@ -74,9 +166,10 @@ def estimate_pose(kpts0: np.ndarray, kpts1: np.ndarray, K0: np.ndarray, K1: np.n
                   engine=None, seed: int = 0) -> Optional[Tuple[np.ndarray, np.ndarray, np.ndarray]]:
     """`estimate_pose` of the reference (`sfm/geometry.py:31-76`): (R [3,3], t [3], inliers [n] bool) with
     x_cam1 = R x_cam0 + t, t up to scale; None with fewer than 5 matches. The reference runs cv2.findEssentialMat (5-point
-    RANSAC) + cv2.recoverPose; here the epipolar geometry of the NORMALISED coordinates is estimated by the 8-point
-    RANSAC of `geometric_verification` (on the device when `engine` is given), projected onto the essential manifold and
-    decomposed with the cheirality test."""
+    RANSAC) + cv2.recoverPose; here, with 8 or more matches, the epipolar geometry of the NORMALISED coordinates is estimated by
+    the 8-point RANSAC of `geometric_verification` (on the device when `engine` is given), projected onto the essential manifold
+    and decomposed with the cheirality test; with 5-7 matches the five-point solver (`essential_five_point`) runs on every
+    5-subset."""
     if len(kpts0) < 5:
         return None
     K0, K1 = np.asarray(K0, np.float64), np.asarray(K1, np.float64)
@@ -85,7 +178,8 @@ def estimate_pose(kpts0: np.ndarray, kpts1: np.ndarray, K0: np.ndarray, K1: np.n
     x0 = (np.asarray(kpts0, np.float64) - K0[[0, 1], [2, 2]][None]) / K0[[0, 1], [0, 1]][None]
     x1 = (np.asarray(kpts1, np.float64) - K1[[0, 1], [2, 2]][None]) / K1[[0, 1], [0, 1]][None]
     if len(x0) < 8:
-        return None   # the 8-point solver needs 8 correspondences (the reference's 5-point solver would still run)
+        # fewer matches than the 8-point hypotheses of the RANSAC below need: the five-point solver on every 5-subset
+        return _estimate_pose_few(x0, x1, norm_thresh ** 2)
     F, mask = geometric_verification(x0.astype(np.float32), x1.astype(np.float32), GeometricVerification.PYDEGENSAC,
                                      threshold=norm_thresh, confidence=conf, seed=seed, engine=engine)
     if F is None:

@@ -467,3 +467,58 @@ def test_state_dict_fingerprint_memo_and_weight_file_cache(tmp_path):
     a = matchers._load_state_dict({"weights_dir": str(tmp_path)}, "superpoint", ["superpoint_v1.pth"])
     b = matchers._load_state_dict({"weights_dir": str(tmp_path)}, "superpoint", ["superpoint_v1.pth"])
     assert a is b
+
+
+def test_estimate_pose_like_the_reference_tests():
+    """The reference's own tests of `estimate_pose` (`tests/test_sfm_geometry.py:8-32`, same inputs): None below five matches, a
+    pose for five."""
+    from icepy4d_amd import sfm
+    assert sfm.estimate_pose(np.array([[0, 0], [0, 1]]), np.array([[0, 0], [0, 1]]), np.eye(3), np.eye(3), 0.5, 0.9999) is None
+    kpts0 = np.array([[1853, 2632], [2122, 2744], [416, 2867], [1880, 2582], [2100, 2770]]).astype(np.float32)
+    kpts1 = np.array([[0, 0], [0, 1], [1, 0], [1, 1], [0.5, 0.5]])
+    res = sfm.estimate_pose(kpts0, kpts1, np.eye(3), np.eye(3), 0.5, 0.9999)
+    assert res is not None
+    R, t, inl = res
+    assert R.shape == (3, 3) and t.shape == (3,) and inl.shape == (5,) and inl.dtype == bool
+    assert abs(np.linalg.det(R) - 1) < 1e-9 and np.abs(R @ R.T - np.eye(3)).max() < 1e-9
+
+
+def test_five_point_solver_known_answers():
+    """`essential_five_point` (what cv2.findEssentialMat evaluates on a minimal sample): on exact synthetic correspondences the
+    true essential matrix is among the solutions to 1e-9, every solution satisfies x1^T E x0 = 0, det E = 0 and
+    2 E E^T E = trace(E E^T) E; with 5-7 noisy matches and one gross outlier `estimate_pose` recovers the motion and flags it."""
+    from icepy4d_amd import sfm
+    rng = np.random.default_rng(11)
+    for _ in range(10):
+        X = np.c_[rng.uniform(-2, 2, 5), rng.uniform(-1.5, 1.5, 5), rng.uniform(4, 9, 5)]
+        ang = rng.uniform(-0.3, 0.3)
+        R = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]])
+        t = rng.normal(size=3)
+        x0 = X[:, :2] / X[:, 2:]
+        Xc = X @ R.T + t
+        x1 = Xc[:, :2] / Xc[:, 2:]
+        Es = sfm.essential_five_point(x0, x1)
+        assert 1 <= len(Es) <= 10
+        tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+        Et = tx @ R
+        Et /= np.linalg.norm(Et)
+        assert min(min(np.abs(E - Et).max(), np.abs(E + Et).max()) for E in Es) < 1e-9
+        h0, h1 = np.c_[x0, np.ones(5)], np.c_[x1, np.ones(5)]
+        for E in Es:
+            assert np.abs(np.einsum("ni,ij,nj->n", h1, E, h0)).max() < 1e-10
+            assert abs(np.linalg.det(E)) < 1e-10 and np.abs(2 * E @ E.T @ E - np.trace(E @ E.T) * E).max() < 1e-9
+    K = np.array([[1000.0, 0, 640], [0, 1000.0, 480], [0, 0, 1]])
+    ang = 0.15
+    R = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]])
+    t = np.array([-1.0, 0.1, 0.2])
+    for n, outlier in ((6, False), (7, True)):   # with six matches a single outlier cannot be told apart: any five define a model
+        X = np.c_[rng.uniform(-2, 2, n), rng.uniform(-1.5, 1.5, n), rng.uniform(4, 9, n)]
+        x0 = (K @ X.T).T
+        x0 = x0[:, :2] / x0[:, 2:]
+        x1 = (K @ (X @ R.T + t).T).T
+        x1 = x1[:, :2] / x1[:, 2:] + rng.normal(0, 0.05, (n, 2))
+        if outlier:
+            x1[2] += 60.0
+        Re, te, inl = sfm.estimate_pose(x0, x1, K, K, 1.0)
+        assert inl.sum() == n - int(outlier) and (not outlier or not inl[2])
+        assert np.abs(Re - R).max() < 2e-2 and np.abs(te / np.linalg.norm(te) - t / np.linalg.norm(t)).max() < 5e-2
