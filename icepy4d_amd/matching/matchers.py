@@ -63,9 +63,10 @@ def get_engine(device: int = 0, state_dicts: Optional[Dict[str, dict]] = None, p
 
 
 def check_dict_keys(dict: dict, keys: List[str]):
-    missing_keys = [key for key in keys if key not in dict]
-    if missing_keys:
-        raise KeyError(f"Missing required keys: {', '.join(missing_keys)} Matcher option dictionary")
+    """KeyError naming every required option that `dict` lacks (`matchers.py:40-47`)."""
+    absent = sorted(set(keys) - set(dict))
+    if absent:
+        raise KeyError(f"matcher options lack the required entries {absent}")
 
 
 @dataclass
@@ -356,37 +357,29 @@ class ImageMatcherBase:
 
     def _store_features(self, features0: FeaturesBase, features1: FeaturesBase, matches0: np.ndarray,
                         force_overwrite: bool = True) -> bool:
-        """Stores keypoints, descriptors and scores of the matches (`matchers.py:641-680`)."""
-        assert isinstance(features0, FeaturesBase), "features0 must be a FeaturesBase object"
-        assert isinstance(features1, FeaturesBase), "features1 must be a FeaturesBase object"
-        if self._mkpts0 is not None and self._mkpts1 is not None and force_overwrite is False:
-            logger.warning("Matches already stored. Not overwriting them. Use force_overwrite=True to force overwrite them.")
+        """Keeps the matched subset: row i of image 0 goes with row matches0[i] of image 1 wherever matches0[i] > -1
+        (`matchers.py:641-680`); descriptors are [256, n] column-wise, as the reference stores them."""
+        for f in (features0, features1):
+            assert isinstance(f, FeaturesBase), "features0 / features1 must be FeaturesBase objects"
+        have_matches = self._mkpts0 is not None and self._mkpts1 is not None
+        if have_matches and not force_overwrite:
+            logger.warning("matches are already stored and force_overwrite is False: keeping the old ones")
             return False
-        valid = matches0 > -1
-        self._valid = valid
-        idx1 = matches0[valid]
-        self._mkpts0 = features0.keypoints[valid]
-        self._mkpts1 = features1.keypoints[idx1]
+        self._valid = matches0 > -1
+        rows0, rows1 = np.flatnonzero(self._valid), matches0[self._valid]
+        self._mkpts0, self._mkpts1 = features0.keypoints[rows0], features1.keypoints[rows1]
         if features0.descriptors is not None:
-            self._descriptors0 = features0.descriptors[:, valid]
-            self._descriptors1 = features1.descriptors[:, idx1]
+            self._descriptors0, self._descriptors1 = features0.descriptors[:, rows0], features1.descriptors[:, rows1]
         if features0.scores is not None:
-            self._scores0 = features0.scores[valid]
-            self._scores1 = features1.scores[idx1]
+            self._scores0, self._scores1 = features0.scores[rows0], features1.scores[rows1]
         return True
 
     def _filter_matches_by_mask(self, inlMask: np.ndarray) -> None:
-        """`matchers.py:682-700`."""
-        self._mkpts0 = self._mkpts0[inlMask, :]
-        self._mkpts1 = self._mkpts1[inlMask, :]
-        if self._descriptors0 is not None:
-            self._descriptors0 = self._descriptors0[:, inlMask]
-        if self._descriptors1 is not None:
-            self._descriptors1 = self._descriptors1[:, inlMask]
-        if self._scores0 is not None:
-            self._scores0 = self._scores0[inlMask]
-        if self._scores1 is not None:
-            self._scores1 = self._scores1[inlMask]
+        """Drops the matches the verification rejected from every stored per-match array (`matchers.py:682-700`)."""
+        for name, axis in (("_mkpts0", 0), ("_mkpts1", 0), ("_descriptors0", 1), ("_descriptors1", 1), ("_scores0", 0), ("_scores1", 0)):
+            arr = getattr(self, name)
+            if arr is not None:
+                setattr(self, name, np.compress(inlMask, arr, axis=axis))
         if self._mconf is not None and len(self._mconf) == len(inlMask):
             self._mconf = self._mconf[inlMask]
 
@@ -558,15 +551,13 @@ class SuperGlueMatcher(ImageMatcherBase):
         self.engine   # binds (or creates) the engine that holds exactly these weights
 
     def _build_superglue_config(self, opt: dict) -> dict:
-        def_opt = {"weights": "outdoor", "keypoint_threshold": 0.001, "max_keypoints": -1, "match_threshold": 0.3,
-                   "force_cpu": False, "nms_radius": 3, "sinkhorn_iterations": 20}
-        opt = {**def_opt, **opt}
-        check_dict_keys(opt, ["weights", "keypoint_threshold", "max_keypoints", "match_threshold", "force_cpu"])
-        return {"superpoint": {"nms_radius": opt["nms_radius"], "keypoint_threshold": opt["keypoint_threshold"],
-                               "max_keypoints": opt["max_keypoints"]},
-                "superglue": {"weights": opt["weights"], "sinkhorn_iterations": opt["sinkhorn_iterations"],
-                              "match_threshold": opt["match_threshold"]},
-                "force_cpu": opt["force_cpu"]}
+        """Defaults of the reference (`matchers.py:854-890`) under the caller's options, split per model."""
+        o = dict(weights="outdoor", keypoint_threshold=0.001, max_keypoints=-1, match_threshold=0.3, force_cpu=False,
+                 nms_radius=3, sinkhorn_iterations=20)
+        o.update(opt)
+        check_dict_keys(o, ["weights", "keypoint_threshold", "max_keypoints", "match_threshold", "force_cpu"])
+        sp_keys, sg_keys = ("nms_radius", "keypoint_threshold", "max_keypoints"), ("weights", "sinkhorn_iterations", "match_threshold")
+        return {"superpoint": {k: o[k] for k in sp_keys}, "superglue": {k: o[k] for k in sg_keys}, "force_cpu": o["force_cpu"]}
 
     def _sp_params(self, **config):
         sp = self._cfg["superpoint"]
