@@ -199,7 +199,7 @@ def main():
     eng = sm.slots[0][0]
     pool = [torch.from_numpy(p).cuda().contiguous() for p in host_pairs]
     table = new_table(args.steps, kpts, eng.device)
-    scratch = new_table(max(args.warmup, 1), kpts, eng.device)
+    scratch = new_table(max(args.warmup, 2), kpts, eng.device)   # >= 2 rows: the untimed gather below must load torch's sort kernels
 
     def barrier():
         sm.synchronize()
