@@ -68,6 +68,25 @@ for fn in glob.glob(f"{src}/pmc_attn_sq/**/*counter_collection.csv", recursive=T
         fh.write("counter,mean,launches\n")
         for k, v in agg.items():
             fh.write(f"{k},{sum(v)/len(v):.1f},{len(v)}\n")
+# matrix-pipe busy share of every kernel of one pair: SQ_VALU_MFMA_BUSY_CYCLES (summed over the 1024 SIMDs) over SQ_BUSY_CYCLES
+# (32 instances per launch, one per shader engine: / 32 = busy cycles of the launch)
+for fn in glob.glob(f"{src}/pmc_sq_all/**/*counter_collection.csv", recursive=True):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(fn)):
+        agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    rows = []
+    for k, c in agg.items():
+        m = {n: sum(v) / len(v) for n, v in c.items()}
+        if m.get("SQ_BUSY_CYCLES", 0) <= 0 or not k.startswith("void im::"):
+            continue
+        cyc = m["SQ_BUSY_CYCLES"] / 32.0
+        rows.append((m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), k.replace("void ", "").split("(")[0], len(c["SQ_BUSY_CYCLES"]), cyc,
+                     m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (cyc * 1024.0), m.get("SQ_WAIT_ANY", 0.0) / max(m.get("SQ_WAVE_CYCLES", 1.0), 1.0),
+                     m.get("SQ_INSTS_VALU", 0.0), m.get("SQ_INSTS_LDS", 0.0)))
+    with open(os.path.join(dst, f"{tag}_mfma_busy_share.csv"), "w") as fh:
+        fh.write("kernel,launches,busy_cycles_per_launch,mfma_pipe_busy_share,wave_cycles_waiting_share,valu_insts_per_launch,lds_insts_per_launch\n")
+        for r in sorted(rows, reverse=True):
+            fh.write(f'"{r[1]}",{r[2]},{r[3]:.0f},{r[4]:.3f},{r[5]:.2f},{r[6]:.0f},{r[7]:.0f}\n')
 for name in ("bench.json", "bench_streams1_under_rocprof.json", "bench_default_under_rocprof.json", "bench_config5.json", "bench_config3.json", "bench_steps20_warmup5.json",
              "bench_config5_under_rocprof.json", "parity_winograd.json", "parity_direct_conv.json"):
     p = os.path.join(src, name)
