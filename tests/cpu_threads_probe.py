@@ -1,3 +1,5 @@
+"""TEST INFRASTRUCTURE (imports oracle/): how many host threads the CPU baseline of bench.py should use on the GPU box
+(SuperPoint of one 1080p image with 16 / 32 / 64 torch threads). Run from the repo root: python tests/cpu_threads_probe.py"""
 import sys, time, os
 sys.path.insert(0, os.getcwd())
 import torch
