@@ -14,9 +14,11 @@ libraries' randomised outputs is statistical only and unpinned):
   best hypothesis is refined by iteratively re-weighted least squares with the MAGSAC++ weights (residuals marginalised over
   the noise scale, chi distribution with 4 degrees of freedom, 0.99 quantile k = 3.64), inliers = residual <= k sigma_max.
 
-Hypotheses are generated and scored in one launch pair on the device when `engine=...` is given (`im_ransac_fundamental`,
-csrc/geometry.hip: what `match()` uses), in batches until the confidence criterion is met; without an engine the numpy loop
-below runs (the checker of the device form in the tests, and what a host-only caller gets)."""
+Hypotheses are generated and scored on the device (`im_ransac_fundamental`, csrc/geometry.hip: one launch pair per batch of
+1024), in batches until the confidence criterion is met; `engine=...` is required - there is no host fallback. The numpy RANSAC
+loop that checks the device form lives with the oracle (`oracle/gv_cpu.py`, tests only) and enters through `hypothesis_fn`.
+The refinement of the winning hypothesis (local optimisation, degeneracy repair, sigma-consensus refit) is small host-side
+linear algebra on the matched points, as in the libraries the reference calls."""
 import logging
 from typing import Tuple
 
@@ -69,8 +71,10 @@ def _needed(confidence: float, w: float) -> int:
 def geometric_verification(mkpts0: np.ndarray = None, mkpts1: np.ndarray = None,
                            method: GeometricVerification = GeometricVerification.PYDEGENSAC, threshold: float = 1,
                            confidence: float = 0.9999, max_iters: int = 10000, seed: int = 0, engine=None,
-                           enable_degeneracy_check: bool = True, **_ignored):
-    """Returns (F [3,3] or None, inlier mask [S] bool), like the reference (`geometric_verification.py:11-102`)."""
+                           enable_degeneracy_check: bool = True, hypothesis_fn=None, **_ignored):
+    """Returns (F [3,3] or None, inlier mask [S] bool), like the reference (`geometric_verification.py:11-102`).
+    `hypothesis_fn(n_hypotheses, seed) -> inlier mask of the best of them` replaces the device stage (test seam: the oracle's
+    numpy RANSAC); without it an engine is mandatory."""
     assert isinstance(method, GeometricVerification), "Invalid method. It must be a GeometricVerification enum"
     n = 0 if mkpts0 is None else len(mkpts0)
     if method == GeometricVerification.NONE or n < 8:
@@ -82,32 +86,20 @@ def geometric_verification(mkpts0: np.ndarray = None, mkpts1: np.ndarray = None,
     if magsac:
         threshold, confidence, max_iters = MAGSAC_K * MAGSAC_SIGMA_MAX, MAGSAC_CONF, MAGSAC_ITERS
     thr2 = float(threshold) ** 2
-    if engine is not None:
-        # batches of hypotheses on the device until the confidence criterion holds for the best inlier ratio so far
-        best_mask, best_cnt, done, needed = np.zeros(n, bool), 0, 0, int(max_iters)
-        while done < min(needed, int(max_iters)):
-            mask = _ransac_on_device(engine, mkpts0, mkpts1, threshold, DEVICE_BATCH, seed + done)
-            done += DEVICE_BATCH
-            cnt = int(mask.sum())
-            if cnt > best_cnt:
-                best_cnt, best_mask = cnt, mask
-            needed = _needed(confidence, best_cnt / n)
-        return _finish(p0, p1, best_mask, thr2, method, n, enable_degeneracy_check, seed)
-    rng = np.random.default_rng(seed)
-    best_mask, best_cnt, it, needed = np.zeros(n, bool), 0, 0, max_iters
-    while it < min(needed, max_iters):
-        idx = rng.choice(n, 8, replace=False)
-        try:
-            F = _eight_point(p0[idx], p1[idx])
-        except np.linalg.LinAlgError:
-            it += 1
-            continue
-        mask = _sampson(F, p0, p1) < thr2
+    if hypothesis_fn is None:
+        if engine is None:
+            raise RuntimeError("geometric_verification needs engine=... : hypotheses are generated and scored on the device "
+                               "(im_ransac_fundamental); there is no host fallback")
+        hypothesis_fn = lambda n_hyp, sd: _ransac_on_device(engine, mkpts0, mkpts1, threshold, n_hyp, sd)   # noqa: E731
+    # batches of hypotheses until the confidence criterion holds for the best inlier ratio so far
+    best_mask, best_cnt, done, needed = np.zeros(n, bool), 0, 0, int(max_iters)
+    while done < min(needed, int(max_iters)):
+        mask = hypothesis_fn(DEVICE_BATCH, seed + done)
+        done += DEVICE_BATCH
         cnt = int(mask.sum())
         if cnt > best_cnt:
             best_cnt, best_mask = cnt, mask
-            needed = _needed(confidence, cnt / n)
-        it += 1
+        needed = _needed(confidence, best_cnt / n)
     return _finish(p0, p1, best_mask, thr2, method, n, enable_degeneracy_check, seed)
 
 

@@ -4,7 +4,7 @@ linear triangulation (`src/icepy4d/sfm/geometry.py:31-76`, `sfm/two_view_geometr
 parity of `estimate_pose` is unpinned (same interface, same conventions, checked on synthetic geometry); the linear
 triangulation is pure numpy in the reference and is reproduced to rounding (tests compare against a restatement of its
 formulation). Small host-side linear algebra on S <= 1e4 matched points: not a device workload; the RANSAC inside
-`estimate_pose` reuses the device hypothesis scorer of `geometric_verification` when an engine is passed."""
+`estimate_pose` uses the device hypothesis scorer of `geometric_verification` (pass `engine=`)."""
 from typing import Optional, Tuple
 
 import numpy as np
@@ -163,11 +163,11 @@ def _recover_pose(E: np.ndarray, x0: np.ndarray, x1: np.ndarray, mask: np.ndarra
 
 
 def estimate_pose(kpts0: np.ndarray, kpts1: np.ndarray, K0: np.ndarray, K1: np.ndarray, thresh: float, conf: float = 0.9999,
-                  engine=None, seed: int = 0) -> Optional[Tuple[np.ndarray, np.ndarray, np.ndarray]]:
+                  engine=None, seed: int = 0, hypothesis_fn=None) -> Optional[Tuple[np.ndarray, np.ndarray, np.ndarray]]:
     """`estimate_pose` of the reference (`sfm/geometry.py:31-76`): (R [3,3], t [3], inliers [n] bool) with
     x_cam1 = R x_cam0 + t, t up to scale; None with fewer than 5 matches. The reference runs cv2.findEssentialMat (5-point
     RANSAC) + cv2.recoverPose; here, with 8 or more matches, the epipolar geometry of the NORMALISED coordinates is estimated by
-    the 8-point RANSAC of `geometric_verification` (on the device when `engine` is given), projected onto the essential manifold
+    the 8-point RANSAC of `geometric_verification` (hypotheses scored on the device: `engine` is required), projected onto the essential manifold
     and decomposed with the cheirality test; with 5-7 matches the five-point solver (`essential_five_point`) runs on every
     5-subset."""
     if len(kpts0) < 5:
@@ -181,7 +181,7 @@ def estimate_pose(kpts0: np.ndarray, kpts1: np.ndarray, K0: np.ndarray, K1: np.n
         # fewer matches than the 8-point hypotheses of the RANSAC below need: the five-point solver on every 5-subset
         return _estimate_pose_few(x0, x1, norm_thresh ** 2)
     F, mask = geometric_verification(x0.astype(np.float32), x1.astype(np.float32), GeometricVerification.PYDEGENSAC,
-                                     threshold=norm_thresh, confidence=conf, seed=seed, engine=engine)
+                                     threshold=norm_thresh, confidence=conf, seed=seed, engine=engine, hypothesis_fn=hypothesis_fn)
     if F is None:
         raise AssertionError("Unable to estimate Essential matrix")
     E = _essential_from_fundamental(F)

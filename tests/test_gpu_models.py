@@ -467,7 +467,8 @@ def test_geometric_verification_on_device():
         p0, p1 = p0.astype(np.float32), p1.astype(np.float32)
         Fd, md = geometric_verification(p0, p1, GeometricVerification.PYDEGENSAC, threshold=1.0, engine=e)
         Fd2, md2 = geometric_verification(p0, p1, GeometricVerification.PYDEGENSAC, threshold=1.0, engine=e)
-        Fh, mh = geometric_verification(p0, p1, GeometricVerification.PYDEGENSAC, threshold=1.0)
+        from oracle import gv_cpu
+        Fh, mh = geometric_verification(p0, p1, GeometricVerification.PYDEGENSAC, threshold=1.0, hypothesis_fn=gv_cpu.hypothesis_fn(p0, p1, 1.0))
         assert Fd is not None and np.array_equal(md, md2) and np.array_equal(Fd, Fd2)
         assert md[n_out:].mean() > 0.97 and md[:n_out].mean() < 0.05, (md[n_out:].mean(), md[:n_out].mean())
         assert np.mean(md == mh) > 0.97, np.mean(md == mh)

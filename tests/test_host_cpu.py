@@ -40,11 +40,27 @@ def test_no_cpu_fallback_without_gpu():
 
 
 def test_product_never_imports_oracle():
+    """No product source imports, includes, loads or executes anything under oracle/ (docstrings may NAME the checker files)."""
+    import ast
+    import re
     for dirpath, _, files in os.walk(os.path.join(ROOT, "icepy4d_amd")):
         for f in files:
-            if f.endswith((".py", ".hip", ".h", ".cpp")):
-                src = open(os.path.join(dirpath, f)).read()
-                assert "oracle" not in src.replace("the oracle", "").replace("CPU oracle", "") or f == "synthetic.py", (dirpath, f)
+            path = os.path.join(dirpath, f)
+            if f.endswith(".py"):
+                tree = ast.parse(open(path).read())
+                for node in ast.walk(tree):
+                    if isinstance(node, ast.Import):
+                        assert not any(a.name.split(".")[0] == "oracle" for a in node.names), path
+                    elif isinstance(node, ast.ImportFrom):
+                        assert (node.module or "").split(".")[0] != "oracle", path
+                    elif isinstance(node, ast.Call):     # importlib.import_module("oracle...") / __import__ / open / CDLL on oracle paths
+                        for arg in node.args:
+                            if isinstance(arg, ast.Constant) and isinstance(arg.value, str):
+                                assert not re.match(r"^(oracle($|[./]))", arg.value), (path, arg.value)
+            elif f.endswith((".hip", ".h", ".cpp")):
+                for line in open(path):
+                    if line.lstrip().startswith("#include"):
+                        assert "oracle" not in line, (path, line)
 
 
 def test_tiler_matches_reference():
@@ -112,7 +128,11 @@ def test_geometric_verification():
     p1 = (K @ X1.T).T
     p1 = p1[:, :2] / p1[:, 2:]
     p1[:40] += rng.uniform(20, 60, size=(40, 2))  # outliers
-    F, mask = geometric_verification(p0.astype(np.float32), p1.astype(np.float32), GeometricVerification.PYDEGENSAC, threshold=1.0)
+    from oracle import gv_cpu
+    with pytest.raises(RuntimeError, match="no host fallback"):       # the product scores hypotheses on the device only
+        geometric_verification(p0.astype(np.float32), p1.astype(np.float32), GeometricVerification.PYDEGENSAC, threshold=1.0)
+    F, mask = geometric_verification(p0.astype(np.float32), p1.astype(np.float32), GeometricVerification.PYDEGENSAC, threshold=1.0,
+                                     hypothesis_fn=gv_cpu.hypothesis_fn(p0, p1, 1.0))   # the oracle's numpy RANSAC in the device stage's place
     assert F is not None and mask[40:].mean() > 0.95 and mask[:40].mean() < 0.2
     F, mask = geometric_verification(p0[:3], p1[:3], GeometricVerification.MAGSAC)
     assert F is None and mask.all()
@@ -286,7 +306,9 @@ def test_sfm_relative_orientation_and_triangulation():
     x1 = (P1 @ h.T).T; x1 = x1[:, :2] / x1[:, 2:]
     x1n = x1 + rng.normal(0, 0.1, x1.shape)
     x1n[:40] += rng.uniform(30, 80, size=(40, 2))
-    Re, te, inl = sfm.estimate_pose(x0, x1n, K, K, thresh=1.0)
+    from oracle import gv_cpu
+    xn0, xn1 = (x0 - K[[0, 1], [2, 2]]) / K[[0, 1], [0, 1]], (x1n - K[[0, 1], [2, 2]]) / K[[0, 1], [0, 1]]
+    Re, te, inl = sfm.estimate_pose(x0, x1n, K, K, thresh=1.0, hypothesis_fn=gv_cpu.hypothesis_fn(xn0, xn1, 1.0 / 1200.0))
     assert inl[40:].mean() > 0.95 and inl[:40].mean() < 0.1
     assert np.abs(Re - R).max() < 5e-3
     assert np.abs(te / np.linalg.norm(te) - t / np.linalg.norm(t)).max() < 2e-2
@@ -427,8 +449,10 @@ def test_geometric_verification_lo_degeneracy_and_magsac():
     X = np.c_[rng.uniform(-1, 1, 400), rng.uniform(-1, 1, 400), rng.uniform(4, 9, 400)]
     p0, p1 = project(X, 0.2)
     p1[:100] += rng.uniform(15, 40, size=(100, 2))
-    F, m_mag = geometric_verification(p0, p1, GeometricVerification.MAGSAC, threshold=50.0)      # threshold is ignored
-    F2, m_deg = geometric_verification(p0, p1, GeometricVerification.PYDEGENSAC, threshold=1.0)
+    from oracle import gv_cpu      # the oracle's numpy RANSAC stands in for the device hypothesis stage (CPU-only test)
+    F, m_mag = geometric_verification(p0, p1, GeometricVerification.MAGSAC, threshold=50.0,      # threshold is ignored
+                                      hypothesis_fn=gv_cpu.hypothesis_fn(p0, p1, gv.MAGSAC_K * gv.MAGSAC_SIGMA_MAX))
+    F2, m_deg = geometric_verification(p0, p1, GeometricVerification.PYDEGENSAC, threshold=1.0, hypothesis_fn=gv_cpu.hypothesis_fn(p0, p1, 1.0))
     assert m_mag[:100].mean() < 0.05 and m_mag[100:].mean() > 0.9 and m_deg[100:].mean() > 0.95
     x0, x1 = np.c_[p0[100:], np.ones(300)], np.c_[p1[100:], np.ones(300)]
     assert np.abs(np.einsum("ni,ij,nj->n", x1, F, x0)).mean() < 2e-3 * np.abs(F).max() * 900
@@ -437,7 +461,7 @@ def test_geometric_verification_lo_degeneracy_and_magsac():
     Xp = np.c_[rng.uniform(-1, 1, n_pl), rng.uniform(-1, 1, n_pl), np.full(n_pl, 6.0)]
     Xo = np.c_[rng.uniform(-1, 1, n_off), rng.uniform(-1, 1, n_off), rng.uniform(3, 9, n_off)]
     p0, p1 = project(np.r_[Xp, Xo], 0.1)
-    _, m_on = geometric_verification(p0, p1, GeometricVerification.PYDEGENSAC, threshold=0.7, seed=3)
+    _, m_on = geometric_verification(p0, p1, GeometricVerification.PYDEGENSAC, threshold=0.7, seed=3, hypothesis_fn=gv_cpu.hypothesis_fn(p0, p1, 0.7))
     assert m_on[:n_pl].mean() > 0.95 and m_on[n_pl:].mean() > 0.8, (m_on[:n_pl].mean(), m_on[n_pl:].mean())
     # (c) confidence drives the hypothesis count
     assert gv._needed(0.9999, 0.5) > gv._needed(0.9, 0.5) > 0 and gv._needed(0.99, 0.9) < 10
