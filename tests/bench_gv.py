@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
-"""Geometric verification (row f-2): device RANSAC vs the numpy loop on synthetic two-view matches."""
+"""TEST INFRASTRUCTURE (imports oracle/): geometric verification (row f-2) with the device hypothesis stage vs the oracle's numpy
+RANSAC in its place, on synthetic two-view matches. Run from the repo root on the GPU box: python tests/bench_gv.py"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from icepy4d_amd.engine import Engine
 from icepy4d_amd.matching import GeometricVerification, geometric_verification
+from oracle import gv_cpu
 
 e = Engine(0)
 for n_pts, frac in ((1000, 0.2), (4000, 0.5), (10000, 0.5)):
@@ -18,5 +20,5 @@ for n_pts, frac in ((1000, 0.2), (4000, 0.5), (10000, 0.5)):
     p0, p1 = p0.astype(np.float32), p1.astype(np.float32)
     geometric_verification(p0, p1, GeometricVerification.PYDEGENSAC, threshold=1.0, engine=e)  # warm
     t0 = time.perf_counter(); _, md = geometric_verification(p0, p1, GeometricVerification.PYDEGENSAC, threshold=1.0, engine=e); td = time.perf_counter() - t0
-    t0 = time.perf_counter(); _, mh = geometric_verification(p0, p1, GeometricVerification.PYDEGENSAC, threshold=1.0); th = time.perf_counter() - t0
+    t0 = time.perf_counter(); _, mh = geometric_verification(p0, p1, GeometricVerification.PYDEGENSAC, threshold=1.0, hypothesis_fn=gv_cpu.hypothesis_fn(p0, p1, 1.0)); th = time.perf_counter() - t0
     print(f"S={n_pts} outliers={frac:.0%}: device {td * 1e3:.2f} ms ({int(md.sum())} inliers), numpy {th * 1e3:.1f} ms ({int(mh.sum())} inliers)")
