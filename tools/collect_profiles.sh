@@ -21,6 +21,6 @@ done
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $out/pmc_attn_sq -- python3 $root/tools/run_attn_once.py > /dev/null 2>&1
 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $out/pmc_sq_all -- python3 $root/tools/run_pair_once.py lightglue 2 > /dev/null 2>&1
 cd $root
-python3 tests/parity_report.py --epochs 6 --superglue --out $out/parity_winograd.json > $out/parity_winograd.log 2>&1
+python3 tests/parity_report.py --epochs 30 --superglue --out $out/parity_winograd.json > $out/parity_winograd.log 2>&1
 IM_CONV_DIRECT=1 python3 tests/parity_report.py --out $out/parity_direct_conv.json > $out/parity_direct_conv.log 2>&1
 python3 tools/summarize_profiles.py $tag
