@@ -15,7 +15,7 @@ from . import _lib
 from ._lib import LightGlueConf, SuperGlueConf, ptr
 
 
-_FP_MEMO: Dict[tuple, str] = {}
+_FP_MEMO: Dict[tuple, tuple] = {}   # cheap key -> (sha1, the tensors themselves)
 
 
 def state_dict_fingerprint(state_dict: Dict[str, torch.Tensor]) -> str:
@@ -24,14 +24,15 @@ def state_dict_fingerprint(state_dict: Dict[str, torch.Tensor]) -> str:
 
     The reference builds a fresh matcher per epoch (`main_dev.py:115-132`), so the hash of an UNCHANGED dict object is memoised
     under a cheap key - (name, storage address, shape, dtype, in-place version counter) of every tensor - and a per-epoch
-    construction costs microseconds; any in-place edit bumps a version counter and the bytes are hashed again."""
+    construction costs microseconds; any in-place edit bumps a version counter and the bytes are hashed again. A memo entry keeps
+    its tensors alive: a freed storage address could otherwise be handed to a different weight set of the same shapes and hit."""
     keys = [k for k in sorted(state_dict) if not k.endswith("num_batches_tracked")]
     cheap = None
     if not any(state_dict[k].is_inference() for k in keys):     # inference tensors carry no version counter: always hashed
         cheap = tuple((k, state_dict[k].data_ptr(), tuple(state_dict[k].shape), str(state_dict[k].dtype), state_dict[k]._version) for k in keys)
         hit = _FP_MEMO.get(cheap)
         if hit is not None:
-            return hit
+            return hit[0]
     h = hashlib.sha1()
     for key in keys:
         t = state_dict[key].detach().cpu().to(torch.float32).contiguous()
@@ -40,10 +41,10 @@ def state_dict_fingerprint(state_dict: Dict[str, torch.Tensor]) -> str:
         h.update(t.numpy().tobytes())
     if cheap is None:
         return h.hexdigest()
-    if len(_FP_MEMO) > 64:
-        _FP_MEMO.clear()
-    _FP_MEMO[cheap] = h.hexdigest()
-    return _FP_MEMO[cheap]
+    if len(_FP_MEMO) >= 8:              # a handful of weight sets at most (each entry pins its tensors in host memory)
+        _FP_MEMO.pop(next(iter(_FP_MEMO)))
+    _FP_MEMO[cheap] = (h.hexdigest(), [state_dict[k] for k in keys])
+    return _FP_MEMO[cheap][0]
 
 
 class Engine:

@@ -486,6 +486,14 @@ def test_state_dict_fingerprint_memo_and_weight_file_cache(tmp_path):
     k = next(iter(sd))
     sd[k].add_(1.0)
     assert engine.state_dict_fingerprint(sd) != f1
+    # a weight set that dies and another one of the same shapes: storage addresses may be reused by the allocator, the memo must
+    # not answer with the dead set's hash (entries pin their tensors, so the addresses cannot be handed out again)
+    seen = set()
+    for seed in range(4):
+        tmp = {kk: torch.full_like(v, float(seed)) for kk, v in sd.items()}
+        seen.add(engine.state_dict_fingerprint(tmp))
+        del tmp
+    assert len(seen) == 4
     p = tmp_path / "superpoint_v1.pth"
     torch.save(synthetic.superpoint_state_dict(0), str(p))
     a = matchers._load_state_dict({"weights_dir": str(tmp_path)}, "superpoint", ["superpoint_v1.pth"])
