@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Generate tests/golden/*.npz by running the REFERENCE modules (imported from /root/reference,
 build container only) on seeded weights and inputs.  Nothing of the reference travels: only the
-input/output vectors written here are committed.  Re-run: `python tools/gen_golden.py`.
+input/output vectors written here are committed.  Re-run: `python tools/gen_golden.py` (every fixture; `--out DIR` writes
+elsewhere, e.g. to compare with the committed files).
 
 Un-vendored dependencies of the reference that are absent here (cv2, kornia, easydict, tkinter) are
 replaced by empty stub modules; no code path that would *call* them is exercised (gray uint8 inputs,
@@ -195,6 +196,12 @@ def gen_prune_threshold():
 
 
 def main():
+    global OUT
+    if "--out" in sys.argv:     # e.g. `python tools/gen_golden.py --out /tmp/golden` to compare with the committed fixtures
+        i = sys.argv.index("--out")
+        OUT = os.path.abspath(sys.argv[i + 1])
+        del sys.argv[i:i + 2]
+        os.makedirs(OUT, exist_ok=True)
     logging.disable(logging.CRITICAL)
     install_stubs()
     sys.path.insert(0, REF_SRC)
@@ -387,6 +394,7 @@ def main():
     print(f"  assets: kpts {f0['keypoints'].shape[1]}/{f1['keypoints'].shape[1]} stop={o['stop']} matches={int((o['matches0'] > -1).sum())}")
     gen_colour(sp_sd)
     gen_prune_threshold()
+    gen_features_pickle()
     save("g5_assets", gray0=g0, gray1=g1, keypoints0=f0["keypoints"][0], keypoints1=f1["keypoints"][0],
          scores0=f0["keypoint_scores"][0], scores1=f1["keypoint_scores"][0],
          desc0_sha=sha(f0["descriptors"][0]), desc0_sample=f0["descriptors"][0][::16],
