@@ -19,6 +19,7 @@ from __future__ import annotations
 
 import logging
 import os
+from abc import ABC, abstractmethod
 from copy import deepcopy
 from dataclasses import dataclass
 from itertools import product
@@ -155,7 +156,23 @@ def _load_state_dict(opt: dict, model: str, filenames: List[str]) -> Dict[str, t
         f"containing one of {filenames}. (The reference downloads them; this build has no network access.)")
 
 
-class ImageMatcherBase:
+class ImageMatcherABC(ABC):
+    """The abstract interface of the reference (`matchers.py:51-65`): a matcher has `match`, `_match_images`, `_match_by_tile`."""
+
+    @abstractmethod
+    def match(self):
+        ...
+
+    @abstractmethod
+    def _match_images(self):
+        ...
+
+    @abstractmethod
+    def _match_by_tile(self):
+        ...
+
+
+class ImageMatcherBase(ImageMatcherABC):
     def __init__(self, opt: dict = {}) -> None:
         """Base class for matchers: `match()` and everything shared; subclasses implement `_match_images`.
 
@@ -728,3 +745,13 @@ class LightGlueMatcher(ImageMatcherBase):
         if features0.scores is not None:
             self._scores0, self._scores1 = features0.scores, features1.scores
         return True
+
+
+class LOFTRMatcher(ImageMatcherBase):
+    """`matchers.py:1005-1200` wraps kornia's LoFTR: a different model family, outside the SuperPoint -> LightGlue / SuperGlue hot
+    path this package rebuilds. Present so that `from icepy4d_amd.matching import *` exports the reference's
+    names; constructing one fails loudly."""
+
+    def __init__(self, opt: dict = {}) -> None:
+        raise NotImplementedError("LOFTRMatcher is outside the scope of icepy4d_amd (SuperPoint + LightGlue / SuperGlue only); "
+                                  "use LightGlueMatcher or SuperGlueMatcher")
