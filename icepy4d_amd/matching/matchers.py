@@ -228,6 +228,8 @@ class ImageMatcherBase(ImageMatcherABC):
         if self._save_dir is not None:
             self._save_dir.mkdir(parents=True, exist_ok=True)
 
+        if config.get("do_viz_matches") or config.get("do_viz_tiles") or config.get("do_viz"):
+            logger.warning("match(): the do_viz_* options are accepted but nothing is drawn (visualisation is out of scope)")
         image0_, image1_ = self._resize_images(quality, image0, image1)
         if tile_selection == TileSelection.NONE:
             logger.info("Matching full images...")
@@ -399,6 +401,15 @@ class ImageMatcherBase(ImageMatcherABC):
                 setattr(self, name, np.compress(inlMask, arr, axis=axis))
         if self._mconf is not None and len(self._mconf) == len(inlMask):
             self._mconf = self._mconf[inlMask]
+
+    def viz_matches_mpl(self, *args, **kwargs) -> None:
+        """Plotting (`matchers.py:702-737`, matplotlib) is outside the hot path this package rebuilds: accepted and skipped, with
+        a warning, so that scripts written against the reference keep running."""
+        logger.warning("viz_matches_mpl: visualisation is out of scope of icepy4d_amd; nothing is drawn")
+
+    def viz_matches_cv2(self, *args, **kwargs) -> None:
+        """`matchers.py:739-800` (OpenCV drawing): see viz_matches_mpl."""
+        logger.warning("viz_matches_cv2: visualisation is out of scope of icepy4d_amd; nothing is drawn")
 
     def save_mkpts_as_txt(self, savedir: Union[str, Path], delimiter: str = ",", header: str = "x,y") -> None:
         """Save keypoints in a .txt file (`matchers.py:802-824`)."""
