@@ -587,6 +587,10 @@ class SuperGlueMatcher(ImageMatcherBase):
         sp_keys, sg_keys = ("nms_radius", "keypoint_threshold", "max_keypoints"), ("weights", "sinkhorn_iterations", "match_threshold")
         return {"superpoint": {k: o[k] for k in sp_keys}, "superglue": {k: o[k] for k in sg_keys}, "force_cpu": o["force_cpu"]}
 
+    def viz_matches(self, *args, **kwargs) -> None:
+        """`matchers.py:942-1002` (SuperGlue's own matplotlib plot): accepted and skipped, see ImageMatcherBase.viz_matches_mpl."""
+        logger.warning("viz_matches: visualisation is out of scope of icepy4d_amd; nothing is drawn")
+
     def _sp_params(self, **config):
         sp = self._cfg["superpoint"]
         return sp["nms_radius"], sp["keypoint_threshold"], 4, int(sp["max_keypoints"]), 1
