@@ -389,6 +389,13 @@ def main():
                               "launches_per_pair": cnt / prof_steps, "algorithmic_gflop_per_launch": fl / cnt / 1e9,
                               "share_of_pair_time": ms / tot, "event_pair_overhead_us": round(1e3 * ev_overhead_ms, 2),
                               "measured": how}
+        if dom == "im::flash_attn_f32_kernel":
+            # the two launch kinds of the class apart: self-attention (4 . 256 . n^2 per image) and the cross block, whose two
+            # launches execute 8 . 256 . n^2 for an algorithmic 6 . 256 . n^2 (S = Q0 Q1^T is computed once per direction)
+            for kname in ("flash_attn_self", "flash_attn_cross"):
+                if kname in prof and prof[kname]["count"]:
+                    f1 = kernel_flops(kname, 2, n0, n1, h, w, cfg5)
+                    result["roofline"]["frac_" + kname.split("_")[-1]] = f1 / (prof[kname]["total_ms"] / prof[kname]["count"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS
         if cfg5 and "sinkhorn" in prof:
             # Sinkhorn: (2 x iterations) sweeps over the (M+1)(N+1) fp32 couplings, one "launch" here = the whole 20-iteration
             # solve of one pair (41 kernel launches of three symbols; rocprofv3 lists them separately)
