@@ -8,6 +8,9 @@
     already resident in HBM -> SuperPoint on both images -> LightGlue (9 layers) -> matches + the pair's match-table record
     on the device. A small pool of pairs is cycled.
 --config 3 (configs[2]): the same step over a sequence of DISTINCT epochs (default 256 steps; seeds 1234+2e / 1235+2e).
+--config 4 (configs[3]): config 3's step over 2048 epochs in total, sharded e = rank (mod N) over --gpus N ranks (2048 / N steps per
+    rank by default), 98 KB records that carry the keypoints of both images, one RCCL all-gather of the tables at the
+    end. A pool of --pool distinct synthetic pairs per rank is cycled (host synthesis of 2048 pairs would take minutes).
 --config 5 (configs[4], not the headline): one step = one 3000x4000 pair, 16384 keypoints, SuperPoint (nms 3) + SuperGlue
     (18 layers, 20 Sinkhorn iterations); roofline objects for the Sinkhorn sweeps (HBM) and the attention kernel (MFMA).
 Every rank processes its own steps (weak scaling, epochs sharded round-robin); the timed region ends with the job's single
@@ -108,9 +111,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--config", type=int, default=2, choices=(2, 3, 5))
+    ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4, 5))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--pool", type=int, default=4, help="config 2: distinct synthetic pairs per rank (cycled)")
+    ap.add_argument("--pool", type=int, default=None, help="configs 2 / 4: distinct synthetic pairs per rank (cycled; default 4 / 32)")
     ap.add_argument("--pairs", default="stereo", choices=("stereo", "translated"),
                     help="stereo = SURVEY §8d homography-warped pair (seeded weights find almost no matches on it: full-depth worst "
                          "case); translated = pure translation by (40, 8) px, ~2500 matches per pair")
@@ -120,21 +123,18 @@ def main():
                                                          "one MI355X: 1 x 3 streams 98.6, 2 x 2 streams 103.0, 4 x 2 streams 95.1 pairs/s")
     ap.add_argument("--no-side-measurements", action="store_true", help="skip the short untimed-side runs (other launch mode, translated pairs)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: spawn / rendezvous / sharding / gather / JSON only")
-    ap.add_argument("--attn-bf16x3", action="store_true",
-                    help="EXPERIMENT (DESIGN.md), not the reported configuration: attention with fp32 products emulated "
-                         "on the bf16 matrix cores")
     args = ap.parse_args()
     if args.steps is None:
-        args.steps = {2: 50, 3: 256, 5: 5}[args.config]
+        args.steps = {2: 50, 3: 256, 4: max(1, 2048 // max(args.gpus, 1)), 5: 5}[args.config]
     if args.warmup is None:
-        args.warmup = {2: 6, 3: 6, 5: 2}[args.config]
+        args.warmup = {2: 6, 3: 6, 4: 6, 5: 2}[args.config]
+    if args.pool is None:
+        args.pool = 32 if args.config == 4 else 4
 
     if args.config == 5:
         args.batch = 1
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn(args)   # does not return
-    if args.attn_bf16x3:
-        os.environ["IM_ATTN_BF16X3"] = "1"   # read by the library when a workspace is reserved
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -194,12 +194,13 @@ def main():
         return e
 
     n_streams = 1 if cfg5 else args.streams
+    with_kp = args.config == 4                     # 98 KB records: keypoints of both images ride along
     sm = PairPipeline(make_engine, h, w, kpts, n_streams=n_streams, use_graph=not args.no_graph, matcher=m_name,
-                      pairs_per_launch=args.batch)
+                      pairs_per_launch=args.batch, with_keypoints=with_kp)
     eng = sm.slots[0][0]
     pool = [torch.from_numpy(p).cuda().contiguous() for p in host_pairs]
-    table = new_table(args.steps, kpts, eng.device)
-    scratch = new_table(max(args.warmup, 2), kpts, eng.device)   # >= 2 rows: the untimed gather below must load torch's sort kernels
+    table = new_table(args.steps, kpts, eng.device, with_kp)
+    scratch = new_table(max(args.warmup, 2), kpts, eng.device, with_kp)   # >= 2 rows: the untimed gather below must load torch's sort kernels
 
     def barrier():
         sm.synchronize()
@@ -243,13 +244,22 @@ def main():
     sm.flush()
     t_enq = time.perf_counter() - t0            # host time to enqueue every step (graph launches are asynchronous)
     sm.synchronize()
+    t_own = time.perf_counter() - t0            # this rank's own pairs done (before the collective)
+    t_g = time.perf_counter()
     full = all_gather_tables(table.cpu() if one_dev else table)
+    torch.cuda.synchronize()
+    t_gather = time.perf_counter() - t_g
     barrier()
     dt = time.perf_counter() - t0
+    ranks = None
     if world > 1 or force_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if one_dev else "cuda")
+        dev_ = "cpu" if one_dev else "cuda"
+        t = torch.tensor([dt], dtype=torch.float64, device=dev_)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # what lets a reader verify that N ranks really took part: every rank reports its own pair count, its own time to finish
+        # them and its time inside the all-gather (one more tiny all-gather, outside the timed region)
+        ranks = rank_report(dist, rank, world, args, t_own, t_gather, torch.cuda.current_device(), dev_, table, full, cpu_group)
     n_pairs = args.steps * world
     assert full.shape[0] == n_pairs, (full.shape, n_pairs)
     nm = full[:, 3].float().mean().item()
@@ -264,6 +274,7 @@ def main():
         metric = "matched stereo image-pairs/sec (4096 kpts, 1080p)"
         workload = (f"configs[{args.config - 1}]: one 1080x1920 gray stereo pair per step"
                     + (" over a sequence of distinct epochs" if args.config == 3 else f" (pool of {len(pool)} pairs cycled)")
+                    + (f", {n_pairs} epochs in total sharded over {world} rank(s), 98 KB records with the keypoints of both images" if args.config == 4 else "")
                     + ", SuperPoint (4096 kpts, nms 4) + LightGlue (9 layers, CPU-path semantics: pruning evaluated every layer), "
                       "seeded weights; epochs sharded round-robin, one all-gather of match tables at the end")
     result = {
@@ -273,20 +284,24 @@ def main():
         "config": {"workload": workload, "height": h, "width": w, "max_keypoints": kpts, "pairs_per_step": 1,
                    "pair_synthesis": args.pairs if not cfg5 else "translated", "hip_graph": not args.no_graph,
                    "pairs_in_flight": n_streams, "pairs_per_launch": args.batch,
-                   "attention": "bf16x3 experiment" if os.environ.get("IM_ATTN_BF16X3") else "fp32 MFMA",
+                   "attention": "fp32 MFMA",
                    "mean_keypoints": n0, "mean_matches": nm},
         "host_enqueue_ms_per_step": 1e3 * t_enq / args.steps, "untimed_pairs_before_timing": warm_pairs,
+        "all_gather_ms": 1e3 * t_gather,
     }
+    if ranks is not None:
+        result["ranks"] = ranks
 
-    def quick_rate(pipe, inputs, n):
+    def quick_rate(pipe, inputs, n, host=False):
         """Untimed-warm, short side measurement on this rank: pairs/s of `pipe` over n pairs of `inputs`."""
-        side = new_table(n, kpts, eng.device)
+        side = new_table(n, kpts, eng.device, with_kp)
+        feed = pipe.match_host_pair if host else pipe.match_pair
         for j in range(min(n, 12)):
-            pipe.match_pair(inputs[j % len(inputs)], j, side, j)
+            feed(inputs[j % len(inputs)], j, side, j)
         pipe.flush(); pipe.synchronize()
         t = time.perf_counter()
         for j in range(n):
-            pipe.match_pair(inputs[j % len(inputs)], j, side, j)
+            feed(inputs[j % len(inputs)], j, side, j)
         pipe.flush(); pipe.synchronize()
         return n / (time.perf_counter() - t), side[:, 3].float().mean().item()
 
@@ -298,6 +313,9 @@ def main():
         alt.close()
         tr_pool = [torch.from_numpy(np.stack(synthetic.translated_pair(j, h, w, 40, 8))).cuda().contiguous() for j in range(2)]
         r_tr, m_tr = quick_rate(sm, tr_pool, 48)
+        # the same pairs handed over in HOST memory (what the reference's epoch loop holds after imread): page-locked staging
+        # ring + asynchronous upload on the launch stream, PCIe inside the measured time
+        r_host, _ = quick_rate(sm, host_pairs, 48, host=True)
         adaptive = {}
         for variant in ("earlystop", "prune"):   # weights whose token confidences stop early / whose matchabilities prune points
             v_sd = synthetic.lightglue_state_dict(0, variant)
@@ -325,6 +343,10 @@ def main():
                                              "(`lightglue.py:571-579`) resp. point pruning (`:563-568`) DO trigger on the translated pairs: the "
                                              "device-side stop flag skips the remaining layers' kernels, pruned images run on the live rows only"),
             "other_launch_mode": {"pairs_per_launch": alt_b, "pairs_in_flight": alt_s, "pairs_per_s": r_alt, "pairs": 48},
+            "host_inputs_pairs_per_s": {"pairs_per_s": r_host, "pairs": 48,
+                                        "note": "PCIe-inclusive: every pair starts as a numpy uint8 array in pageable host memory, is copied "
+                                                "into a page-locked staging ring and uploaded asynchronously on the launch stream "
+                                                "(`PairPipeline.match_host_pair`); never `value`"},
             "translated_pairs": {"pairs_per_s": r_tr, "mean_matches": m_tr, "pairs": 48,
                                  "note": "pairs related by a pure (40, 8) px translation: the seeded weights match ~1000 keypoints "
                                          "per pair on them (8 on the homography-warped pairs of `value`); same launches, no pruning or "
@@ -385,6 +407,8 @@ def main():
         result["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                               "frac": ach / PEAK_F32_MFMA_TFLOPS,
                               "traffic": traffic_db.get(dom + "<2>" + ("@16384" if cfg5 else ""), {}).get("traffic_bytes"),
+                              "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of a builder run, "
+                                                "FETCH_SIZE doubled per the gfx950 correction; NOT measured by this run)",
                               "avg_launch_ms": ms / cnt,
                               "launches_per_pair": cnt / prof_steps, "algorithmic_gflop_per_launch": fl / cnt / 1e9,
                               "share_of_pair_time": ms / tot, "event_pair_overhead_us": round(1e3 * ev_overhead_ms, 2),
@@ -413,7 +437,15 @@ def main():
                                                    "half of that (`traffic`), i.e. the HBM rate actually sustained is achieved / 2"}
         result["kernel_ms_per_pair"] = {k: round(v["total_ms"] / prof_steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}
         pair_flops = (2 * 2035e9 + 10818e9) if cfg5 else (2 * 351.7e9 + 734.4e9)  # algorithmic FLOPs per pair
-        result["pair_roofline_frac"] = pair_flops * (n_pairs / dt) / world / (PEAK_F32_MFMA_TFLOPS * 1e12)
+        # speed of light by ALGORITHMIC FLOPs (direct-form convolutions): the 3x3 layers run as Winograd F(2x2, 3x3), which executes
+        # 1 / 2.25 of those multiplies, so this figure is not a utilisation and may exceed 1; the executed-FLOP figure is next to it
+        result["pair_algorithmic_speed_of_light_frac"] = pair_flops * (n_pairs / dt) / world / (PEAK_F32_MFMA_TFLOPS * 1e12)
+        if not cfg5:
+            conv3 = 2 * sum(conv_flops(*d) for d in ((h, w, 64, 64), (h // 2, w // 2, 64, 64), (h // 2, w // 2, 64, 64), (h // 4, w // 4, 64, 128),
+                                                     (h // 4, w // 4, 128, 128), (h // 8, w // 8, 128, 128), (h // 8, w // 8, 128, 128),
+                                                     (h // 8, w // 8, 128, 256), (h // 8, w // 8, 128, 256)))
+            executed = pair_flops - conv3 * (1 - 1 / 2.25) + 2.0 * 256 * n0 * n1 * 9   # Winograd multiplies; S computed once per direction
+            result["pair_executed_mfma_utilisation"] = executed * (n_pairs / dt) / world / (PEAK_F32_MFMA_TFLOPS * 1e12)
 
         # ---- CPU baseline: the oracle (torch-CPU fp32 restatement of the reference path) on this box's host cores
         if world == 1 and not args.no_cpu_baseline and not cfg5:
@@ -422,6 +454,31 @@ def main():
     if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def rank_report(dist, rank, world, args, t_own, t_gather, device_index, dev_, table, full, cpu_group):
+    """The `ranks` object of an N > 1 line: every rank reports its own pair count, its own time to finish them and its time inside
+    the table all-gather (one more tiny all-gather, outside the timed region), so that a reader can verify that N ranks on N
+    devices took part and that the gathered table holds every epoch."""
+    import torch
+    from icepy4d_amd.sequence import shard_epochs
+    mine = torch.tensor([float(rank), float(args.steps), t_own, t_gather, float(device_index)], dtype=torch.float64, device=dev_)
+    every = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(every, mine)
+    every = sorted((e.tolist() for e in every), key=lambda r: r[0])
+    nccl_version = None
+    if not cpu_group:
+        try:
+            nccl_version = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            pass
+    total = args.warmup + args.steps
+    want = sorted(e for r in range(world) for e in shard_epochs(total * world, r, world)[args.warmup:])
+    return {"world": dist.get_world_size(), "backend": dist.get_backend(), "nccl_version": nccl_version,
+            "pairs_per_rank": [int(r[1]) for r in every], "device_per_rank": [int(r[4]) for r in every],
+            "per_rank_pairs_per_s": [r[1] / max(r[2], 1e-9) for r in every], "all_gather_ms": [1e3 * r[3] for r in every],
+            "record_bytes": int(table.shape[1]) * 4, "gathered_table_bytes": int(full.numel()) * 4,
+            "epochs_in_gathered_table": int(full.shape[0]), "epochs_complete_and_sorted": bool(full[:, 0].tolist() == want)}
 
 
 def cpu_baseline(epochs):
@@ -467,7 +524,7 @@ def dry_run(args, rank, world, epochs, kpts, dist):
     rank 0 prints a JSON line with the contract's fields (value = records per second of this fake work: NOT a measurement)."""
     import torch
     from icepy4d_amd.sequence import all_gather_tables, new_table
-    table = new_table(args.steps, kpts, "cpu")
+    table = new_table(args.steps, kpts, "cpu", args.config == 4)
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
@@ -477,7 +534,10 @@ def dry_run(args, rank, world, epochs, kpts, dist):
         table[i, 1] = kpts
         table[i, 2] = kpts
         table[i, 3] = e
+    t_own = time.perf_counter() - t0
+    t_g = time.perf_counter()
     full = all_gather_tables(table)
+    t_gather = time.perf_counter() - t_g
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
@@ -489,8 +549,9 @@ def dry_run(args, rank, world, epochs, kpts, dist):
     assert full.shape[0] == n_pairs, (full.shape, n_pairs)
     want = sorted(e for r in range(world) for e in range(r, (args.warmup + args.steps) * world, world)[args.warmup:])
     assert full[:, 0].tolist() == want and full[:, 3].tolist() == want
+    ranks = rank_report(dist, rank, world, args, t_own, t_gather, -1, "cpu", table, full, True) if world > 1 else None
     if rank == 0:
-        print(json.dumps({"metric": "matched stereo image-pairs/sec (4096 kpts, 1080p)", "value": n_pairs / dt, "unit": "pairs/s",
+        print(json.dumps({"ranks": ranks, "metric": "matched stereo image-pairs/sec (4096 kpts, 1080p)", "value": n_pairs / dt, "unit": "pairs/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                           "config": {"workload": "DRY RUN: fabricated records, no GPU work"}, "dry_run": True,

@@ -45,7 +45,7 @@ SIGNATURES = {
     "im_superpoint_candidates": [_P, _I, _P, _P],
     "im_lightglue_forward": [_P, _P, _P, _P, _P, C.POINTER(LightGlueConf), _P, _P, _P, _P, _P],
     "im_lightglue_forward_pairs": [_P, _I, _P, _P, _P, _P, C.POINTER(LightGlueConf), _P, _P, _P, _P, _P],
-    "im_pack_records": [_P, _I, _P, _P, _P, _P, _I, _P, _P],
+    "im_pack_records": [_P, _I, _P, _P, _P, _P, _I, _P, _P, _P],
     "im_superglue_forward": [_P, _P, _P, _P, _P, _P, C.POINTER(SuperGlueConf), _P, _P, _P, _P],
     "im_pack_record": [_P, _P, _P, _P, _P, _I, _P, _P],
     "im_debug_read": [_P, C.c_char_p, _P, C.c_size_t, _P],
@@ -61,7 +61,6 @@ SIGNATURES = {
     "im_sample_descriptors": [_P, _P, _I, _I, _I, _P, _P, _P, _P],
     "im_assign_from_sim": [_P, _P, _I, _I, _I, _P, _P, _F, _P, _P, _P, _P, _P],
     "im_log_optimal_transport": [_P, _P, _I, _I, _I, _F, _I, _P, _P],
-    "im_flash_attn_bf16x3": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
     "im_merge_tile_matches": [_P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "im_gather_rows": [_P, _P, _I, _P, _I, _P, _P],
     "im_ransac_fundamental": [_P, _P, _P, _I, _I, C.c_double, C.c_uint, _P, _P, _P, _P],

@@ -83,9 +83,6 @@ static constexpr int ATTN_MAX_SPLIT = 4;
 inline size_t attn_part_floats(int n_max, int batch, int heads) { return (size_t)ATTN_MAX_SPLIT * batch * heads * n_max * 66; }
 inline size_t attn_counter_ints(int n_max, int batch, int heads) { return (size_t)batch * heads * ((n_max + 127) / 128); }
 hipError_t launch_flash_attn(const AttnArgs& a, hipStream_t s);
-// experiment (attention_bf16x3.hip): the same attention with fp32 products emulated on the bf16 matrix cores; opt-in only
-size_t attn_x3_plane_elems(int n_max, int batch, int heads);
-hipError_t launch_flash_attn_bf16x3(const AttnArgs& a, unsigned short* qp, unsigned short* kp, unsigned short* vtp, bool resplit, hipStream_t s);
 
 // ------------------------------------------------------------------ conv.hip
 struct ConvArgs {

@@ -48,7 +48,7 @@ hipError_t launch_lg_select_layer(LGState* st, int n_pairs, int n_layers, int* s
 hipError_t launch_assign(const AssignArgs& a, hipStream_t s);
 hipError_t launch_zero_words(void* p, long nwords, hipStream_t s);   // use instead of hipMemsetAsync inside forwards (see lg_misc.hip)
 hipError_t launch_pack_record(const int* n, const int* matches0, const float* mscores0, const int* info, int epoch, int K,
-                              int* rec, int n_pairs, hipStream_t s);
+                              int* rec, int n_pairs, const float* kpts, hipStream_t s);
 hipError_t launch_logsig(const float* z, long bstride, const LGState* st, int n_images, int n_max, float* lz, hipStream_t s);
 
 }  // namespace im

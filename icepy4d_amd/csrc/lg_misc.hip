@@ -724,14 +724,17 @@ hipError_t launch_assign(const AssignArgs& a, hipStream_t s) {
 }
 
 // match-table record of one pair (layout in icepy4d_amd/sequence.py): header {epoch, n0, n1, n_matches, stop, 0, 0, 0},
-// matches0 [K], matching_scores0 [K] (bit patterns). One block; the match count is an integer block reduction.
+// matches0 [K], matching_scores0 [K] (bit patterns), and - when kpts is given - the keypoints of both images [2][K][2] as bit
+// patterns (the 98 KB record of SURVEY 8d config 4). One block per pair; the match count is an integer block reduction.
 __global__ __launch_bounds__(256) void pack_record_kernel(const int* __restrict__ n, const int* __restrict__ matches0,
                                                            const float* __restrict__ mscores0, const int* __restrict__ info,
-                                                           int epoch, int K, int* __restrict__ rec) {
+                                                           int epoch, int K, int* __restrict__ rec, const float* __restrict__ kpts) {
     __shared__ int red[4];
-    {   // pair blockIdx.x of a batch: n [2P], matches / scores [2P][K] (row 2p = matches0 of pair p), info [P][4], rec [P][8 + 2K]
+    {   // pair blockIdx.x of a batch: n [2P], matches / scores [2P][K] (row 2p = matches0 of pair p), info [P][4], kpts [2P][K][2]
         const int p = blockIdx.x;
-        n += 2 * p; matches0 += (long)2 * p * K; mscores0 += (long)2 * p * K; info += 4 * p; rec += (long)p * (8 + 2 * K); epoch += p;
+        n += 2 * p; matches0 += (long)2 * p * K; mscores0 += (long)2 * p * K; info += 4 * p; epoch += p;
+        rec += (long)p * (8 + (kpts ? 6 : 2) * K);
+        if (kpts) kpts += (long)4 * p * K;
     }
     int cnt = 0;
     for (int i = threadIdx.x; i < K; i += 256) {
@@ -740,6 +743,8 @@ __global__ __launch_bounds__(256) void pack_record_kernel(const int* __restrict_
         rec[8 + K + i] = __float_as_int(mscores0[i]);
         cnt += m > -1;
     }
+    if (kpts)
+        for (int i = threadIdx.x; i < 4 * K; i += 256) rec[8 + 2 * K + i] = __float_as_int(kpts[i]);
     cnt = wave_sum_i(cnt);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
     __syncthreads();
@@ -750,8 +755,8 @@ __global__ __launch_bounds__(256) void pack_record_kernel(const int* __restrict_
 }
 
 hipError_t launch_pack_record(const int* n, const int* matches0, const float* mscores0, const int* info, int epoch, int K,
-                              int* rec, int n_pairs, hipStream_t s) {
-    hipLaunchKernelGGL(pack_record_kernel, dim3(n_pairs), dim3(256), 0, s, n, matches0, mscores0, info, epoch, K, rec);
+                              int* rec, int n_pairs, const float* kpts, hipStream_t s) {
+    hipLaunchKernelGGL(pack_record_kernel, dim3(n_pairs), dim3(256), 0, s, n, matches0, mscores0, info, epoch, K, rec, kpts);
     return hipGetLastError();
 }
 

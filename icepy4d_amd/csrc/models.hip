@@ -334,10 +334,6 @@ int im_ctx_reserve(im_ctx* ctx, int max_h, int max_w, int max_images, int max_kp
     A(ws->q, NI * K * 256); A(ws->k, NI * K * 256); A(ws->v, NI * K * 256);
     A(ws->att, NI * K * 256); A(ws->msg, NI * K * 256); A(ws->h, NI * K * 512);
     A(ws->attn_part, attn_part_floats((int)K, (int)NI, 4)); A(ws->attn_cnt, attn_counter_ints((int)K, (int)NI, 4));
-    if (getenv("IM_ATTN_BF16X3")) {   // experiment, opt-in: planes for the bf16 x 3 attention
-        const size_t xe = attn_x3_plane_elems((int)K, (int)NI, 4);
-        A(ws->x3_q, xe); A(ws->x3_k, xe); A(ws->x3_vt, xe);
-    }
     A(ws->conf, NI * K); A(ws->msc, NI * K); A(ws->keep_idx, NI * K); A(ws->prune, NI * K);
     A(ws->md, NI * K * 256); A(ws->z, NI * K); A(ws->lz, NI * K);
     ws->sim_ps = (((size_t)K * K + (size_t)K + 4) + 3) & ~(size_t)3;     // floats between the score matrices of consecutive pairs
@@ -354,6 +350,7 @@ int im_ctx_reserve(im_ctx* ctx, int max_h, int max_w, int max_images, int max_kp
     if (!ok) {
         for (void* p : ws->allocs) hipFree(p);
         delete ws;
+        ctx->max_h = ctx->max_w = ctx->max_images = ctx->max_kpts = 0;   // no workspace any more: the next call starts from its own sizes
         return ctx->fail(-31, "im_ctx_reserve: out of device memory (%d x %d, %d images, %d keypoints)", max_h, max_w, max_images, max_kpts);
     }
     ctx->ws = ws;
@@ -384,7 +381,9 @@ int im_superpoint_forward(im_ctx* ctx, const uint8_t* d_img, int n_images, int h
     const SuperPointW& W = ctx->sp;
     const int B = n_images, K = ctx->max_kpts;
     // 3x3 layers run in Winograd F(2x2,3x3) form (conv_wino.hip); IM_CONV_DIRECT=1 selects the direct implicit GEMM
-    static const bool direct = getenv("IM_CONV_DIRECT") && getenv("IM_CONV_DIRECT")[0] == '1';
+    // (read per call, not cached: the parity tests run both forms in one process; a captured graph keeps the form it was captured with)
+    const char* const direct_env = getenv("IM_CONV_DIRECT");
+    const bool direct = direct_env && direct_env[0] == '1';
     auto conv = [&](ConvArgs& a, int layer) { a.w = direct ? W.cw[layer] : W.cww[layer]; return direct ? launch_conv3x3(a, s) : launch_conv3x3_wino(a, s); };
     // conv1a is fused into conv1b's patch producer: the full-resolution 64-channel activation never touches HBM
     float* src = nullptr;
@@ -474,12 +473,7 @@ static int lg_block(im_ctx* ctx, hipStream_t s, int NI, int layer, bool cross, f
         IM_LAUNCH(ctx, "lg_proj_gemm", s, launch_gemm(g, s));
         at.scale = 1.f;
     }
-    if (ws->x3_q) {   // experiment (IM_ATTN_BF16X3=1 at reserve time): operand split pass + bf16 x 3 attention
-        if (cross) at.k = ws->q;
-        IM_LAUNCH(ctx, cross ? "flash_attn_cross" : "flash_attn_self", s, launch_flash_attn_bf16x3(at, ws->x3_q, ws->x3_k, ws->x3_vt, true, s));
-    } else {
-        IM_LAUNCH(ctx, cross ? "flash_attn_cross" : "flash_attn_self", s, launch_flash_attn(at, s));
-    }
+    IM_LAUNCH(ctx, cross ? "flash_attn_cross" : "flash_attn_self", s, launch_flash_attn(at, s));
     // A/B switch: IM_FFN_UNFUSED=1 keeps the three-launch form (ffn.0 GEMM, LayerNorm + GELU, ffn.3 GEMM + residual)
     static const bool unfused = getenv("IM_FFN_UNFUSED") && getenv("IM_FFN_UNFUSED")[0] == '1';
     if (!unfused) {   // ffn.0 on cat([x, att]) (out_proj folded into the weights), LayerNorm, GELU, ffn.3, residual: one kernel
@@ -528,7 +522,6 @@ static int lightglue_forward(im_ctx* ctx, int n_pairs, const float* d_kpts, cons
     const int L = conf->n_layers;
     const int NP = n_pairs, NI = 2 * n_pairs;
     if (L < 1 || L > 9) return ctx->fail(-52, "im_lightglue_forward: n_layers must be 1..9");
-    if (ws->x3_q && n_pairs > 1) return ctx->fail(-54, "im_lightglue_forward: the bf16x3 attention experiment handles one pair per call");
     const bool do_stop = conf->depth_confidence > 0, do_prune = conf->width_confidence > 0;
     const long xb = (long)K * 256, eb = (long)K * 32;
     LGState* st = ws->st;
@@ -609,15 +602,15 @@ int im_pack_record(im_ctx* ctx, const int32_t* d_n, const int32_t* d_matches0, c
                    int epoch, int32_t* d_record, void* stream) {
     IM_CHECK_CTX(ctx);
     if (!ctx->ws) return ctx->fail(-51, "im_pack_record: call im_ctx_reserve first");
-    IM_HIP(ctx, launch_pack_record(d_n, d_matches0, d_mscores0, d_info, epoch, ctx->max_kpts, d_record, 1, (hipStream_t)stream));
+    IM_HIP(ctx, launch_pack_record(d_n, d_matches0, d_mscores0, d_info, epoch, ctx->max_kpts, d_record, 1, nullptr, (hipStream_t)stream));
     return 0;
 }
 
 int im_pack_records(im_ctx* ctx, int n_pairs, const int32_t* d_n, const int32_t* d_matches, const float* d_mscores, const int32_t* d_info,
-                    int first_epoch, int32_t* d_records, void* stream) {
+                    int first_epoch, int32_t* d_records, const float* d_kpts, void* stream) {
     IM_CHECK_CTX(ctx);
     if (!ctx->ws || n_pairs < 1) return ctx->fail(-51, "im_pack_records: call im_ctx_reserve first");
-    IM_HIP(ctx, launch_pack_record(d_n, d_matches, d_mscores, d_info, first_epoch, ctx->max_kpts, d_records, n_pairs, (hipStream_t)stream));
+    IM_HIP(ctx, launch_pack_record(d_n, d_matches, d_mscores, d_info, first_epoch, ctx->max_kpts, d_records, n_pairs, d_kpts, (hipStream_t)stream));
     return 0;
 }
 

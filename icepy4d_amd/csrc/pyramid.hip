@@ -47,12 +47,14 @@ __global__ __launch_bounds__(256) void pyr_up_kernel(const uint8_t* __restrict__
     const int ox = xc / C, ch = xc - ox * C;
     const uint8_t* img = in + (long)b * H * W * C;
     const int i = oy >> 1, j = ox >> 1;
-    // per axis: even sample = prev + 6 cur + next, odd sample = 4 (cur + next)
+    // per axis: even sample = prev + 6 cur + next, odd sample = 4 (cur + next). Borders as in OpenCV's pyrUp: the sample before
+    // the first one is reflected (101), the one after the LAST one is the last one itself (its last column is
+    // src[W-2] + 7 src[W-1] / 8 src[W-1]; rows go through borderInterpolate(2 sy, 2 H, REFLECT_101) / 2 = H - 1 for sy = H)
     int ry[3], wy[3], rx[3], wx[3];
-    if (oy & 1) { ry[0] = i; wy[0] = 4; ry[1] = reflect101(i + 1, H); wy[1] = 4; ry[2] = i; wy[2] = 0; }
-    else { ry[0] = reflect101(i - 1, H); wy[0] = 1; ry[1] = i; wy[1] = 6; ry[2] = reflect101(i + 1, H); wy[2] = 1; }
-    if (ox & 1) { rx[0] = j; wx[0] = 4; rx[1] = reflect101(j + 1, W); wx[1] = 4; rx[2] = j; wx[2] = 0; }
-    else { rx[0] = reflect101(j - 1, W); wx[0] = 1; rx[1] = j; wx[1] = 6; rx[2] = reflect101(j + 1, W); wx[2] = 1; }
+    if (oy & 1) { ry[0] = i; wy[0] = 4; ry[1] = min(i + 1, H - 1); wy[1] = 4; ry[2] = i; wy[2] = 0; }
+    else { ry[0] = reflect101(i - 1, H); wy[0] = 1; ry[1] = i; wy[1] = 6; ry[2] = min(i + 1, H - 1); wy[2] = 1; }
+    if (ox & 1) { rx[0] = j; wx[0] = 4; rx[1] = min(j + 1, W - 1); wx[1] = 4; rx[2] = j; wx[2] = 0; }
+    else { rx[0] = reflect101(j - 1, W); wx[0] = 1; rx[1] = j; wx[1] = 6; rx[2] = min(j + 1, W - 1); wx[2] = 1; }
     int sum = 0;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {

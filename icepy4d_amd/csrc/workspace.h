@@ -23,7 +23,6 @@ struct Workspace {
     int* ind[2] = {nullptr, nullptr};
     float* q = nullptr; float* k = nullptr; float* v = nullptr;
     float* att = nullptr; float* msg = nullptr; float* h = nullptr;
-    unsigned short *x3_q = nullptr, *x3_k = nullptr, *x3_vt = nullptr;   // bf16 x 3 planes (experiment, IM_ATTN_BF16X3=1 only)
     float* attn_part = nullptr; int* attn_cnt = nullptr;   // split-KV partials and block counters (attention.hip)
     float* conf = nullptr; float* msc = nullptr; int* keep_idx = nullptr; int* prune = nullptr;
     float* md = nullptr; float* z = nullptr; float* lz = nullptr;

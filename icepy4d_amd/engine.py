@@ -98,7 +98,17 @@ class Engine:
             return
         max_h, max_w, max_images = max(max_h, self.max_h), max(max_w, self.max_w), max(max_images, self.max_images)
         max_kpts = max(max_kpts, self.max_kpts)
-        self.ctx.call("im_ctx_reserve", max_h, max_w, max_images, max_kpts)
+        try:
+            self.ctx.call("im_ctx_reserve", max_h, max_w, max_images, max_kpts)
+        except Exception:
+            # the library has already released the old workspace (a failed growth, e.g. out of device memory, leaves the context
+            # without one): forget the old sizes and buffers, invalidate every captured graph, and let the caller see the error.
+            # A later reserve() then really calls the library instead of returning early on stale sizes; the engine stays usable
+            # (also for the other matcher objects that share it through matchers.get_engine).
+            self.max_h = self.max_w = self.max_images = self.max_kpts = 0
+            self.generation += 1
+            self.graphs.clear()
+            raise
         self.max_h, self.max_w, self.max_images, self.max_kpts = max_h, max_w, max_images, max_kpts
         self.generation += 1
         K, B = max_kpts, max_images

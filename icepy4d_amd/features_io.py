@@ -60,13 +60,14 @@ def _reference_names():
     """pickle stores classes by (module, name) and checks that the name resolves to the very object: when the reference package
     is not importable, a module object with the stand-ins answers under the reference's module path."""
     created = []
-    try:
-        import importlib
-        real = importlib.import_module(_REF_MODULE)   # an icepy4d installation: use its own classes
+    try:                                                # only the import is guarded: an error raised by the with-body must
+        import importlib                                # propagate, not be swallowed here and answered by a second yield
+        real = importlib.import_module(_REF_MODULE)     # an icepy4d installation: use its own classes
+    except Exception:
+        real = None
+    if real is not None:
         yield real.Feature, real.Features
         return
-    except Exception:
-        pass
     try:
         for name in ("icepy4d", "icepy4d.core", _REF_MODULE):
             if name not in sys.modules:

@@ -91,17 +91,13 @@ def _as_device_image(image: np.ndarray) -> np.ndarray:
     raise ValueError(f"Not an image: {image.shape}")
 
 
-def _resized_gray(image: np.ndarray, resize: int) -> Tuple[np.ndarray, np.ndarray]:
-    """`ImagePreprocessor.__call__` with `resize` given (`lightglue/utils.py:26-39`, called by `SuperPoint.extract`
-    `lightglue/superpoint.py:217-231`): u8 -> float / 255 (`matchers.py:1212-1220`), kornia `resize(img, resize, side="long",
-    antialias=True, align_corners=None, interpolation="bilinear")`, then kornia `rgb_to_grayscale`. kornia is un-vendored and
-    absent: its published algorithm is restated here with torch CPU ops (Gaussian blur with sigma = (factor - 1) / 2 per axis,
-    kernel size int(max(4 sigma, 3)) made odd, reflect border, before a bilinear `F.interpolate` when downscaling) -
-    parity unpinned. Returns (float32 gray [H', W'] in [0, 1], scales = [W' / W, H' / H] float32). icepy4d itself never passes
-    `resize` (`matchers.py:1247-1248` reads it from **config, `main_dev.py:115-132` does not set it)."""
+def _preprocess_once(x: "torch.Tensor", resize: int) -> Tuple["torch.Tensor", np.ndarray]:
+    """One `ImagePreprocessor.__call__` (`lightglue/utils.py:26-39`) on a float [C, h, w] image: kornia `resize(img, resize,
+    side="long", antialias=True, align_corners=None, interpolation="bilinear")`, then `rgb_to_grayscale` if C == 3. kornia is
+    un-vendored and absent: its published algorithm is restated with torch CPU ops (Gaussian blur with sigma = (factor - 1) / 2
+    per axis, kernel size int(max(4 sigma, 3)) made odd, reflect border, before a bilinear `F.interpolate` when downscaling) -
+    parity unpinned. Returns (image', scales = [w' / w, h' / h])."""
     import torch.nn.functional as F
-    x = torch.tensor(image / 255.0, dtype=torch.float)
-    x = x.permute(2, 0, 1) if x.dim() == 3 else x[None]
     h, w = x.shape[-2:]
     aspect = w / h
     size = (int(resize / aspect), int(resize)) if aspect > 1 else (int(resize), int(resize * aspect))
@@ -127,6 +123,21 @@ def _resized_gray(image: np.ndarray, resize: int) -> Tuple[np.ndarray, np.ndarra
     scales = np.array([x.shape[-1] / w, x.shape[-2] / h], dtype=np.float32)
     if x.shape[0] == 3:
         x = (0.299 * x[0:1] + 0.587 * x[1:2]) + 0.114 * x[2:3]
+    return x, scales
+
+
+def _resized_gray(image: np.ndarray, resize: int) -> Tuple[np.ndarray, np.ndarray]:
+    """`SuperPoint.extract(img, resize=...)` (`lightglue/superpoint.py:217-231`) up to the network input: u8 -> float / 255
+    (`matchers.py:1212-1220`), then the reference's TWO `ImagePreprocessor` calls (`superpoint.py:224-227`). The second call sees
+    the already resized gray image, so the `scales` that `extract` finally uses are those of the second call - [1, 1] unless
+    int() rounds the target size differently for the resized aspect ratio - and the keypoints stay in the RESIZED frame while
+    `image_size` is the original (W, H): that observable behaviour is reproduced here. Returns (float32 gray [H', W'] in [0, 1],
+    scales of the second call). icepy4d itself never passes `resize` (`matchers.py:1247-1248` reads it from **config,
+    `main_dev.py:115-132` does not set it)."""
+    x = torch.tensor(image / 255.0, dtype=torch.float)
+    x = x.permute(2, 0, 1) if x.dim() == 3 else x[None]
+    x, _ = _preprocess_once(x, resize)
+    x, scales = _preprocess_once(x, resize)
     return np.ascontiguousarray(x[0].numpy()), scales
 
 
@@ -402,15 +413,6 @@ class ImageMatcherBase(ImageMatcherABC):
         if self._mconf is not None and len(self._mconf) == len(inlMask):
             self._mconf = self._mconf[inlMask]
 
-    def viz_matches_mpl(self, *args, **kwargs) -> None:
-        """Plotting (`matchers.py:702-737`, matplotlib) is outside the hot path this package rebuilds: accepted and skipped, with
-        a warning, so that scripts written against the reference keep running."""
-        logger.warning("viz_matches_mpl: visualisation is out of scope of icepy4d_amd; nothing is drawn")
-
-    def viz_matches_cv2(self, *args, **kwargs) -> None:
-        """`matchers.py:739-800` (OpenCV drawing): see viz_matches_mpl."""
-        logger.warning("viz_matches_cv2: visualisation is out of scope of icepy4d_amd; nothing is drawn")
-
     def save_mkpts_as_txt(self, savedir: Union[str, Path], delimiter: str = ",", header: str = "x,y") -> None:
         """Save keypoints in a .txt file (`matchers.py:802-824`)."""
         path = Path(savedir)
@@ -587,10 +589,6 @@ class SuperGlueMatcher(ImageMatcherBase):
         sp_keys, sg_keys = ("nms_radius", "keypoint_threshold", "max_keypoints"), ("weights", "sinkhorn_iterations", "match_threshold")
         return {"superpoint": {k: o[k] for k in sp_keys}, "superglue": {k: o[k] for k in sg_keys}, "force_cpu": o["force_cpu"]}
 
-    def viz_matches(self, *args, **kwargs) -> None:
-        """`matchers.py:942-1002` (SuperGlue's own matplotlib plot): accepted and skipped, see ImageMatcherBase.viz_matches_mpl."""
-        logger.warning("viz_matches: visualisation is out of scope of icepy4d_amd; nothing is drawn")
-
     def _sp_params(self, **config):
         sp = self._cfg["superpoint"]
         return sp["nms_radius"], sp["keypoint_threshold"], 4, int(sp["max_keypoints"]), 1
@@ -731,8 +729,8 @@ class LightGlueMatcher(ImageMatcherBase):
     def _match_images_resized(self, image0: np.ndarray, image1: np.ndarray, resize: int, max_keypoints: int):
         """`extract(image, resize=resize)` (`lightglue/superpoint.py:217-231`): the images are resized (long side = `resize`) and
         converted to gray on the HOST (kornia's algorithm restated, `_resized_gray`), extraction runs on the float gray images,
-        keypoints go back to the original frame as `(k + 0.5) / scales - 0.5` before matching, `image_size` stays the
-        original (W, H)."""
+        keypoints are mapped by `(k + 0.5) / scales - 0.5` with the scales of the reference's SECOND preprocessor call (normally
+        [1, 1]: they stay in the resized frame, as in the reference), `image_size` stays the original (W, H)."""
         eng = self.engine
         g, sc = zip(*(_resized_gray(im, resize) for im in (image0, image1)))
         eng.reserve(max(x.shape[0] for x in g), max(x.shape[1] for x in g), 2, max_keypoints)
@@ -760,13 +758,3 @@ class LightGlueMatcher(ImageMatcherBase):
         if features0.scores is not None:
             self._scores0, self._scores1 = features0.scores, features1.scores
         return True
-
-
-class LOFTRMatcher(ImageMatcherBase):
-    """`matchers.py:1005-1200` wraps kornia's LoFTR: a different model family, outside the SuperPoint -> LightGlue / SuperGlue hot
-    path this package rebuilds. Present so that `from icepy4d_amd.matching import *` exports the reference's
-    names; constructing one fails loudly."""
-
-    def __init__(self, opt: dict = {}) -> None:
-        raise NotImplementedError("LOFTRMatcher is outside the scope of icepy4d_amd (SuperPoint + LightGlue / SuperGlue only); "
-                                  "use LightGlueMatcher or SuperGlueMatcher")

@@ -11,6 +11,9 @@ Record layout (int32 words):
     [0] epoch  [1] n0  [2] n1  [3] n_matches (-1 = pair failed)  [4] stop layer  [5..7] reserved
     [8 : 8+K]       matches0 (int32, -1 = unmatched)
     [8+K : 8+2K]    matching_scores0 (float32 bit patterns)
+    [8+2K : 8+6K]   optional payload (`with_keypoints`): keypoints0, keypoints1 as float32 [K][2] (x, y) bit patterns - the 98 KB
+                    record of SURVEY §8d config 4, with which a rank that holds the gathered table can rebuild matched point pairs
+                    of every epoch without the extracting rank's buffers
 """
 from __future__ import annotations
 
@@ -23,8 +26,8 @@ HEADER = 8
 _FORCE_COLLECTIVE = __import__("os").environ.get("IM_BENCH_FORCE_DIST") == "1"   # rehearsal: run the all-gather at world size 1 too
 
 
-def record_words(max_kpts: int) -> int:
-    return HEADER + 2 * max_kpts
+def record_words(max_kpts: int, with_keypoints: bool = False) -> int:
+    return HEADER + (6 if with_keypoints else 2) * max_kpts
 
 
 def shard_epochs(n_epochs: int, rank: int, world: int) -> List[int]:
@@ -33,8 +36,8 @@ def shard_epochs(n_epochs: int, rank: int, world: int) -> List[int]:
     return list(range(rank, n_epochs, world))
 
 
-def new_table(n_rows: int, max_kpts: int, device) -> torch.Tensor:
-    t = torch.full((n_rows, record_words(max_kpts)), -1, dtype=torch.int32, device=device)
+def new_table(n_rows: int, max_kpts: int, device, with_keypoints: bool = False) -> torch.Tensor:
+    t = torch.full((n_rows, record_words(max_kpts, with_keypoints)), -1, dtype=torch.int32, device=device)
     t[:, HEADER + max_kpts:] = 0
     return t
 
@@ -43,9 +46,10 @@ def write_records(table: torch.Tensor, row: int, first_epoch: int, n_pairs: int,
     """Rows row .. row + n_pairs - 1 of `table` from the outputs of the engine's last `lightglue(n_pairs=...)`: one kernel."""
     from ._lib import ptr, stream_ptr
     K = engine.max_kpts
-    assert table.shape[1] == HEADER + 2 * K and table.is_contiguous() and row + n_pairs <= table.shape[0]
+    assert table.shape[1] in (HEADER + 2 * K, HEADER + 6 * K) and table.is_contiguous() and row + n_pairs <= table.shape[0]
+    kpts = ptr(engine.kpts) if table.shape[1] == HEADER + 6 * K else None     # keypoint payload: engine.kpts [2 P][K][2]
     engine.ctx.call("im_pack_records", int(n_pairs), ptr(engine.n), ptr(engine.matches), ptr(engine.mscores), ptr(engine.info),
-                    int(first_epoch), table[row].data_ptr(), stream_ptr())
+                    int(first_epoch), table[row].data_ptr(), kpts, stream_ptr())
 
 
 def write_record(table: torch.Tensor, row: int, epoch: int, n: torch.Tensor, matches0: torch.Tensor,
@@ -90,11 +94,16 @@ def all_gather_tables(local: torch.Tensor, group=None) -> torch.Tensor:
 
 
 def decode_record(rec: np.ndarray, max_kpts: int) -> dict:
-    rec = np.asarray(rec)
+    rec = np.ascontiguousarray(rec)
     K = max_kpts
-    return dict(epoch=int(rec[0]), n0=int(rec[1]), n1=int(rec[2]), n_matches=int(rec[3]), stop=int(rec[4]),
-                matches0=rec[HEADER:HEADER + K][:max(int(rec[1]), 0)].astype(np.int64),
-                matching_scores0=rec[HEADER + K:HEADER + 2 * K].view(np.float32)[:max(int(rec[1]), 0)])
+    n0, n1 = max(int(rec[1]), 0), max(int(rec[2]), 0)
+    out = dict(epoch=int(rec[0]), n0=int(rec[1]), n1=int(rec[2]), n_matches=int(rec[3]), stop=int(rec[4]),
+               matches0=rec[HEADER:HEADER + K][:n0].astype(np.int64),
+               matching_scores0=rec[HEADER + K:HEADER + 2 * K].view(np.float32)[:n0])
+    if len(rec) == HEADER + 6 * K:
+        kp = rec[HEADER + 2 * K:].view(np.float32).reshape(2, K, 2)
+        out["keypoints0"], out["keypoints1"] = kp[0, :n0], kp[1, :n1]
+    return out
 
 
 def save_table(path: str, table: torch.Tensor, max_kpts: int) -> None:
@@ -144,7 +153,7 @@ class SequenceMatcher:
                  detection_threshold: float = 0.0005, remove_borders: int = 4, depth_confidence: float = 0.95,
                  width_confidence: float = 0.99, filter_threshold: float = 0.1, use_graph: bool = True,
                  matcher: str = "lightglue", sinkhorn_iterations: int = 20, match_threshold: float = 0.3,
-                 pruning_min_kpts: int = -1, channels: int = 1, pairs_per_launch: int = 1):
+                 pruning_min_kpts: int = -1, channels: int = 1, pairs_per_launch: int = 1, with_keypoints: bool = False):
         self.e = engine
         self.h, self.w, self.k = height, width, max_keypoints
         self.matcher = matcher
@@ -165,8 +174,10 @@ class SequenceMatcher:
         self._graph = None
         shape = (2 * self.P, height, width) if channels == 1 else (2 * self.P, height, width, 3)
         self._inp = torch.zeros(shape, dtype=torch.uint8, device=engine.device)
-        self._rec = new_table(self.P, engine.max_kpts, engine.device)
+        self._rec = new_table(self.P, engine.max_kpts, engine.device, with_keypoints)
         self._pending = []           # (epoch, table, row) of the pairs waiting in self._inp
+        self._pinned = None          # host feeder: ring of page-locked staging buffers (match_host_pair)
+        self._pin_i = 0
 
     def _enqueue(self, pairs_u8: torch.Tensor) -> None:
         e = self.e
@@ -228,6 +239,35 @@ class SequenceMatcher:
         if len(self._pending) == self.P:
             self._run_group()
 
+    def match_host_pair(self, pair_u8: np.ndarray, epoch: int, table: torch.Tensor, row: int) -> None:
+        """The same for a pair in HOST memory (what the reference's loop has after `cv2.imread`, `core/images.py:44-93` ->
+        `main_dev.py:115-132`): numpy uint8 [2, H, W] (or [2, H, W, 3]). The pair is copied into a page-locked staging buffer
+        (a ring of 2 P + 2 buffers, so that the host never rewrites a buffer whose upload may still be in flight) and uploaded
+        with an asynchronous copy on the CURRENT stream, in front of the launches that read it: no synchronisation, the
+        upload of one pair overlaps the kernels of the previous one. Before a staging buffer is reused its last upload is
+        waited for through an event - by then two launch groups old."""
+        if self._pinned is None:
+            shape = tuple(self._inp.shape[1:])
+            self._pinned = [[torch.empty((2,) + shape, dtype=torch.uint8).pin_memory(), None] for _ in range(2 * self.P + 2)]
+        slot = self._pinned[self._pin_i]
+        self._pin_i = (self._pin_i + 1) % len(self._pinned)
+        if slot[1] is not None:
+            slot[1].synchronize()
+        np.copyto(slot[0].numpy(), pair_u8)
+        if self.use_graph and self._graph is None:
+            self._capture()
+        j = len(self._pending) if (self.P > 1 or self.use_graph) else 0
+        self._inp[2 * j:2 * j + 2].copy_(slot[0], non_blocking=True)
+        slot[1] = torch.cuda.Event()
+        slot[1].record()
+        if self.P == 1 and not self.use_graph:
+            self._enqueue(self._inp)
+            self._record(table, row, epoch, 1)
+            return
+        self._pending.append((epoch, table, row))
+        if len(self._pending) == self.P:
+            self._run_group()
+
     def flush(self) -> None:
         """Run a partially filled group (direct launches for just the parked pairs)."""
         self._run_group()
@@ -272,6 +312,15 @@ class PairPipeline:
         with torch.cuda.stream(stream):
             sm.match_pair(pair_u8, epoch, table, row)
         if not sm._pending:                       # the slot's launch group went out: the next pair goes to the next slot
+            self._next = (self._next + 1) % len(self.slots)
+
+    def match_host_pair(self, pair_u8: np.ndarray, epoch: int, table: torch.Tensor, row: int) -> None:
+        """A pair in host memory (numpy uint8): staged through page-locked buffers and uploaded asynchronously on the slot's
+        stream (`SequenceMatcher.match_host_pair`); never synchronises the device."""
+        eng, stream, sm = self.slots[self._next]
+        with torch.cuda.stream(stream):
+            sm.match_host_pair(pair_u8, epoch, table, row)
+        if not sm._pending:
             self._next = (self._next + 1) % len(self.slots)
 
     def flush(self) -> None:

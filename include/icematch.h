@@ -117,9 +117,12 @@ int im_superglue_forward(im_ctx* ctx, const float* d_kpts, const float* d_scores
 int im_pack_record(im_ctx* ctx, const int32_t* d_n, const int32_t* d_matches0, const float* d_mscores0,
                    const int32_t* d_info, int epoch, int32_t* d_record, void* stream);
 /* n_pairs records at once from the outputs of im_lightglue_forward_pairs (epochs first_epoch .. first_epoch + n_pairs - 1);
- * d_records [n_pairs][8 + 2 * max_kpts]. */
+ * d_records [n_pairs][8 + 2 * max_kpts]. With d_kpts != NULL (the [2 n_pairs][max_kpts][2] keypoints of im_superpoint_forward)
+ * every record also carries the keypoints of both images as float32 bit patterns: d_records [n_pairs][8 + 6 * max_kpts]
+ * (the 98 KB record of a sharded run whose gathered table must be self-contained; the reference keeps them in
+ * `Epoch.features`, `main_dev.py:160-173`). */
 int im_pack_records(im_ctx* ctx, int n_pairs, const int32_t* d_n, const int32_t* d_matches, const float* d_mscores,
-                    const int32_t* d_info, int first_epoch, int32_t* d_records, void* stream);
+                    const int32_t* d_info, int first_epoch, int32_t* d_records, const float* d_kpts, void* stream);
 /* Copies an internal buffer of the last forward ("lg_x", "lg_cos", "lg_sin", "sim", "md", "sp_smap", "sp_nms") for
  * stage-level parity tests. */
 int im_debug_read(im_ctx* ctx, const char* name, float* d_dst, size_t nfloats, void* stream);
@@ -192,12 +195,6 @@ int im_gather_rows(im_ctx* ctx, const float* d_src, int row_floats, const int32_
  * its inliers; d_info {inlier count, hypothesis index}. The least-squares refit on the inliers is left to the caller. */
 int im_ransac_fundamental(im_ctx* ctx, const float* d_p0, const float* d_p1, int n, int n_hyp, double threshold,
                           unsigned int seed, double* d_F, uint8_t* d_mask, int32_t* d_info, void* stream);
-
-/* EXPERIMENT, not used by any model path: im_flash_attn with every fp32 product emulated on the
- * BF16 matrix cores (3-way operand split, six cross products, fp32 accumulation). resplit = 0 reuses the bf16 planes of
- * the previous call (timing of the attention kernel alone). */
-int im_flash_attn_bf16x3(im_ctx* ctx, const float* d_q, const float* d_k, const float* d_v, float* d_out, const int32_t* d_n,
-                         int n_max, int batch, int heads, int cross, float scale, int resplit, void* stream);
 
 #ifdef __cplusplus
 }

@@ -4,7 +4,8 @@
 Gaussian pyramid steps used by `Quality` resizing and tile preselection. The reference calls OpenCV
 (`cv2.pyrDown` / `cv2.pyrUp`, `matchers.py:529-530, 599-609`), an un-vendored dependency that is absent
 here, so this is a restatement of OpenCV's documented algorithm for 8-bit images: separable 5-tap kernel
-[1 4 6 4 1]/16, BORDER_REFLECT_101, fixed-point rounding (sum + 128) >> 8 for pyrDown and (sum + 32) >> 6 for
+[1 4 6 4 1]/16, BORDER_REFLECT_101 (pyrUp: reflected before the first sample, clamped after the last one, as in
+OpenCV's `pyrUp_`), fixed-point rounding (sum + 128) >> 8 for pyrDown and (sum + 32) >> 6 for
 pyrUp. Parity with a specific OpenCV build is unpinned (no cv2 in the image)."""
 import numpy as np
 
@@ -43,7 +44,7 @@ def pyr_up(img: np.ndarray) -> np.ndarray:
         out = np.zeros((2 * n,) + x.shape[1:], dtype=np.int64)
         i = np.arange(n)
         prev = x[_reflect101(i - 1, n)]
-        nxt = x[_reflect101(i + 1, n)]
+        nxt = x[np.minimum(i + 1, n - 1)]     # OpenCV's pyrUp: the sample after the last one is the last one itself
         out[0::2] = prev + 6 * x + nxt        # even samples: [1 6 1] / 8
         out[1::2] = 4 * (x + nxt)             # odd samples:  [4 4] / 8
         return out

@@ -174,3 +174,16 @@ def explain_match_diffs(log_assign: torch.Tensor, m0_ours: np.ndarray, m0_ref: n
 def match_pairs(kp0: np.ndarray, kp1: np.ndarray, m0: np.ndarray) -> set:
     """Matches as coordinate pairs ((x0, y0), (x1, y1)): independent of the order keypoints are listed in."""
     return {(tuple(kp0[i]), tuple(kp1[j])) for i, j in enumerate(m0) if j > -1}
+
+
+def assert_same_matches(k0, k1, m0, ref_k0, ref_k1, ref_m0, ref_s0=None, ref_s1=None):
+    """Match indices bit-exact when both sides list the keypoints in the same order; when the top-k order differs among
+    scores closer than the float error (tests/margins.py), the same matched COORDINATE pairs."""
+    if np.array_equal(k0, ref_k0) and np.array_equal(k1, ref_k1):
+        assert np.array_equal(m0, ref_m0), int(np.sum(m0 != ref_m0))
+        return
+    assert {tuple(p) for p in k0} == {tuple(p) for p in ref_k0} and {tuple(p) for p in k1} == {tuple(p) for p in ref_k1}
+    if ref_s0 is not None:
+        assert explain_order_diffs(k0, ref_k0, ref_s0, 1e-6)["unexplained"] == []
+        assert explain_order_diffs(k1, ref_k1, ref_s1, 1e-6)["unexplained"] == []
+    assert match_pairs(k0, k1, m0) == match_pairs(ref_k0, ref_k1, ref_m0)

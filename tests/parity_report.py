@@ -7,7 +7,7 @@ decision margin that explains it (tests/margins.py).   *** TEST INFRASTRUCTURE (
 `run_case` is also what tests/test_gpu_parity.py asserts on (zero unexplained mismatches).
 
 The chain that is verified, per case:
-  A. extraction: device score map vs oracle score map (max abs error, the float tolerance eps_s := 4 x that, capped at 1e-5);
+  A. extraction: device score map vs oracle score map (max abs error, asserted < 5e-7 by the tests; the float tolerance eps_s := 4 x that, capped at 2e-6);
      device keypoints vs oracle keypoints: every keypoint of the symmetric difference must be explained by an oracle decision
      (NMS equality / threshold / top-k cut) with margin <= eps_s; keypoints present on both sides carry scores within 1e-5 and
      descriptors within 1e-4;
@@ -36,6 +36,13 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 import margins  # noqa: E402
 from icepy4d_amd import synthetic  # noqa: E402
+
+
+# The score map of the device differs from the oracle's by another fp32 summation order only: 0.7-2.1e-7 over every case of
+# rounds 1-3 (profiles/r0*_parity_*.json). The tests assert err < ERR_BOUND, and an oracle decision margin may "explain" a
+# flipped keypoint only below eps = min(4 err, EPS_CAP): a convolution that drifted to 2e-6 fails instead of explaining more.
+ERR_BOUND = 5e-7
+EPS_CAP = 2e-6
 
 
 def _read(eng, name, numel):
@@ -80,7 +87,7 @@ def run_case(eng, img0, img1, sp_sd, lg_sd, max_k, lg_conf=None, radius=4, thr=0
             ref = o.superpoint_lg(o.frame_to_tensor(img), sp_sd, max_k, radius, thr, border, trace=tr)
         smap_o, nms_o = tr["score_map"][0], tr["nms"][0]
         err = float((smap_d[b] - smap_o).abs().max())
-        eps = min(max(4.0 * err, 1e-9), 1e-5)
+        eps = min(max(4.0 * err, 1e-9), EPS_CAP)
         eps_all = max(eps_all, eps)
         ref_kp, ref_sc, ref_desc = ref["keypoints"].numpy(), ref["keypoint_scores"].numpy(), ref["descriptors"].numpy()
         ex = margins.explain_keypoint_diffs(smap_o, nms_o, kp, ref_kp, radius, border, thr, max_k, eps)
@@ -171,7 +178,7 @@ def run_case_superglue(eng, img0, img1, sp_sd, sg_sd, max_k, radius=3, thr=0.001
             nms_on_d = o.simple_nms(smap_d[b][None], radius)[0]
             kp_b, sc_b = o.select_keypoints_sg(nms_on_d, border, thr, max_k)
         err = float((smap_d[b] - smap_o[0]).abs().max())
-        eps = min(max(4.0 * err, 1e-9), 1e-5)
+        eps = min(max(4.0 * err, 1e-9), EPS_CAP)
         ref_kp, ref_sc, ref_desc = ref_kp_t.numpy(), ref_sc_t.numpy(), ref_desc_t.numpy().T
         ex = margins.explain_keypoint_diffs(smap_o[0], nms_o[0], kp, ref_kp, radius, border, thr, max_k, eps)
         ours = {tuple(q): i for i, q in enumerate(kp)}

@@ -210,29 +210,3 @@ def test_flash_attn_large_dynamic_range(ctx):
         assert err < max(4 * err32, 1e-4), (z, err, err32)
 
 
-@pytest.mark.parametrize("n0,n1,cross", [(128, 128, 0), (300, 257, 0), (300, 257, 1), (1000, 77, 1), (64, 1, 1), (33, 95, 1)])
-def test_flash_attn_bf16x3_experiment(ctx, n0, n1, cross):
-    """The bf16 x 3 emulation of the attention kernel (experiment) against the same fp64 reference
-    and the SAME tolerance as the fp32-MFMA kernel."""
-    from icepy4d_amd._lib import ptr, stream_ptr
-    nmax, heads = 1024, 4
-    g = torch.Generator().manual_seed(n0 * 7 + n1)
-    q = torch.randn(2, heads, nmax, 64, generator=g)
-    k = torch.randn(2, heads, nmax, 64, generator=g)
-    v = torch.randn(2, heads, nmax, 64, generator=g)
-    ns = [n0, n1]
-    scale = 0.125
-    dout = torch.full((2, nmax, heads * 64), float("nan"), device="cuda")
-    dn = torch.tensor(ns, dtype=torch.int32, device="cuda")
-    dq, dk, dv = dev(q), dev(k), dev(v)
-    ctx.call("im_flash_attn_bf16x3", ptr(dq), ptr(dk), ptr(dv), ptr(dout), ptr(dn), nmax, 2, heads, cross, scale, 1, stream_ptr())
-    torch.cuda.synchronize()
-    out = dout.cpu()
-    for z in range(2):
-        y = z ^ 1 if cross else z
-        qq, kk, vv = q[z, :, :ns[z]].double(), k[y, :, :ns[y]].double(), v[y, :, :ns[y]].double()
-        att = torch.softmax(qq @ kk.transpose(-1, -2) * scale, -1) @ vv
-        ref = att.transpose(0, 1).reshape(ns[z], heads * 64)
-        err = (out[z, :ns[z]].double() - ref).abs().max().item()
-        assert err < 2e-5, (z, err)
-        assert torch.isnan(out[z, ns[z]:]).all()

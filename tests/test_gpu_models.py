@@ -243,28 +243,6 @@ def test_lightglue_golden(lg_eng, ci):
         assert np.array_equal(out["prune1"], g["prune1"])
 
 
-@pytest.mark.parametrize("ci", [1, 3, 5])
-def test_lightglue_golden_with_bf16x3_attention_experiment(ci, monkeypatch):
-    """The opt-in experiment (attention with fp32 products emulated on the bf16 matrix cores) has to
-    stay as exact as the default path: same reference goldens, same assertions (indices exact, scores 1e-4)."""
-    from icepy4d_amd.engine import Engine
-    monkeypatch.setenv("IM_ATTN_BF16X3", "1")      # read by the library when a workspace is reserved
-    e = Engine(0)
-    e.reserve(64, 64, 2, 1024)
-    monkeypatch.delenv("IM_ATTN_BF16X3")
-    g = load_golden(f"g2_lightglue_{ci}")
-    e.load_state_dict("lightglue", synthetic.lightglue_state_dict(0, str(g["variant"])))
-    f = synthetic.synthetic_features(int(g["seed"]), int(g["m"]), int(g["n"]))
-    wc, dc = float(g["width_confidence"]), float(g["depth_confidence"])
-    out = run_lightglue(e, f, depth_confidence=dc, width_confidence=wc)
-    assert out["stop"] == int(g["stop"])
-    assert np.array_equal(out["matches0"], g["matches0"]) and np.array_equal(out["matches1"], g["matches1"])
-    assert np.abs(out["matching_scores0"] - g["matching_scores0"]).max() < 1e-4
-    if wc > 0:
-        assert np.array_equal(out["prune0"], g["prune0"]) and np.array_equal(out["prune1"], g["prune1"])
-    e.close()
-
-
 def test_assign_from_sim_exact(lg_eng):
     """Stage-isolated: the oracle's own similarity matrix in, match indices bit-exact out."""
     from icepy4d_amd._lib import stream_ptr
@@ -337,18 +315,7 @@ def test_superglue_empty_input(lg_eng):
 
 
 # ------------------------------------------------------------------------------------------- matcher API (wrappers)
-def assert_same_matches(k0, k1, m0, ref_k0, ref_k1, ref_m0, ref_s0=None, ref_s1=None):
-    """Match indices bit-exact when both sides list the keypoints in the same order; when the top-k order differs among
-    scores closer than the float error (tests/margins.py), the same matched COORDINATE pairs."""
-    import margins
-    if np.array_equal(k0, ref_k0) and np.array_equal(k1, ref_k1):
-        assert np.array_equal(m0, ref_m0), int(np.sum(m0 != ref_m0))
-        return
-    assert {tuple(p) for p in k0} == {tuple(p) for p in ref_k0} and {tuple(p) for p in k1} == {tuple(p) for p in ref_k1}
-    if ref_s0 is not None:
-        assert margins.explain_order_diffs(k0, ref_k0, ref_s0, 1e-6)["unexplained"] == []
-        assert margins.explain_order_diffs(k1, ref_k1, ref_s1, 1e-6)["unexplained"] == []
-    assert margins.match_pairs(k0, k1, m0) == margins.match_pairs(ref_k0, ref_k1, ref_m0)
+from margins import assert_same_matches  # noqa: E402  (shared with test_gpu_fullsize.py)
 
 
 def test_lightglue_matcher_api():
@@ -643,6 +610,14 @@ def test_pack_record_matches_torch_twin(lg_eng):
     assert torch.equal(t_lib.cpu()[:, :8 + 2 * K], t_ref.cpu()[:, :8 + 2 * K].where(t_ref.cpu()[:, :8 + 2 * K] != -1, t_lib.cpu()[:, :8 + 2 * K]))
     r = sq.decode_record(t_lib[1].cpu().numpy(), K)
     assert r["epoch"] == 77 and r["n_matches"] == int((g["matches0"] > -1).sum()) and np.array_equal(r["matches0"], g["matches0"])
+    # the 98 KB form: the same record followed by the keypoints of both images, written by the same kernel
+    t_kp = sq.new_table(2, K, e.device, with_keypoints=True)
+    sq.write_records(t_kp, 1, 77, 1, e)
+    torch.cuda.synchronize()
+    assert t_kp.shape[1] == 8 + 6 * K and torch.equal(t_kp[1, :8 + 2 * K].cpu(), t_lib[1].cpu())
+    rk = sq.decode_record(t_kp[1].cpu().numpy(), K)
+    assert np.array_equal(rk["keypoints0"], e.kpts[0, :rk["n0"]].cpu().numpy()) and np.array_equal(rk["keypoints1"], e.kpts[1, :rk["n1"]].cpu().numpy())
+    assert np.array_equal(rk["matches0"], r["matches0"]) and rk["keypoints0"].shape == (int(g["m"]), 2)
 
 
 # ------------------------------------------------------------------------------------------- colour input, pruning gate
@@ -951,8 +926,9 @@ def test_reserve_refuses_sizes_beyond_32_bit_offsets():
 
 def test_resize_option_of_extract():
     """`_match_images(..., resize=R)` (`matchers.py:1247-1248`, `lightglue/superpoint.py:217-231`): extraction on the image resized
-    to long side R (float gray path of the device, channels = 4), keypoints mapped back by `(k + .5) / scales - .5`, matching
-    with the ORIGINAL image sizes. Against the oracle run on the same resized float images (the kornia resize itself is a
+    to long side R (float gray path of the device, channels = 4), keypoints mapped by `(k + .5) / scales - .5` with the scales of
+    the reference's SECOND preprocessor call ([1, 1] here: the keypoints stay in the resized frame, `superpoint.py:224-227`),
+    matching with the ORIGINAL image sizes. Against the oracle run on the same resized float images (the kornia resize itself is a
     restatement, parity unpinned)."""
     from icepy4d_amd.matching import LightGlueMatcher
     from icepy4d_amd.matching.matchers import _resized_gray
@@ -976,4 +952,4 @@ def test_resize_option_of_extract():
         out = o.lightglue(feats[0], feats[1], lg_sd)
     assert_same_matches(f0.keypoints, f1.keypoints, matches0, feats[0]["keypoints"].numpy(), feats[1]["keypoints"].numpy(),
                         out["matches0"].numpy(), feats[0]["keypoint_scores"].numpy(), feats[1]["keypoint_scores"].numpy())
-    assert f0.keypoints[:, 0].max() > 200 and (matches0 > -1).sum() > 10       # keypoints live in the original 304 x 200 frame
+    assert f0.keypoints[:, 0].max() < 200 and sc.tolist() == [1.0, 1.0] and (matches0 > -1).sum() > 10   # the resized 200 x 131 frame

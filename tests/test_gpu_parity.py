@@ -35,7 +35,7 @@ def eng():
 
 def assert_exact_or_explained(rep):
     for im in rep["images"]:
-        assert im["score_map_max_abs_err"] < 1e-5, im
+        assert im["score_map_max_abs_err"] < parity_report.ERR_BOUND and im["eps"] <= parity_report.EPS_CAP, im
         assert im["integer_stages_exact_on_device_map"], "integer stages differ from the oracle on the device's own score map"
         assert im["unexplained"] == [], f"keypoints without an explaining oracle margin: {im['unexplained']}"
         assert im["ranks_moved_unexplained"] == [], im["ranks_moved_unexplained"]
@@ -45,23 +45,41 @@ def assert_exact_or_explained(rep):
     assert c["unexplained"] == [], f"match indices without an explaining arg-max / threshold margin: {c['unexplained']}"
     assert c["stop_device"] == c["stop_oracle"] and c["prune0_equal"] and c["prune1_equal"], c
     assert c["mscore_max_abs_err"] < 1e-4, c
-    if all(im["keypoint_set_diff"] == 0 for im in rep["images"]) and c["matches0_diff"] == 0:
-        assert rep["end_to_end"]["identical"], rep["end_to_end"]   # same keypoints, same decisions => same matched pairs
+    flips = sum(im["keypoint_set_diff"] for im in rep["images"])
+    e2e = rep["end_to_end"]
+    if flips == 0 and c["matches0_diff"] == 0:
+        assert e2e["identical"], e2e                               # same keypoints, same decisions => same matched pairs
+    else:
+        # a keypoint flipped at a margin below the float error changes every descriptor a little through attention, so no margin
+        # applies to the matches; but the damage must stay local: at most a few matched pairs per flipped keypoint
+        assert e2e["pairs_common"] >= e2e["pairs_oracle"] - 4 * max(flips, 1), e2e
+        assert e2e["pairs_device"] <= e2e["pairs_oracle"] + 4 * max(flips, 1), e2e
+
+
+@pytest.fixture(params=["winograd", "direct"])
+def conv_form(request, monkeypatch):
+    """Both forms of the 3x3 convolutions stay under the same parity bar: Winograd F(2x2, 3x3) (the default) and the direct
+    implicit GEMM (`IM_CONV_DIRECT=1`, read by the library at every SuperPoint call)."""
+    if request.param == "direct":
+        monkeypatch.setenv("IM_CONV_DIRECT", "1")
+    else:
+        monkeypatch.delenv("IM_CONV_DIRECT", raising=False)
+    return request.param
 
 
 @pytest.mark.parametrize("name", ["g1_superpoint_a", "g1_superpoint_b"])
-def test_small_goldens_exact_or_explained(eng, name):
+def test_small_goldens_exact_or_explained(eng, name, conv_form):
     g = load_golden(name)
     rep = parity_report.run_case(eng, g["image"], g["image"], SP_SD, LG_SD, min(int(g["max_k"]), 512))
     assert_exact_or_explained(rep)
 
 
-def test_wrapper_pair_exact_or_explained(eng):
+def test_wrapper_pair_exact_or_explained(eng, conv_form):
     g = load_golden("g4_wrappers")
     assert_exact_or_explained(parity_report.run_case(eng, g["image0"], g["image1"], SP_SD, LG_SD, 256))
 
 
-def test_config1_assets_pair_vs_reference_golden(eng):
+def test_config1_assets_pair_vs_reference_golden(eng, conv_form):
     """BASELINE configs[0] / north_star "match-index parity on assets/img": the two asset images (decoded pixels committed in
     g5_assets.npz), 2048 keypoints, through the HIP path, against the outputs of the REFERENCE modules (keypoints, matches0,
     stop, prune0/1 in the golden) and against the oracle with margins."""
@@ -90,7 +108,7 @@ def test_config1_assets_pair_vs_reference_golden(eng):
 
 
 @pytest.mark.parametrize("kind", ["translated", "stereo"])
-def test_config2_full_size_exact_or_explained(eng, kind):
+def test_config2_full_size_exact_or_explained(eng, kind, conv_form):
     """BASELINE configs[1]: 1080 x 1920, 4096 keypoints; the translated pair has ~1000 matches, the bench's stereo pair ~16."""
     if kind == "translated":
         a, b = synthetic.translated_pair(0, 1080, 1920, 40, 8)

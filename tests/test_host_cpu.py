@@ -114,6 +114,13 @@ def test_pyramid():
     z[::2, ::2] = d
     ref_up = (ndimage.correlate(z, k2, mode="constant") + 32) >> 6
     assert np.array_equal(pyr_up(d)[2:-2, 2:-2], np.clip(ref_up, 0, 255)[2:-2, 2:-2].astype(np.uint8))
+    # border rule of OpenCV's `pyrUp_` (recalled from its source; cv2 is absent, so this pins the CHOSEN rule, not a cv2 build):
+    # before the first sample reflect-101 (6 cur + 2 next), after the last one the last one itself (prev + 7 cur, 8 cur)
+    u, dd = pyr_up(d).astype(np.int64), d.astype(np.int64)
+    assert u[-1, -1] == dd[-1, -1]
+    assert u[-2, -1] == ((dd[-2, -1] + 7 * dd[-1, -1]) * 8 + 32) >> 6
+    assert u[-1, -2] == ((dd[-1, -2] + 7 * dd[-1, -1]) * 8 + 32) >> 6
+    assert u[0, 0] == ((6 * dd[0, 0] + 2 * dd[1, 0]) * 6 + 2 * (6 * dd[0, 1] + 2 * dd[1, 1]) + 32) >> 6
 
 
 def test_geometric_verification():
@@ -346,6 +353,17 @@ def test_bench_gpus2_as_typed_spawns_its_ranks_dry_run():
     assert d["n_gpus"] == 2 and d["steps"] == 5 and d["warmup"] == 2 and d["dry_run"] is True and d["scaling"] == "weak"
     for k in ("metric", "value", "unit", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
+    # the N > 1 line is self-verifying: who took part, with how many pairs each, and what the gathered table holds
+    rk = d["ranks"]
+    assert rk["world"] == 2 and rk["backend"] == "gloo" and rk["pairs_per_rank"] == [5, 5] and len(rk["per_rank_pairs_per_s"]) == 2
+    assert rk["epochs_in_gathered_table"] == 10 and rk["epochs_complete_and_sorted"] is True and len(rk["all_gather_ms"]) == 2
+    assert rk["record_bytes"] == 4 * (8 + 2 * 4096) and rk["gathered_table_bytes"] == 10 * rk["record_bytes"]
+    # config 4: the 98 KB records with the keypoints of both images, sharded over the ranks
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "4", "--steps", "3", "--warmup", "1", "--dry-run"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d4 = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert d4["ranks"]["record_bytes"] == 4 * (8 + 6 * 4096) == 98336 and d4["ranks"]["epochs_complete_and_sorted"] is True
     # a mismatch between --gpus and the launcher's world size is an error, not a silent single-rank run
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"],
                        env=dict(env, WORLD_SIZE="1", RANK="0"), capture_output=True, text=True, timeout=120)
@@ -554,3 +572,36 @@ def test_five_point_solver_known_answers():
         Re, te, inl = sfm.estimate_pose(x0, x1, K, K, 1.0)
         assert inl.sum() == n - int(outlier) and (not outlier or not inl[2])
         assert np.abs(Re - R).max() < 2e-2 and np.abs(te / np.linalg.norm(te) - t / np.linalg.norm(t)).max() < 5e-2
+
+
+def test_engine_reserve_failure_forgets_the_stale_workspace():
+    """A failed workspace growth (out of device memory inside `im_ctx_reserve`, which has released the old workspace by then)
+    must not leave the Python side with the old sizes: the next reserve() has to reach the library again, and graphs captured
+    against the released buffers must be dropped (engines are shared by every matcher object with equal weights)."""
+    from icepy4d_amd.engine import Engine
+
+    class FakeCtx:
+        def __init__(self):
+            self.calls, self.fail_next = [], False
+
+        def call(self, name, *a):
+            self.calls.append((name, a))
+            if self.fail_next:
+                self.fail_next = False
+                raise RuntimeError("im_ctx_reserve: out of device memory (-31)")
+
+    e = object.__new__(Engine)
+    e.device = torch.device("cpu")
+    e.ctx = FakeCtx()
+    e.max_h = e.max_w = e.max_images = e.max_kpts = 0
+    e.generation, e._loaded, e.graphs = 0, {}, {}
+    e.reserve(64, 64, 2, 128)
+    assert (e.max_h, e.max_kpts) == (64, 128) and len(e.ctx.calls) == 1
+    e.graphs["k"] = object()
+    gen = e.generation
+    e.ctx.fail_next = True
+    with pytest.raises(RuntimeError, match="out of device memory"):
+        e.reserve(64, 64, 2, 1 << 14)
+    assert (e.max_h, e.max_w, e.max_images, e.max_kpts) == (0, 0, 0, 0) and e.graphs == {} and e.generation > gen
+    e.reserve(32, 32, 2, 64)                        # smaller than the stale sizes: must still call the library
+    assert len(e.ctx.calls) == 3 and e.ctx.calls[-1][1] == (32, 32, 2, 64) and e.max_kpts == 64

@@ -36,16 +36,6 @@ def main():
                 ms = timeit(lambda: ctx.call("im_flash_attn", ptr(q), ptr(k), ptr(v), ptr(out), ptr(dn), n, 2, 4, cross, 0.125, stream_ptr()))
                 fl = 2 * 4 * 4.0 * n * n * 64
                 print(f"attn n={n} cross={cross}: {ms:.4f} ms  {fl / ms / 1e9:.1f} TFLOP/s (executed)  {fl / ms / 1e9 / 157.3 * 100:.1f}% of fp32 MFMA peak", flush=True)
-    if "attn3" in which:  # the bf16 x 3 experiment (attention kernel alone: planes split once, reused)
-        for n in (4096, 2048):
-            q = torch.randn(2, 4, n, 64, device="cuda"); k = torch.randn_like(q); v = torch.randn_like(q)
-            out = torch.empty(2, n, 256, device="cuda")
-            dn = torch.tensor([n, n], dtype=torch.int32, device="cuda")
-            ctx.call("im_flash_attn_bf16x3", ptr(q), ptr(k), ptr(v), ptr(out), ptr(dn), n, 2, 4, 1, 0.125, 1, stream_ptr())
-            for resplit in (0, 1):
-                ms = timeit(lambda: ctx.call("im_flash_attn_bf16x3", ptr(q), ptr(k), ptr(v), ptr(out), ptr(dn), n, 2, 4, 1, 0.125, resplit, stream_ptr()))
-                fl = 2 * 4 * 4.0 * n * n * 64
-                print(f"attn bf16x3 n={n} cross=1 resplit={resplit}: {ms:.4f} ms  {fl / ms / 1e9:.1f} TFLOP/s fp32-equivalent (executed)", flush=True)
     if "attn" in which:   # pruned pairs: the buffers are sized for 4096 keypoints, fewer are live (decided on the device)
         nmax = 4096
         q = torch.randn(2, 4, nmax, 64, device="cuda"); k = torch.randn_like(q); v = torch.randn_like(q)
