@@ -64,8 +64,9 @@ def main():
                 buf = ctypes.create_string_buffer(4096)
                 ctx.call("im_profile_end", buf, len(buf))
                 prof = json.loads(buf.value.decode())
+                cal = prof.pop("_empty_event_pair", None)
                 v = next(iter(prof.values()))
-                ms = v["total_ms"] / v["count"]
+                ms = v["total_ms"] / v["count"] - (cal["total_ms"] / cal["count"] if cal else 0.0)
                 line += f"  {name[3:]} {ms:.3f} ms ({fl / ms / 1e9:.0f} TFLOP/s alg.)"
             print(line, flush=True)
     if "gemm" in which:
