@@ -64,6 +64,8 @@ SIGNATURES = {
     "im_merge_tile_matches": [_P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "im_gather_rows": [_P, _P, _I, _P, _I, _P, _P],
     "im_ransac_fundamental": [_P, _P, _P, _I, _I, C.c_double, C.c_uint, _P, _P, _P, _P],
+    "im_ransac_essential": [_P, _P, _P, _I, _I, C.c_double, C.c_uint, _P, _P, _P, _P],
+    "im_triangulate_linear": [_P, _P, _P, _P, _P, _I, _P, _P],
 }
 
 

@@ -55,6 +55,59 @@ __device__ void smallest_eigvec3(double a[3][3], double v[3]) {
     for (int k = 0; k < 3; ++k) v[k] = q[k][m];
 }
 
+// symmetric N x N eigen-decomposition by cyclic Jacobi: on return a is (numerically) diagonal, the columns of q are eigenvectors
+template <int N>
+__device__ void jacobi_sym(double a[N][N], double q[N][N]) {
+    for (int i = 0; i < N; ++i)
+        for (int j = 0; j < N; ++j) q[i][j] = i == j ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 16; ++sweep) {
+        double off = 0.0;
+        for (int p = 0; p < N - 1; ++p)
+            for (int r = p + 1; r < N; ++r) off += fabs(a[p][r]);
+        if (off < 1e-300) break;
+        for (int p = 0; p < N - 1; ++p)
+            for (int r = p + 1; r < N; ++r) {
+                if (fabs(a[p][r]) < 1e-300) continue;
+                const double theta = (a[r][r] - a[p][p]) / (2.0 * a[p][r]);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < N; ++k) { const double akp = a[k][p], akr = a[k][r]; a[k][p] = c * akp - s * akr; a[k][r] = s * akp + c * akr; }
+                for (int k = 0; k < N; ++k) { const double apk = a[p][k], ark = a[r][k]; a[p][k] = c * apk - s * ark; a[r][k] = s * apk + c * ark; }
+                for (int k = 0; k < N; ++k) { const double qkp = q[k][p], qkr = q[k][r]; q[k][p] = c * qkp - s * qkr; q[k][r] = s * qkp + c * qkr; }
+            }
+    }
+}
+
+// Projection of a 3 x 3 matrix onto the essential manifold (two equal singular values, the third zero): with F = U diag(s) V^T,
+// E = U diag(m, m, 0) V^T, m = (s1 + s2) / 2 - written as E = F V diag(m / s1, m / s2, 0) V^T from the eigen-decomposition of
+// F^T F (what `cv2.findEssentialMat` guarantees of its result, `sfm/geometry.py:64-66`). Returns false for a rank < 2 input.
+__device__ bool project_essential(double F[9]) {
+    double M[3][3], V[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) M[i][j] = F[i] * F[j] + F[3 + i] * F[3 + j] + F[6 + i] * F[6 + j];
+    jacobi_sym<3>(M, V);
+    int o[3] = {0, 1, 2};                                  // eigenvalues in descending order
+    for (int i = 0; i < 2; ++i)
+        for (int j = i + 1; j < 3; ++j)
+            if (M[o[j]][o[j]] > M[o[i]][o[i]]) { const int t = o[i]; o[i] = o[j]; o[j] = t; }
+    const double s1 = sqrt(fmax(M[o[0]][o[0]], 0.0)), s2 = sqrt(fmax(M[o[1]][o[1]], 0.0));
+    if (!(s2 > 1e-12 * s1) || !(s1 > 0.0)) return false;
+    const double m = 0.5 * (s1 + s2), d1 = m / s1, d2 = m / s2;
+    double D[3][3];                                        // V diag(d1, d2, 0) V^T
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) D[i][j] = d1 * V[i][o[0]] * V[j][o[0]] + d2 * V[i][o[1]] * V[j][o[1]];
+    double E[9], nrm = 0.0;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            E[3 * i + j] = F[3 * i] * D[0][j] + F[3 * i + 1] * D[1][j] + F[3 * i + 2] * D[2][j];
+            nrm += E[3 * i + j] * E[3 * i + j];
+        }
+    nrm = sqrt(nrm);
+    if (!(nrm > 1e-300)) return false;
+    for (int j = 0; j < 9; ++j) F[j] = E[j] / nrm;
+    return true;
+}
+
 __device__ __forceinline__ bool sampson_inlier(const double F[9], double x0, double y0, double x1, double y1, double thr2) {
     const double fx0 = F[0] * x0 + F[1] * y0 + F[2], fx1 = F[3] * x0 + F[4] * y0 + F[5], fx2 = F[6] * x0 + F[7] * y0 + F[8];
     const double ft0 = F[0] * x1 + F[3] * y1 + F[6], ft1 = F[1] * x1 + F[4] * y1 + F[7];
@@ -139,7 +192,8 @@ __device__ bool eight_point(const float* __restrict__ p0, const float* __restric
 }
 
 __global__ __launch_bounds__(64) void ransac_hypotheses_kernel(const float* __restrict__ p0, const float* __restrict__ p1, int n, int n_hyp,
-                                                               uint32_t seed, double thr2, int* __restrict__ counts, double* __restrict__ Fs) {
+                                                               uint32_t seed, double thr2, int* __restrict__ counts, double* __restrict__ Fs,
+                                                               int essential) {
     const int h = blockIdx.x * 64 + threadIdx.x;
     if (h >= n_hyp) return;
     int idx[8];
@@ -154,7 +208,7 @@ __global__ __launch_bounds__(64) void ransac_hypotheses_kernel(const float* __re
     }
     double F[9];
     int cnt = 0;
-    if (eight_point(p0, p1, idx, F)) {
+    if (eight_point(p0, p1, idx, F) && (!essential || project_essential(F))) {
         for (int i = 0; i < n; ++i) cnt += sampson_inlier(F, p0[2 * i], p0[2 * i + 1], p1[2 * i], p1[2 * i + 1], thr2) ? 1 : 0;
     } else {
         for (int j = 0; j < 9; ++j) F[j] = 0.0;
@@ -191,26 +245,81 @@ __global__ __launch_bounds__(1024) void ransac_select_kernel(const float* __rest
         mask[i] = sampson_inlier(F, p0[2 * i], p0[2 * i + 1], p1[2 * i], p1[2 * i + 1], thr2) ? 1 : 0;
 }
 
-}  // namespace im
-
-using namespace im;
-
-extern "C" int im_ransac_fundamental(im_ctx* ctx, const float* d_p0, const float* d_p1, int n, int n_hyp, double threshold,
-                                     unsigned int seed, double* d_F, uint8_t* d_mask, int32_t* d_info, void* stream) {
+static int ransac_entry(im_ctx* ctx, const char* who, int essential, const float* d_p0, const float* d_p1, int n, int n_hyp, double threshold,
+                        unsigned int seed, double* d_F, uint8_t* d_mask, int32_t* d_info, void* stream) {
     IM_CHECK_CTX(ctx);
-    if (n < 8 || n_hyp < 1) return ctx->fail(-70, "im_ransac_fundamental: needs >= 8 correspondences and >= 1 hypothesis");
+    if (n < 8 || n_hyp < 1) return ctx->fail(-70, "%s: needs >= 8 correspondences and >= 1 hypothesis", who);
     hipStream_t s = (hipStream_t)stream;
     int* counts = nullptr;
     double* Fs = nullptr;
     IM_HIP(ctx, hipMallocAsync((void**)&counts, sizeof(int) * n_hyp, s));
     IM_HIP(ctx, hipMallocAsync((void**)&Fs, sizeof(double) * 9 * n_hyp, s));
     hipLaunchKernelGGL(ransac_hypotheses_kernel, dim3((n_hyp + 63) / 64), dim3(64), 0, s, d_p0, d_p1, n, n_hyp, seed,
-                       threshold * threshold, counts, Fs);
+                       threshold * threshold, counts, Fs, essential);
     hipLaunchKernelGGL(ransac_select_kernel, dim3(1), dim3(1024), 0, s, d_p0, d_p1, n, n_hyp, threshold * threshold, counts, Fs, d_F,
                        d_mask, d_info);
     hipError_t e = hipGetLastError();
     hipFreeAsync(counts, s);
     hipFreeAsync(Fs, s);
+    IM_HIP(ctx, e);
+    return 0;
+}
+
+// linear (DLT) two-view triangulation, one thread per point (`sfm/triangulation.py:153-163`): the four rows x (P X) = 0 of the two
+// views, X = the eigenvector of the smallest eigenvalue of A^T A (fp64 Jacobi), normalised to X[3] = 1
+__global__ __launch_bounds__(64) void triangulate_linear_kernel(const double* __restrict__ P, const double* __restrict__ x0,
+                                                                const double* __restrict__ x1, int n, double* __restrict__ X) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    double A[4][4];
+    for (int v = 0; v < 2; ++v) {
+        const double* p = P + 12 * v;
+        const double* x = (v == 0 ? x0 : x1) + 3 * (long)i;
+        for (int j = 0; j < 4; ++j) {
+            A[2 * v][j] = x[0] * p[8 + j] - x[2] * p[j];
+            A[2 * v + 1][j] = x[1] * p[8 + j] - x[2] * p[4 + j];
+        }
+    }
+    double M[4][4], Q[4][4];
+    for (int a = 0; a < 4; ++a)
+        for (int b = 0; b < 4; ++b) M[a][b] = A[0][a] * A[0][b] + A[1][a] * A[1][b] + A[2][a] * A[2][b] + A[3][a] * A[3][b];
+    jacobi_sym<4>(M, Q);
+    int m = 0;
+    for (int k = 1; k < 4; ++k)
+        if (M[k][k] < M[m][m]) m = k;
+    const double w = Q[3][m];
+    for (int k = 0; k < 4; ++k) X[4 * (long)i + k] = Q[k][m] / w;
+}
+
+}  // namespace im
+
+using namespace im;
+
+extern "C" int im_ransac_fundamental(im_ctx* ctx, const float* d_p0, const float* d_p1, int n, int n_hyp, double threshold,
+                                     unsigned int seed, double* d_F, uint8_t* d_mask, int32_t* d_info, void* stream) {
+    return ransac_entry(ctx, "im_ransac_fundamental", 0, d_p0, d_p1, n, n_hyp, threshold, seed, d_F, d_mask, d_info, stream);
+}
+
+extern "C" int im_ransac_essential(im_ctx* ctx, const float* d_x0, const float* d_x1, int n, int n_hyp, double threshold,
+                                   unsigned int seed, double* d_E, uint8_t* d_mask, int32_t* d_info, void* stream) {
+    return ransac_entry(ctx, "im_ransac_essential", 1, d_x0, d_x1, n, n_hyp, threshold, seed, d_E, d_mask, d_info, stream);
+}
+
+extern "C" int im_triangulate_linear(im_ctx* ctx, const double* h_P0, const double* h_P1, const double* d_x0, const double* d_x1, int n,
+                                     double* d_X, void* stream) {
+    IM_CHECK_CTX(ctx);
+    if (!h_P0 || !h_P1 || !d_x0 || !d_x1 || !d_X || n < 0) return ctx->fail(-71, "im_triangulate_linear: null argument");
+    if (n == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    double hP[24];
+    for (int j = 0; j < 12; ++j) { hP[j] = h_P0[j]; hP[12 + j] = h_P1[j]; }
+    double* dP = nullptr;
+    IM_HIP(ctx, hipMallocAsync((void**)&dP, sizeof(hP), s));
+    IM_HIP(ctx, hipMemcpyAsync(dP, hP, sizeof(hP), hipMemcpyHostToDevice, s));
+    IM_HIP(ctx, hipStreamSynchronize(s));     // hP lives on this stack frame
+    hipLaunchKernelGGL(triangulate_linear_kernel, dim3((n + 63) / 64), dim3(64), 0, s, dP, d_x0, d_x1, n, d_X);
+    hipError_t e = hipGetLastError();
+    hipFreeAsync(dP, s);
     IM_HIP(ctx, e);
     return 0;
 }

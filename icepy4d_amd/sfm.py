@@ -4,7 +4,9 @@ linear triangulation (`src/icepy4d/sfm/geometry.py:31-76`, `sfm/two_view_geometr
 parity of `estimate_pose` is unpinned (same interface, same conventions, checked on synthetic geometry); the linear
 triangulation is pure numpy in the reference and is reproduced to rounding (tests compare against a restatement of its
 formulation). Small host-side linear algebra on S <= 1e4 matched points: not a device workload; the RANSAC inside
-`estimate_pose` uses the device hypothesis scorer of `geometric_verification` (pass `engine=`)."""
+`estimate_pose(engine=...)` generates and scores essential-matrix hypotheses on the device (`im_ransac_essential`, csrc/geometry.hip)
+and `triangulate_points_linear(engine=...)` triangulates on the device (`im_triangulate_linear`); the cheirality test and the 5-7
+match case (five-point solver on every 5-subset) stay host numpy: one 3 x 3 matrix."""
 from typing import Optional, Tuple
 
 import numpy as np
@@ -29,13 +31,24 @@ def triangulate_nviews(P, ip) -> np.ndarray:
     return X / X[3]
 
 
-def triangulate_points_linear(P1, P2, x1, x2) -> np.ndarray:
+def triangulate_points_linear(P1, P2, x1, x2, engine=None) -> np.ndarray:
     """Two-view triangulation of n points (`triangulation.py:153-163`); x1, x2 are [n, 3] homogeneous image points.
-    Vectorised DLT: one batched 4x4 SVD instead of the reference's Python loop over an (6 x 6) system per point."""
+    Vectorised DLT: one batched 4x4 SVD instead of the reference's Python loop over an (6 x 6) system per point. With
+    `engine=` the points are triangulated on the device (`im_triangulate_linear`: one thread per point, fp64 Jacobi on A^T A)."""
     x1, x2 = np.asarray(x1, np.float64), np.asarray(x2, np.float64)
     if len(x1) != len(x2):
         raise ValueError("Number of points don't match.")
     P1, P2 = np.asarray(P1, np.float64), np.asarray(P2, np.float64)
+    if engine is not None:
+        import torch
+        from ._lib import ptr, stream_ptr
+        n = len(x1)
+        d1 = torch.from_numpy(np.ascontiguousarray(x1)).to(engine.device)
+        d2 = torch.from_numpy(np.ascontiguousarray(x2)).to(engine.device)
+        dX = torch.empty((n, 4), dtype=torch.float64, device=engine.device)
+        p1, p2 = np.ascontiguousarray(P1.reshape(12)), np.ascontiguousarray(P2.reshape(12))
+        engine.ctx.call("im_triangulate_linear", p1.ctypes.data, p2.ctypes.data, ptr(d1), ptr(d2), n, ptr(dX), stream_ptr())
+        return dX.cpu().numpy()
     A = np.stack([x1[:, 0:1] * P1[2] - x1[:, 2:3] * P1[0], x1[:, 1:2] * P1[2] - x1[:, 2:3] * P1[1],
                   x2[:, 0:1] * P2[2] - x2[:, 2:3] * P2[0], x2[:, 1:2] * P2[2] - x2[:, 2:3] * P2[1]], axis=1)   # [n, 4, 4]
     X = np.linalg.svd(A)[2][:, -1, :]
@@ -139,6 +152,42 @@ def _essential_from_fundamental(F: np.ndarray) -> np.ndarray:
     return u @ np.diag([1.0, 1.0, 0.0]) @ vt
 
 
+def _essential_ransac_on_device(engine, x0: np.ndarray, x1: np.ndarray, threshold: float, confidence: float, seed: int,
+                                max_iters: int = 10000):
+    """RANSAC over essential-matrix hypotheses generated and scored on the device (`im_ransac_essential`), in batches of 1024
+    until the confidence criterion holds for the best inlier ratio; then one refit on the inliers of the winner (8-point on all
+    of them, projected onto the essential manifold) that is kept if it does not lose inliers. Returns (E, inlier mask)."""
+    import torch
+    from ._lib import ptr, stream_ptr
+    from .matching.geometric_verification import DEVICE_BATCH, _eight_point, _needed, _sampson
+    dev = engine.device
+    d0 = torch.from_numpy(np.ascontiguousarray(x0, dtype=np.float32)).to(dev)
+    d1 = torch.from_numpy(np.ascontiguousarray(x1, dtype=np.float32)).to(dev)
+    n = len(x0)
+    dE = torch.empty(9, dtype=torch.float64, device=dev)
+    dmask = torch.empty(n, dtype=torch.uint8, device=dev)
+    dinfo = torch.empty(2, dtype=torch.int32, device=dev)
+    best = (0, None, None)
+    done, needed = 0, int(max_iters)
+    while done < min(needed, int(max_iters)):
+        engine.ctx.call("im_ransac_essential", ptr(d0), ptr(d1), n, DEVICE_BATCH, float(threshold), (int(seed) + done) & 0xFFFFFFFF,
+                        ptr(dE), ptr(dmask), ptr(dinfo), stream_ptr())
+        done += DEVICE_BATCH
+        cnt = int(dinfo[0].item())
+        if cnt > best[0]:
+            best = (cnt, dE.cpu().numpy().reshape(3, 3).copy(), dmask.cpu().numpy().astype(bool))
+        needed = _needed(confidence, best[0] / n)
+    if best[1] is None:
+        return None, np.zeros(n, bool)
+    cnt, E, mask = best
+    if cnt >= 8:
+        E2 = _essential_from_fundamental(_eight_point(x0[mask], x1[mask]))
+        m2 = _sampson(E2, x0, x1) < threshold ** 2
+        if int(m2.sum()) >= cnt:
+            E, mask = E2 / np.linalg.norm(E2), m2
+    return E, mask
+
+
 def _recover_pose(E: np.ndarray, x0: np.ndarray, x1: np.ndarray, mask: np.ndarray):
     """The (R, t) of the four decompositions of E that puts most inliers in front of both cameras (what
     cv2.recoverPose does); x0, x1 are normalised image coordinates [n, 2]."""
@@ -167,8 +216,9 @@ def estimate_pose(kpts0: np.ndarray, kpts1: np.ndarray, K0: np.ndarray, K1: np.n
     """`estimate_pose` of the reference (`sfm/geometry.py:31-76`): (R [3,3], t [3], inliers [n] bool) with
     x_cam1 = R x_cam0 + t, t up to scale; None with fewer than 5 matches. The reference runs cv2.findEssentialMat (5-point
     RANSAC) + cv2.recoverPose; here, with 8 or more matches, the epipolar geometry of the NORMALISED coordinates is estimated by
-    the 8-point RANSAC of `geometric_verification` (hypotheses scored on the device: `engine` is required), projected onto the essential manifold
-    and decomposed with the cheirality test; with 5-7 matches the five-point solver (`essential_five_point`) runs on every
+    an 8-point RANSAC whose hypotheses are projected onto the essential manifold and scored ON THE DEVICE (`engine=...`:
+    `im_ransac_essential`; with a `hypothesis_fn` test seam instead: the F-matrix RANSAC of `geometric_verification`, projected
+    afterwards) and decomposed with the cheirality test; with 5-7 matches the five-point solver (`essential_five_point`) runs on every
     5-subset."""
     if len(kpts0) < 5:
         return None
@@ -180,11 +230,17 @@ def estimate_pose(kpts0: np.ndarray, kpts1: np.ndarray, K0: np.ndarray, K1: np.n
     if len(x0) < 8:
         # fewer matches than the 8-point hypotheses of the RANSAC below need: the five-point solver on every 5-subset
         return _estimate_pose_few(x0, x1, norm_thresh ** 2)
-    F, mask = geometric_verification(x0.astype(np.float32), x1.astype(np.float32), GeometricVerification.PYDEGENSAC,
-                                     threshold=norm_thresh, confidence=conf, seed=seed, engine=engine, hypothesis_fn=hypothesis_fn)
-    if F is None:
-        raise AssertionError("Unable to estimate Essential matrix")
-    E = _essential_from_fundamental(F)
+    if engine is not None and hypothesis_fn is None:
+        # device path: essential-matrix hypotheses (8-point, projected onto the essential manifold) generated and scored on the GPU
+        E, mask = _essential_ransac_on_device(engine, x0, x1, norm_thresh, conf, seed)
+        if E is None:
+            raise AssertionError("Unable to estimate Essential matrix")
+    else:
+        F, mask = geometric_verification(x0.astype(np.float32), x1.astype(np.float32), GeometricVerification.PYDEGENSAC,
+                                         threshold=norm_thresh, confidence=conf, seed=seed, engine=engine, hypothesis_fn=hypothesis_fn)
+        if F is None:
+            raise AssertionError("Unable to estimate Essential matrix")
+        E = _essential_from_fundamental(F)
     n_front, R, t, front = _recover_pose(E, x0, x1, mask)
     inliers = mask.copy()
     inliers[np.flatnonzero(mask)[~front]] = False

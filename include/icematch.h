@@ -196,6 +196,20 @@ int im_gather_rows(im_ctx* ctx, const float* d_src, int row_floats, const int32_
 int im_ransac_fundamental(im_ctx* ctx, const float* d_p0, const float* d_p1, int n, int n_hyp, double threshold,
                           unsigned int seed, double* d_F, uint8_t* d_mask, int32_t* d_info, void* stream);
 
+/* Relative orientation, device stage (replaces the RANSAC inside `cv2.findEssentialMat`, `src/icepy4d/sfm/geometry.py:64-66`):
+ * like im_ransac_fundamental on NORMALISED image coordinates (d_x0, d_x1 [n][2] float), every 8-point hypothesis projected onto
+ * the essential manifold (two equal singular values, one zero) before it is scored; d_E [9] double = the best hypothesis
+ * (x1^T E x0 = 0, unit Frobenius norm), d_mask / d_info as above. The cheirality test (`cv2.recoverPose`, `geometry.py:70-75`)
+ * and the 5-7 correspondence case (five-point solver) stay on the host: one 3 x 3 matrix. */
+int im_ransac_essential(im_ctx* ctx, const float* d_x0, const float* d_x1, int n, int n_hyp, double threshold,
+                        unsigned int seed, double* d_E, uint8_t* d_mask, int32_t* d_info, void* stream);
+
+/* Linear two-view triangulation of n points on the device (replaces the per-point Python loop of
+ * `src/icepy4d/sfm/triangulation.py:153-186`): h_P0, h_P1 = the two 3 x 4 projection matrices (row-major doubles in HOST
+ * memory), d_x0, d_x1 [n][3] double homogeneous image points, d_X [n][4] double = homogeneous points normalised to X[3] = 1. */
+int im_triangulate_linear(im_ctx* ctx, const double* h_P0, const double* h_P1, const double* d_x0, const double* d_x1, int n,
+                          double* d_X, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

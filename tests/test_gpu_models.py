@@ -953,3 +953,69 @@ def test_resize_option_of_extract():
     assert_same_matches(f0.keypoints, f1.keypoints, matches0, feats[0]["keypoints"].numpy(), feats[1]["keypoints"].numpy(),
                         out["matches0"].numpy(), feats[0]["keypoint_scores"].numpy(), feats[1]["keypoint_scores"].numpy())
     assert f0.keypoints[:, 0].max() < 200 and sc.tolist() == [1.0, 1.0] and (matches0 > -1).sum() > 10   # the resized 200 x 131 frame
+
+
+# ------------------------------------------------------------------------------------------- f-4: relative orientation, triangulation
+def _synthetic_two_view(seed, n, n_outliers, noise_px=0.3):
+    rng = np.random.default_rng(seed)
+    K = np.array([[1400.0, 0, 960], [0, 1400.0, 540], [0, 0, 1]])
+    X = np.c_[rng.uniform(-4, 4, n), rng.uniform(-2.5, 2.5, n), rng.uniform(6, 14, n)]
+    ang = np.deg2rad([3.0, -8.0, 1.5])
+    cx, cy, cz = np.cos(ang); sx, sy, sz = np.sin(ang)
+    R = (np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]]) @ np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+         @ np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]]))
+    t = np.array([1.0, 0.1, 0.15]); t /= np.linalg.norm(t)
+    def proj(Xc):
+        p = (K @ Xc.T).T
+        return p[:, :2] / p[:, 2:]
+    k0 = proj(X) + rng.normal(0, noise_px, (n, 2))
+    k1 = proj(X @ R.T + t) + rng.normal(0, noise_px, (n, 2))
+    k1[:n_outliers] += rng.uniform(30, 120, (n_outliers, 2)) * rng.choice([-1, 1], (n_outliers, 2))
+    return K, R, t, X, k0, k1
+
+
+def test_relative_orientation_and_triangulation_on_device():
+    """Row f-4 (`sfm/geometry.py:31-76`, `sfm/triangulation.py:153-186`) on the device path: `estimate_pose(engine=...)` runs its
+    RANSAC over essential-matrix hypotheses generated and scored on the GPU (`im_ransac_essential`), against KNOWN poses
+    (rotation within 0.2 degrees and translation direction within 1 degree with 450+ inliers at 0.3 px noise; outliers rejected) and on the reference's own two test
+    inputs (`tests/test_sfm_geometry.py:8-32`); `triangulate_points_linear(engine=...)` equals the host formulation of the
+    reference's DLT to 1e-7 and recovers the true points."""
+    from icepy4d_amd import sfm
+    from icepy4d_amd.engine import Engine
+    e = Engine(0)
+    for seed, n, n_out in ((0, 600, 150), (1, 2500, 900), (2, 40, 6)):
+        K, R, t, X, k0, k1 = _synthetic_two_view(seed, n, n_out)
+        res = sfm.estimate_pose(k0, k1, K, K, thresh=1.0, conf=0.9999, engine=e, seed=seed)
+        assert res is not None
+        Re, te, inl = res
+        ang = np.rad2deg(np.arccos(np.clip((np.trace(Re @ R.T) - 1) / 2, -1, 1)))
+        tdir = np.rad2deg(np.arccos(np.clip(te @ t / np.linalg.norm(te), -1, 1)))
+        assert ang < (0.2 if n >= 500 else 0.5) and tdir < (1.0 if n >= 500 else 2.0), (seed, ang, tdir)   # 34 inliers at 0.3 px noise: ~0.2 deg
+        assert abs(np.linalg.det(Re) - 1) < 1e-9 and np.abs(Re @ Re.T - np.eye(3)).max() < 1e-9
+        assert inl[:n_out].mean() < 0.05 and inl[n_out:].mean() > 0.9, (seed, inl[:n_out].mean(), inl[n_out:].mean())
+        # triangulation with the TRUE cameras: device == host formulation, both recover the scene points of the inliers
+        P0, P1 = K @ np.eye(3, 4), K @ np.c_[R, t]
+        h0, h1 = np.c_[k0, np.ones(n)], np.c_[k1, np.ones(n)]
+        Xd = sfm.triangulate_points_linear(P0, P1, h0, h1, engine=e)
+        Xh = sfm.triangulate_points_linear(P0, P1, h0, h1)
+        assert Xd.shape == (n, 4) and np.abs(Xd[n_out:] - Xh[n_out:]).max() < 1e-7 * np.abs(Xh[n_out:]).max()
+        assert np.median(np.linalg.norm(Xd[n_out:, :3] - X[n_out:], axis=1)) < 0.05
+    # the reference's own tests: None below five matches, a pose for five (host five-point solver: below the 8 of a device hypothesis)
+    assert sfm.estimate_pose(np.array([[0, 0], [0, 1]]), np.array([[0, 0], [0, 1]]), np.eye(3), np.eye(3), 0.5, 0.9999, engine=e) is None
+    kpts0 = np.array([[1853, 2632], [2122, 2744], [416, 2867], [1880, 2582], [2100, 2770]]).astype(np.float32)
+    kpts1 = np.array([[0, 0], [0, 1], [1, 0], [1, 1], [0.5, 0.5]])
+    res = sfm.estimate_pose(kpts0, kpts1, np.eye(3), np.eye(3), 0.5, 0.9999, engine=e)
+    assert res is not None and res[0].shape == (3, 3) and res[1].shape == (3,) and res[2].shape == (5,)
+    # exact correspondences: the device's best essential hypothesis is an essential matrix (singular values 1 : 1 : 0) that
+    # satisfies the epipolar constraint of every point
+    K, R, t, X, k0, k1 = _synthetic_two_view(3, 300, 0, noise_px=0.0)
+    x0 = (k0 - K[[0, 1], [2, 2]]) / K[[0, 1], [0, 1]]
+    x1 = (k1 - K[[0, 1], [2, 2]]) / K[[0, 1], [0, 1]]
+    E, mask = sfm._essential_ransac_on_device(e, x0, x1, 1e-4, 0.9999, 0)
+    sv = np.linalg.svd(E)[1]
+    assert mask.all() and abs(sv[0] - sv[1]) < 1e-9 * sv[0] and sv[2] < 1e-9 * sv[0]
+    tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+    Et = tx @ R
+    Et /= np.linalg.norm(Et)
+    assert min(np.abs(E - Et).max(), np.abs(E + Et).max()) < 1e-6
+    e.close()
