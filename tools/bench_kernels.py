@@ -70,7 +70,7 @@ def main():
                 line += f"  {name[3:]} {ms:.3f} ms ({fl / ms / 1e9:.0f} TFLOP/s alg.)"
             print(line, flush=True)
     if "gemm" in which:
-        for (m, n, k, big) in ((8192, 256, 256, 0), (8192, 256, 256, 1), (8192, 512, 512, 0), (8192, 512, 512, 1), (8192, 256, 512, 0), (8192, 256, 512, 1), (8192, 768, 256, 0), (8192, 768, 256, 1), (4096, 4096, 256, 1), (64800, 256, 256, 0), (64800, 256, 256, 1)):
+        for (m, n, k, big) in ((16384, 768, 256, 0), (16384, 768, 256, 1), (16384, 512, 256, 0), (16384, 512, 256, 1), (8192, 256, 256, 0), (8192, 256, 256, 1), (8192, 512, 512, 0), (8192, 512, 512, 1), (8192, 256, 512, 0), (8192, 256, 512, 1), (8192, 768, 256, 0), (8192, 768, 256, 1), (4096, 4096, 256, 1), (64800, 256, 256, 0), (64800, 256, 256, 1)):
             a = torch.randn(m, k, device="cuda"); w = torch.randn(n, k, device="cuda"); b = torch.randn(n, device="cuda")
             c = torch.empty(m, n, device="cuda")
             ms = timeit(lambda: ctx.call("im_gemm_nt", ptr(a), ptr(w), ptr(b), ptr(c), m, n, k, 1.0, big, stream_ptr()))
