@@ -50,17 +50,19 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t wmake_rsrc(const void* base, u
     void* p = reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo);
     return __builtin_amdgcn_make_buffer_rsrc(p, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
 }
-// packed fp32 on float4 halves (the compiler scalarises float4 arithmetic)
+// packed fp32 on float4 halves: two-element vector arithmetic, which the compiler lowers to v_pk_add_f32 (plain float4 arithmetic
+// is scalarised). NOT inline asm: round 3 found that `asm("v_pk_add_f32 ...")` next to the MFMAs gives wrong results as soon as
+// the register allocation changes (any reordering of the slab step that keeps the U fragments live across the stage; the same
+// source with these compiler-visible adds is correct, tools/conv_reorder_test.py) - the hazard recogniser cannot see into an asm
+// statement, so a VALU write that an MFMA reads too early goes unprotected.
 __device__ __forceinline__ float4 add4(float4 x, float4 y) {
-    f32x2 a = {x.x, x.y}, b = {x.z, x.w}, c = {y.x, y.y}, d = {y.z, y.w}, r0, r1;
-    asm("v_pk_add_f32 %0, %1, %2" : "=v"(r0) : "v"(a), "v"(c));
-    asm("v_pk_add_f32 %0, %1, %2" : "=v"(r1) : "v"(b), "v"(d));
+    const f32x2 a = {x.x, x.y}, b = {x.z, x.w}, c = {y.x, y.y}, d = {y.z, y.w};
+    const f32x2 r0 = a + c, r1 = b + d;
     return make_float4(r0.x, r0.y, r1.x, r1.y);
 }
 __device__ __forceinline__ float4 sub4(float4 x, float4 y) {
-    f32x2 a = {x.x, x.y}, b = {x.z, x.w}, c = {y.x, y.y}, d = {y.z, y.w}, r0, r1;
-    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r0) : "v"(a), "v"(c));
-    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r1) : "v"(b), "v"(d));
+    const f32x2 a = {x.x, x.y}, b = {x.z, x.w}, c = {y.x, y.y}, d = {y.z, y.w};
+    const f32x2 r0 = a - c, r1 = b - d;
     return make_float4(r0.x, r0.y, r1.x, r1.y);
 }
 
