@@ -1,8 +1,8 @@
 #!/bin/bash
 # Runs the measurement passes behind profiles/ on the GPU box (one gpurun call):
-#   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh r02'
+#   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh r03'
 # rocprofv3 wants cwd=/tmp and TMPDIR=/tmp on this pool; PMC passes are separate runs with --kernel-trace only.
-tag=${1:-r02}
+tag=${1:-r03}
 root=${GRAFT_REPO_ROOT:-/root/repo}
 out=$root/gpurun_out/$tag
 mkdir -p $out
@@ -13,6 +13,12 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats1 -- python3 $
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_default -- python3 $root/bench.py --no-cpu-baseline --no-side-measurements > $out/bench_default_under_rocprof.json 2> /dev/null
 python3 $root/bench.py --config 5 > $out/bench_config5.json 2> $out/bench_config5.err
 python3 $root/bench.py --config 3 --no-cpu-baseline > $out/bench_config3.json 2> $out/bench_config3.err
+# config 4 rehearsed on the one GPU of this box: (a) 256 of its 2048 epochs on one rank (98 KB records with keypoints);
+# (b) the same through torch.distributed.run with ONE rank and the nccl backend forced (RCCL init, all-gather, `ranks` object);
+# (c) two ranks sharing cuda:0 over gloo (IM_BENCH_ONE_DEVICE=1): the N > 1 code path end to end with real GPU work
+python3 $root/bench.py --config 4 --steps 256 --no-cpu-baseline --no-side-measurements > $out/bench_config4_1gpu_256epochs.json 2> $out/bench_config4.err
+IM_BENCH_FORCE_DIST=1 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 $root/bench.py --gpus 1 --config 4 --steps 64 --no-cpu-baseline --no-side-measurements > $out/bench_config4_nccl_world1.json 2> $out/bench_config4_nccl.err
+IM_BENCH_ONE_DEVICE=1 python3 $root/bench.py --gpus 2 --steps 24 --warmup 4 --no-cpu-baseline --no-side-measurements > $out/bench_2ranks_one_device_gloo.json 2> $out/bench_2ranks.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_config5 -- python3 $root/bench.py --config 5 --steps 3 --warmup 1 > $out/bench_config5_under_rocprof.json 2> /dev/null
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_lg_$c -- python3 $root/tools/run_pair_once.py lightglue 2 > /dev/null 2>&1
