@@ -77,6 +77,28 @@ static constexpr int S_LDS_FLOATS = S_MAIN;
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
+// One LDS-DMA piece (buffer_load_dwordx4 ... lds: 64 lanes x 16 bytes land at lds_byte_addr + 16 * lane) issued as INLINE ASM, so
+// that the compiler's wait-count pass does not know about it: with the `__builtin_amdgcn_raw_ptr_buffer_load_lds` form it orders
+// every later LDS read behind the transfer with `s_waitcnt vmcnt(0)` (it cannot tell which LDS bytes a transfer writes), i.e. each
+// slab step first waited for the transfer of the NEXT slab that it had just started. Issued this way the transfer of slab + 1 stays
+// in flight under the reads, the transform and the 32 MFMAs of slab and is waited for by an explicit s_waitcnt vmcnt(0) in front
+// of the step's barrier (IM_DMA_WAIT). The descriptor is four SGPRs, the LDS address goes through M0.
+typedef unsigned int wu32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ wu32x4 wmake_rsrc4(const void* base, unsigned bytes) {
+    const unsigned long long b = reinterpret_cast<unsigned long long>(base);
+    wu32x4 r;
+    r.x = __builtin_amdgcn_readfirstlane((unsigned)b);
+    r.y = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32)) & 0xFFFFu;
+    r.z = __builtin_amdgcn_readfirstlane(bytes);
+    r.w = 0x00020000u;
+    return r;
+}
+__device__ __forceinline__ void dma16(wu32x4 rsrc, unsigned lds_byte_addr, unsigned voff, unsigned soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :: "s"(lds_byte_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+#define IM_DMA_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+
 template <bool POOL, bool FUSE1A>
 __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -125,9 +147,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
             for (int dx = 0; dx < 3; ++dx) tap[dy * 3 + dx] = sImg[(iy + dy) * S_IW + ix + dx];
     }
 
-    const __amdgpu_buffer_rsrc_t rin = wmake_rsrc(FUSE1A ? (const void*)a.w : (const void*)(a.in + (long)b * a.H * a.W * a.Cin),
-                                                  FUSE1A ? 0u : (unsigned)a.H * a.W * a.Cin * 4u);
-    const __amdgpu_buffer_rsrc_t ruw = wmake_rsrc(a.w, (unsigned)(a.Cin / WCC) * 16u * a.Cout * WCC * 4u);
+    const wu32x4 rin = wmake_rsrc4(FUSE1A ? (const void*)a.w : (const void*)(a.in + (long)b * a.H * a.W * a.Cin),
+                                   FUSE1A ? 0u : (unsigned)a.H * a.W * a.Cin * 4u);
+    const wu32x4 ruw = wmake_rsrc4(a.w, (unsigned)(a.Cin / WCC) * 16u * a.Cout * WCC * 4u);
+    const unsigned lds_sP = (unsigned)(unsigned long)(lds_ptr_t)sP, lds_sU = (unsigned)(unsigned long)(lds_ptr_t)sU;   // LDS byte addresses
+    // The fused first layer keeps the builtin form of the U transfer (compiler-managed waits): its stage is dominated by the conv1a
+    // arithmetic and the ds_writes of the patch, and with the asm form it measured 10 % SLOWER (1.67 vs 1.52 ms at 1080p); the
+    // plain layers gain 3-5 % from the asm form.
+    const __amdgpu_buffer_rsrc_t ruw_b = wmake_rsrc(a.w, (unsigned)(a.Cin / WCC) * 16u * a.Cout * WCC * 4u);
     const unsigned pv = p_in ? (unsigned)(((unsigned)p_gy * a.W + p_gx) * a.Cin) * 4u : 0xFFFFF000u;
     // U image in LDS: [pos][channel quad][64 output channels] float4, so that the 16 lanes of a ds_read_b128 lane
     // group read 16 consecutive slots (with the quad innermost the even / odd slots of one quad gave a 2-way bank
@@ -153,18 +180,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
     // fill stage (slab & 1) with slab's U block and patch
 #define IM_SSTAGE(slab)                                                                                 \
     {                                                                                                   \
-        float* ub = sU + ((slab) & 1) * W_SU + wave * 256;                                              \
+        const unsigned ub = lds_sU + (((slab) & 1) * W_SU + wave * 256) * 4u;                           \
         const unsigned so_ = (slab) * u_slab_bytes;                                                     \
-        _Pragma("unroll") for (int k_ = 0; k_ < 8; ++k_)                                                \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ruw, (lds_ptr_t)(ub + k_ * 1024), 16, uv, so_ + k_ * u_k_bytes, 0, 0); \
+        _Pragma("unroll") for (int k_ = 0; k_ < 8; ++k_) {                                              \
+            if constexpr (FUSE1A) __builtin_amdgcn_raw_ptr_buffer_load_lds(ruw_b, (lds_ptr_t)(sU + ((slab) & 1) * W_SU + wave * 256 + k_ * 1024), 16, uv, so_ + k_ * u_k_bytes, 0, 0); \
+            else dma16(ruw, ub + k_ * 4096u, uv, so_ + k_ * u_k_bytes);                                 \
+        }                                                                                               \
         float* pb = sP + ((slab) & 1) * S_SP;                                                           \
         if (tid < S_QUAD) {                                                                             \
             if constexpr (FUSE1A) {                                                                     \
                 reinterpret_cast<float4*>(pb)[tid] = fused_quad((slab) * WCC);                          \
                 reinterpret_cast<float4*>(pb)[S_QUAD + tid] = fused_quad((slab) * WCC + 4);             \
             } else {                                                                                    \
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_ptr_t)(pb + wave * 256), 16, pv, (slab) * (WCC * 4u), 0, 0); \
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_ptr_t)(pb + S_QUAD * 4 + wave * 256), 16, pv, (slab) * (WCC * 4u) + 16u, 0, 0); \
+                const unsigned pb_ = lds_sP + (((slab) & 1) * S_SP + wave * 256) * 4u;                  \
+                dma16(rin, pb_, pv, (slab) * (WCC * 4u));                                               \
+                dma16(rin, pb_ + S_QUAD * 16u, pv, (slab) * (WCC * 4u) + 16u);                          \
             }                                                                                           \
         }                                                                                               \
     }
@@ -211,11 +241,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
 
     const int nslab = a.Cin / WCC;
     IM_SSTAGE(0)
+    if constexpr (!FUSE1A) IM_DMA_WAIT();
     __syncthreads();
     for (int slab = 0; slab < nslab; ++slab) {
-        if (slab + 1 < nslab) IM_SSTAGE(slab + 1)   // stage (slab + 1) & 1 was last read in step slab - 1
+        if (slab + 1 < nslab) IM_SSTAGE(slab + 1)   // stage (slab + 1) & 1 was last read in step slab - 1; stays in flight under this step
         IM_SMMA(slab)
-        __syncthreads();                            // also waits for the DMA of this step (vmcnt(0))
+        if constexpr (!FUSE1A) {
+            __builtin_amdgcn_sched_barrier(0);      // the MFMAs stay in FRONT of the wait and the barrier
+            IM_DMA_WAIT();                          // the transfers of slab + 1 have landed (this wave's; the barrier covers the others')
+        }
+        __syncthreads();                            // FUSE1A: the compiler's own vmcnt(0) in front of the barrier covers the builtin transfers
     }
 #undef IM_SSTAGE
 #undef IM_SD
