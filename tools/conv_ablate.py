@@ -10,13 +10,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ABL = {
     "base": [],
     # no U transfer: the 8 LDS-DMA pieces of the U block per slab and wave are not issued (the patch still is)
-    "no_udma": [("            __builtin_amdgcn_raw_ptr_buffer_load_lds(ruw, (lds_ptr_t)(ub + k_ * 1024), 16, uv, so_ + k_ * u_k_bytes, 0, 0); \\",
-                 "            { if (so_ == 0xFFFFFFFFu) __builtin_amdgcn_raw_ptr_buffer_load_lds(ruw, (lds_ptr_t)(ub + k_ * 1024), 16, uv, so_ + k_ * u_k_bytes, 0, 0); } \\")],
+    "no_udma": [("            else dma16(ruw, ub + k_ * 4096u, uv, so_ + k_ * u_k_bytes);                                 \\",
+                 "            else if (so_ == 0xFFFFFFFFu) dma16(ruw, ub + k_ * 4096u, uv, so_ + k_ * u_k_bytes);           \\")],
     # no patch transfer (non-fused layers): the two patch pieces per slab are not issued
-    "no_pdma": [("                __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_ptr_t)(pb + wave * 256), 16, pv, (slab) * (WCC * 4u), 0, 0); \\",
-                 "                if (pv == 0x12345u) __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_ptr_t)(pb + wave * 256), 16, pv, (slab) * (WCC * 4u), 0, 0); \\"),
-                ("                __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_ptr_t)(pb + S_QUAD * 4 + wave * 256), 16, pv, (slab) * (WCC * 4u) + 16u, 0, 0); \\",
-                 "                if (pv == 0x12345u) __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_ptr_t)(pb + S_QUAD * 4 + wave * 256), 16, pv, (slab) * (WCC * 4u) + 16u, 0, 0); \\")],
+    "no_pdma": [("                dma16(rin, pb_, pv, (slab) * (WCC * 4u));                                               \\",
+                 "                if (pv == 0x12345u) dma16(rin, pb_, pv, (slab) * (WCC * 4u));                           \\"),
+                ("                dma16(rin, pb_ + S_QUAD * 16u, pv, (slab) * (WCC * 4u) + 16u);                          \\",
+                 "                if (pv == 0x12345u) dma16(rin, pb_ + S_QUAD * 16u, pv, (slab) * (WCC * 4u) + 16u);      \\")],
+    # one block per CU instead of two (LDS request padded past half of the 160 KB)
+    "one_block": [("    const size_t lds = (S_LDS_FLOATS + (FUSE ? S_FUSE : 0)) * sizeof(float);",
+                   "    const size_t lds = (S_LDS_FLOATS + (FUSE ? S_FUSE : 0)) * sizeof(float) + 16384;")],
     # no input transform: the 12 patch reads and 32 packed adds are replaced by 2 reads (the MFMA operands are whatever they hold)
     "no_xform": [("                    const float4 d0 = IM_SD(0, j_), d1 = IM_SD(1, j_), d2 = IM_SD(2, j_);               \\\n                    t0[j_] = sub4(d0, d2); t1[j_] = add4(d1, d2);                                       \\",
                   "                    t0[j_] = IM_SD(0, 0); t1[j_] = IM_SD(1, 0);                                         \\"),
