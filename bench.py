@@ -58,6 +58,15 @@ def kernel_flops(name, n_images=2, n0=KPTS, n1=KPTS, h=H, w=W, superglue=False):
     return None
 
 
+_REAL_STDOUT = None
+
+
+def emit(line: str) -> None:
+    """The one JSON line, on the process's ORIGINAL stdout (see main)."""
+    sys.stdout.flush()
+    os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, (line + "\n").encode())
+
+
 def spawn(args) -> None:
     """`python bench.py --gpus N` typed as is: this parent (which never touches a GPU) starts N ranks through
     torch.distributed.run and relays their output; rank 0 prints the JSON line."""
@@ -135,6 +144,13 @@ def main():
         args.batch = 1
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn(args)   # does not return
+    # the contract is ONE JSON line on stdout: native libraries write there too (RCCL prints a version banner when its first
+    # communicator is made, gloo its connection notes), so file descriptor 1 is pointed at stderr for the whole run and the line goes
+    # out through a duplicate of the original descriptor (`emit`)
+    global _REAL_STDOUT
+    sys.stdout.flush()
+    _REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -450,7 +466,7 @@ def main():
         # ---- CPU baseline: the oracle (torch-CPU fp32 restatement of the reference path) on this box's host cores
         if world == 1 and not args.no_cpu_baseline and not cfg5:
             result["cpu_baseline"] = cpu_baseline(epochs)
-        print(json.dumps(result), flush=True)
+        emit(json.dumps(result))
     if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -551,11 +567,11 @@ def dry_run(args, rank, world, epochs, kpts, dist):
     assert full[:, 0].tolist() == want and full[:, 3].tolist() == want
     ranks = rank_report(dist, rank, world, args, t_own, t_gather, -1, "cpu", table, full, True) if world > 1 else None
     if rank == 0:
-        print(json.dumps({"ranks": ranks, "metric": "matched stereo image-pairs/sec (4096 kpts, 1080p)", "value": n_pairs / dt, "unit": "pairs/s",
+        emit(json.dumps({"ranks": ranks, "metric": "matched stereo image-pairs/sec (4096 kpts, 1080p)", "value": n_pairs / dt, "unit": "pairs/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                           "config": {"workload": "DRY RUN: fabricated records, no GPU work"}, "dry_run": True,
-                          "roofline": None, "cpu_baseline": None}), flush=True)
+                          "roofline": None, "cpu_baseline": None}))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

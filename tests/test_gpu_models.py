@@ -1019,3 +1019,44 @@ def test_relative_orientation_and_triangulation_on_device():
     Et /= np.linalg.norm(Et)
     assert min(np.abs(E - Et).max(), np.abs(E + Et).max()) < 1e-6
     e.close()
+
+
+def test_host_feeder_equals_device_resident_inputs():
+    """`PairPipeline.match_host_pair` (pairs in pageable HOST memory, as the reference's loop holds them after imread,
+    `core/images.py:44-93` -> `main_dev.py:115-132`): staged through the page-locked ring and uploaded asynchronously on the launch
+    stream, the records are bit-identical to those of device-resident inputs - also when the ring wraps (7 pairs through 2 P + 2 = 6
+    staging buffers), with graph replay, two pairs per launch, two launch groups and an odd tail; the 98 KB records carry the keypoints."""
+    from icepy4d_amd.engine import Engine
+    from icepy4d_amd import sequence as sq
+    lg_sd = synthetic.lightglue_state_dict(0, "passthrough")
+    host = [np.stack(synthetic.translated_pair(s, 136, 200)) for s in range(1, 8)]
+    dev = [torch.from_numpy(p).cuda() for p in host]
+
+    def make_engine():
+        e = Engine(0)
+        e.load_state_dict("superpoint", SP_SD)
+        e.load_state_dict("lightglue", lg_sd)
+        return e
+
+    tabs = []
+    for feed_host in (False, True):
+        pipe = sq.PairPipeline(make_engine, 136, 200, 256, n_streams=2, use_graph=True, pairs_per_launch=2, with_keypoints=True)
+        tab = sq.new_table(len(host), pipe.max_kpts, pipe.device, with_keypoints=True)
+        for row in range(len(host)):
+            if feed_host:
+                scratch = host[row].copy()
+                pipe.match_host_pair(scratch, 50 + row, tab, row)
+                scratch[:] = 0                       # the caller may reuse its array at once: the pair was copied into the staging ring
+            else:
+                pipe.match_pair(dev[row], 50 + row, tab, row)
+        pipe.flush()
+        pipe.synchronize()
+        tabs.append(tab.cpu())
+        pipe.close()
+    assert torch.equal(tabs[0], tabs[1])
+    K = tabs[0].shape[1] - 8
+    assert tabs[0].shape[1] == 8 + 6 * 256 and tabs[0][:, 0].tolist() == list(range(50, 57)) and (tabs[0][:, 3] > 20).all()
+    rec = sq.decode_record(tabs[1][3].numpy(), 256)
+    v = rec["matches0"] > -1
+    d = rec["keypoints1"][rec["matches0"][v]] - rec["keypoints0"][v]       # matched point pairs straight from the gathered record
+    assert np.mean(np.all(np.abs(d - np.median(d, 0)) < 1.5, 1)) > 0.8
