@@ -1059,4 +1059,4 @@ def test_host_feeder_equals_device_resident_inputs():
     rec = sq.decode_record(tabs[1][3].numpy(), 256)
     v = rec["matches0"] > -1
     d = rec["keypoints1"][rec["matches0"][v]] - rec["keypoints0"][v]       # matched point pairs straight from the gathered record
-    assert np.mean(np.all(np.abs(d - np.median(d, 0)) < 1.5, 1)) > 0.8
+    assert v.sum() > 20 and np.mean(np.all(np.abs(d - np.array([40, 8])) < 1.5, 1)) > 0.6     # most follow the true (40, 8) px translation
