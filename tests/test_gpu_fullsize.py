@@ -155,7 +155,8 @@ def test_config3_timed_launch_mode_equals_direct_launches_and_the_oracle():
     e.close()
 
 
-@pytest.mark.parametrize("flags", [["--steps", "5", "--warmup", "3"], ["--steps", "2", "--warmup", "0"]])
+@pytest.mark.parametrize("flags", [["--steps", "5", "--warmup", "3"], ["--steps", "2", "--warmup", "0"],
+                                   ["--steps", "4", "--warmup", "2", "--config", "4", "--pool", "2"]])
 def test_bench_line_with_odd_step_counts(flags):
     """`python bench.py --gpus 1 --steps K --warmup W` as the round driver types it, with counts that do not fill the launch
     groups of two pairs: one JSON line with the contract fields, every step recorded, a throughput in the range of the device
@@ -175,3 +176,6 @@ def test_bench_line_with_odd_step_counts(flags):
     assert d["n_gpus"] == 1 and d["steps"] == int(flags[1]) and d["warmup"] == int(flags[3]) and d["unit"] == "pairs/s"
     assert d["config"]["mean_keypoints"] == 4096 and d["roofline"]["bound"] == "mfma" and 0.5 < d["roofline"]["frac"] < 1.0
     assert d["value"] > 5.0, d["value"]      # a sanity bound, not a performance threshold (a cold or shared device is slower)
+    assert "all_gather_ms" in d and "traffic_source" in d["roofline"] and "pair_executed_mfma_utilisation" in d
+    if "--config" in flags:                 # configs[3] on one rank: 98 KB records (keypoints of both images ride along)
+        assert "98 KB records" in d["config"]["workload"] and "configs[3]" in d["config"]["workload"]
