@@ -36,6 +36,14 @@ ABL = {
     # no epilogue: the accumulators are consumed, nothing is exchanged or stored
     "no_epi": [("    f32x16 e00, e01, e10, e11;\n",
                 "    { float keep_ = 0.f; _Pragma(\"unroll\") for (int p_ = 0; p_ < 8; ++p_) keep_ += acc[p_][0] + acc[p_][15]; if (keep_ == 12345.678f) a.out[0] = keep_; return; }\n    f32x16 e00, e01, e10, e11;\n")],
+    # epilogue without its global stores (values consumed by an empty asm)
+    "no_store": [("                    if (py < Ho && px < Wo) a.out[(((long)b * Ho + py) * Wo + px) * a.Cout + co] = fmaxf(fmaxf(y00, y01), fmaxf(y10, y11));",
+                  "                    { float k_ = fmaxf(fmaxf(y00, y01), fmaxf(y10, y11)); asm volatile(\"\" :: \"v\"(k_), \"v\"(py), \"v\"(px)); }"),
+                 ("                    if (oy < a.H && ox < a.W) o[0] = y00;\n                    if (oy < a.H && ox + 1 < a.W) o[a.Cout] = y01;\n                    if (oy + 1 < a.H && ox < a.W) o[(long)a.W * a.Cout] = y10;\n                    if (oy + 1 < a.H && ox + 1 < a.W) o[(long)a.W * a.Cout + a.Cout] = y11;",
+                  "                    asm volatile(\"\" :: \"v\"(y00), \"v\"(y01), \"v\"(y10), \"v\"(y11), \"v\"(o));")],
+    # epilogue without the LDS exchange between the two V-row halves (own partials used twice, no barrier)
+    "no_xchg": [("        __syncthreads();\n        const float4* xr = reinterpret_cast<const float4*>(sX) + ((P ^ 1) * 8) * 128 + (tid & 127);",
+                 "        const float4* xr = reinterpret_cast<const float4*>(sX) + (P * 8) * 128 + (tid & 127);")],
     # main loop only one slab (prologue + 1 step + epilogue)
     "one_slab": [("    const int nslab = a.Cin / WCC;", "    const int nslab = 1;")],
 }
