@@ -92,31 +92,21 @@ __device__ __forceinline__ void qk_tile(const float* __restrict__ sK, int c, int
 // On gfx950 the fp32 MFMA and the ordinary VALU share issue cycles: `tools/mfma_peak.hip` shows every VALU
 // instruction next to a v_mfma_f32_32x32x2_f32 stream costs its full 4 (exp2: 8) cycles of matrix-pipe time, with one
 // or two waves per SIMD alike. The softmax is therefore written for instruction COUNT, not for overlap:
-//   * max with v_max3_f32 (16 instructions for the 32 scores of a lane; the asm also avoids the canonicalising
-//     v_max x, x, x the compiler puts in front of every fmaxf of an MFMA result);
+//   * max as nested maxima that the compiler fuses into v_max3_f32 (16 instructions for the 32 scores of a lane);
 //   * subtraction and row sum on whole vectors, which lower to packed fp32 (v_pk_add_f32: two values per lane-op);
 //   * the running max is a REFERENCE, only raised when some row of the wave exceeds it by more than 2^8: P then stays
 //     <= 256 (harmless in fp32: l <= 4096 keys x 256) and the common step has no alpha, no rescale of O, no l * alpha.
 //     Softmax is shift invariant, so O / l is the same quantity as with the exact running max.
 static constexpr float M_SLACK = 8.f;
 
-__device__ __forceinline__ float max3(float a, float b, float c) {
-    float d;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
-}
-
-// packed fp32 (two values per lane-op); written as asm because the compiler scalarises these vector expressions
-__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
-    f32x2 d;
-    asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
-    return d;
-}
-__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
-    f32x2 d;
-    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
-    return d;
-}
+// Compiler-visible since round 3 (rounds 1-2 had `asm("v_max3_f32 ...")` / `asm("v_pk_add_f32 ...")` here): an asm VALU write next to
+// MFMAs is invisible to the hazard recogniser - in conv_wino.hip that produced wrong results as soon as the register allocation
+// changed. The compiler still forms v_max3_f32 from the nested maxima and v_pk_add_f32 for about half of the
+// two-element operations (it scalarises the rest: +240 v_add_f32 in the listing); measured cost 0.3 % of the kernel (2.334 against
+// 2.328 ms per pair over the nine self-attention launches), results bit-identical.
+__device__ __forceinline__ float max3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) { return a + b; }
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) { return a - b; }
 #define IM_PAIR(v, i) f32x2{v[2 * (i)], v[2 * (i) + 1]}
 
 template <bool TAIL>
