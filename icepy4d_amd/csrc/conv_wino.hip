@@ -199,18 +199,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
         }                                                                                               \
     }
 
-    f32x16 acc[8];   // position (2 ph + (p >> 2), p & 3)
-#pragma unroll
-    for (int p = 0; p < 8; ++p)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+    f32x16 acc[8];   // position (2 ph + (p >> 2), p & 3); first written by the MFMAs of slab 0, which take a literal zero as C
 
     // lane (c, hh): tile c of the 4 x 8 tile grid, channel quad hh; B operand: output channel cb * 32 + c
     const int t_ty = c >> 3, t_tx = c & 7;
     const int a_slot = hh * S_QUAD + (2 * t_ty + ph) * S_ROW + t_tx;         // patch row 2 ty + ph, parity 0, quad hh
     const int b_slot = ((ph * 8) * 2 + hh) * 64 + cb * 32 + c;               // position 8 ph, quad hh, this lane's channel
 #define IM_SD(i, j) pa[a_slot + (i) * S_ROW + ((j) & 1) * S_PAR + ((j) >> 1)]
-#define IM_SMMA(slab)                                                                                   \
+#define IM_SMMA(slab, FIRST)                                                                              \
     {                                                                                                   \
         const float4* pa = reinterpret_cast<const float4*>(sP + ((slab) & 1) * S_SP);                   \
         const float4* ua = reinterpret_cast<const float4*>(sU + ((slab) & 1) * W_SU) + b_slot;          \
@@ -233,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
         }                                                                                               \
         float4 u[8];                                                                                    \
         _Pragma("unroll") for (int p_ = 0; p_ < 8; ++p_) u[p_] = ua[p_ * 128];                          \
-        _Pragma("unroll") for (int p_ = 0; p_ < 8; ++p_) acc[p_] = mfma32(v[p_].x, u[p_].x, acc[p_]);   \
+        _Pragma("unroll") for (int p_ = 0; p_ < 8; ++p_) acc[p_] = mfma32(v[p_].x, u[p_].x, (FIRST) ? f32x16{} : acc[p_]); \
         _Pragma("unroll") for (int p_ = 0; p_ < 8; ++p_) acc[p_] = mfma32(v[p_].y, u[p_].y, acc[p_]);   \
         _Pragma("unroll") for (int p_ = 0; p_ < 8; ++p_) acc[p_] = mfma32(v[p_].z, u[p_].z, acc[p_]);   \
         _Pragma("unroll") for (int p_ = 0; p_ < 8; ++p_) acc[p_] = mfma32(v[p_].w, u[p_].w, acc[p_]);   \
@@ -243,15 +239,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
     IM_SSTAGE(0)
     if constexpr (!FUSE1A) IM_DMA_WAIT();
     __syncthreads();
-    for (int slab = 0; slab < nslab; ++slab) {
-        if (slab + 1 < nslab) IM_SSTAGE(slab + 1)   // stage (slab + 1) & 1 was last read in step slab - 1; stays in flight under this step
-        IM_SMMA(slab)
-        if constexpr (!FUSE1A) {
-            __builtin_amdgcn_sched_barrier(0);      // the MFMAs stay in FRONT of the wait and the barrier
-            IM_DMA_WAIT();                          // the transfers of slab + 1 have landed (this wave's; the barrier covers the others')
-        }
-        __syncthreads();                            // FUSE1A: the compiler's own vmcnt(0) in front of the barrier covers the builtin transfers
+    // one step: stage (slab + 1) & 1 was last read in step slab - 1 and its transfers stay in flight under this step's MFMAs;
+    // the MFMAs stay in FRONT of the wait and the barrier; the wait covers this wave's transfers, the barrier the others'
+    // (FUSE1A: the compiler's own vmcnt(0) in front of the barrier covers the builtin transfers)
+#define IM_SSTEP(slab, FIRST)                                                                           \
+    {                                                                                                   \
+        if ((slab) + 1 < nslab) IM_SSTAGE((slab) + 1)                                                   \
+        IM_SMMA(slab, FIRST)                                                                            \
+        if constexpr (!FUSE1A) {                                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                          \
+            IM_DMA_WAIT();                                                                              \
+        }                                                                                               \
+        __syncthreads();                                                                                \
     }
+    // slab 0 is peeled so that its first MFMAs start the accumulators from a literal zero: zeroing 128 registers ahead of the
+    // loop was 256 v_mov per wave (the compiler emitted the zeroing twice), a fifth of the kernel's non-MFMA vector instructions,
+    // and fp32 MFMA and VALU never co-execute on this part
+    IM_SSTEP(0, true)
+    for (int slab = 1; slab < nslab; ++slab) IM_SSTEP(slab, false)
+#undef IM_SSTEP
 #undef IM_SSTAGE
 #undef IM_SD
 #undef IM_SMMA
@@ -327,7 +333,7 @@ static hipError_t launch_wino(const ConvArgs& a, hipStream_t s) {
 }
 
 hipError_t launch_conv3x3_wino(const ConvArgs& a, hipStream_t s) {
-    if (a.Cin % WCC != 0 || a.Cout % 64 != 0) return hipErrorInvalidValue;
+    if (a.Cin < WCC || a.Cin % WCC != 0 || a.Cout % 64 != 0) return hipErrorInvalidValue;
     if (a.img) {
         if (a.Cin != 64 || !a.w1 || !a.b1) return hipErrorInvalidValue;
         return a.pool ? launch_wino<true, true>(a, s) : launch_wino<false, true>(a, s);
