@@ -31,7 +31,11 @@
 //
 // History (same tests, conv 64 -> 64 + pool at 1080p, non-fused): 8-wave kernel with a V image in LDS 2.08 ms; its
 // 4-wave form with a register-local inverse transform 2.08; register input transform, 8 waves, one block per CU 1.60
-// (ablations: no MFMA 0.82, prologue + one slab + epilogue 0.48, no epilogue 1.39); this kernel 1.53 ms.
+// (ablations: no MFMA 0.82, prologue + one slab + epilogue 0.48, no epilogue 1.39); two blocks per CU 1.53 ms; round 3: LDS-DMA
+// issued as asm (no forced wait in front of the step's LDS reads) 1.49; instruction-count work found with tools/isa_census.py -
+// accumulators started from a literal-zero C operand instead of 256 v_mov per wave 1.445; epilogue in vectors over neighbouring
+// accumulator registers (no moves), packed subtracts (v_pk_fma_f32 by an opaque -1), uniform output addressing and max3 for
+// ReLU + pool, about 500 -> 170 vector instructions per wave, 1.42 ms (fused first layer 1.49 -> 1.43).
 #include <cstdlib>
 #include <type_traits>
 
@@ -60,10 +64,31 @@ __device__ __forceinline__ float4 add4(float4 x, float4 y) {
     const f32x2 r0 = a + c, r1 = b + d;
     return make_float4(r0.x, r0.y, r1.x, r1.y);
 }
-__device__ __forceinline__ float4 sub4(float4 x, float4 y) {
+// x - y as fma(y, -1, x) with the -1 in a register the compiler cannot see through (`minus_one()`): the same value, rounded once,
+// but lowered to v_pk_fma_f32, where a vector subtraction (and an fma by a literal -1, which is folded back into one) is scalarised
+// into two v_sub_f32. fp32 MFMA and VALU never co-execute on this part, so every vector instruction saved is MFMA time.
+// The asm is NOT volatile: a volatile asm statement counts as a possible store, after which the compiler no longer proves the
+// uniform weight loads of the fused first layer unclobbered and turns its scalar loads into 20 vector loads per stage (+15 %).
+__device__ __forceinline__ f32x2 minus_one() {
+    float m = -1.f;
+    asm("" : "+s"(m));
+    return f32x2{m, m};
+}
+__device__ __forceinline__ float4 sub4(float4 x, float4 y, f32x2 m1) {
     const f32x2 a = {x.x, x.y}, b = {x.z, x.w}, c = {y.x, y.y}, d = {y.z, y.w};
-    const f32x2 r0 = a - c, r1 = b - d;
+    const f32x2 r0 = __builtin_elementwise_fma(c, m1, a), r1 = __builtin_elementwise_fma(d, m1, b);
     return make_float4(r0.x, r0.y, r1.x, r1.y);
+}
+// max(v, floor) as one v_med3_f32 (fmaxf of two values of unknown origin costs two canonicalising v_max besides the max itself)
+__device__ __forceinline__ float relu_floor(float v, float floor_) { return __builtin_amdgcn_fmed3f(v, floor_, __builtin_inff()); }
+__device__ __forceinline__ f32x16 sub16(const f32x16& x, const f32x16& y, f32x2 m1) {
+    f32x16 r;
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) {
+        const f32x2 v = __builtin_elementwise_fma(f32x2{y[i], y[i + 1]}, m1, f32x2{x[i], x[i + 1]});
+        r[i] = v.x; r[i + 1] = v.y;
+    }
+    return r;
 }
 
 static constexpr int S_TH = 8, S_TW = 16;
@@ -206,7 +231,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
     const int a_slot = hh * S_QUAD + (2 * t_ty + ph) * S_ROW + t_tx;         // patch row 2 ty + ph, parity 0, quad hh
     const int b_slot = ((ph * 8) * 2 + hh) * 64 + cb * 32 + c;               // position 8 ph, quad hh, this lane's channel
 #define IM_SD(i, j) pa[a_slot + (i) * S_ROW + ((j) & 1) * S_PAR + ((j) >> 1)]
-#define IM_SMMA(slab, FIRST)                                                                              \
+#define IM_SMMA(slab, FIRST)                                                                            \
     {                                                                                                   \
         const float4* pa = reinterpret_cast<const float4*>(sP + ((slab) & 1) * S_SP);                   \
         const float4* ua = reinterpret_cast<const float4*>(sU + ((slab) & 1) * W_SU) + b_slot;          \
@@ -216,16 +241,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
             if (ph == 0) {              /* V rows 0, 1 from patch rows 0, 1, 2 */                       \
                 _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                      \
                     const float4 d0 = IM_SD(0, j_), d1 = IM_SD(1, j_), d2 = IM_SD(2, j_);               \
-                    t0[j_] = sub4(d0, d2); t1[j_] = add4(d1, d2);                                       \
+                    t0[j_] = sub4(d0, d2, m1); t1[j_] = add4(d1, d2);                                   \
                 }                                                                                       \
             } else {                    /* V rows 2, 3 from patch rows 1, 2, 3 (= rows 0, 1, 2 relative to ph) */ \
                 _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                      \
                     const float4 d1 = IM_SD(0, j_), d2 = IM_SD(1, j_), d3 = IM_SD(2, j_);               \
-                    t0[j_] = sub4(d2, d1); t1[j_] = sub4(d1, d3);                                       \
+                    t0[j_] = sub4(d2, d1, m1); t1[j_] = sub4(d1, d3, m1);                               \
                 }                                                                                       \
             }                                                                                           \
-            v[0] = sub4(t0[0], t0[2]); v[1] = add4(t0[1], t0[2]); v[2] = sub4(t0[2], t0[1]); v[3] = sub4(t0[1], t0[3]); \
-            v[4] = sub4(t1[0], t1[2]); v[5] = add4(t1[1], t1[2]); v[6] = sub4(t1[2], t1[1]); v[7] = sub4(t1[1], t1[3]); \
+            v[0] = sub4(t0[0], t0[2], m1); v[1] = add4(t0[1], t0[2]); v[2] = sub4(t0[2], t0[1], m1); v[3] = sub4(t0[1], t0[3], m1); \
+            v[4] = sub4(t1[0], t1[2], m1); v[5] = add4(t1[1], t1[2]); v[6] = sub4(t1[2], t1[1], m1); v[7] = sub4(t1[1], t1[3], m1); \
         }                                                                                               \
         float4 u[8];                                                                                    \
         _Pragma("unroll") for (int p_ = 0; p_ < 8; ++p_) u[p_] = ua[p_ * 128];                          \
@@ -236,6 +261,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
     }
 
     const int nslab = a.Cin / WCC;
+    const f32x2 m1 = minus_one();
     IM_SSTAGE(0)
     if constexpr (!FUSE1A) IM_DMA_WAIT();
     __syncthreads();
@@ -264,18 +290,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
 
     // ---- inverse transform Y = A^T M A. Row pass (over j) in registers: s[il][b]; the column pass needs both V-row halves:
     //   Y[0][b] = s[0][b] + s[1][b] + s[2][b],   Y[1][b] = s[1][b] - s[2][b] - s[3][b]
-    // ph 0 holds {s0 + s1, s1}, ph 1 holds {s2, -(s2 + s3)}; ph 0 keeps accumulator registers 0..7, ph 1 registers 8..15,
-    // and each sends the other its partials of the registers it gives away ([sender][slot][thread] float4).
-    f32x16 e00, e01, e10, e11;
-    {
-        const f32x16 sa0 = (acc[0] + acc[1]) + acc[2], sa1 = (acc[1] - acc[2]) - acc[3];
-        const f32x16 sb0 = (acc[4] + acc[5]) + acc[6], sb1 = (acc[5] - acc[6]) - acc[7];
-        if (ph == 0) { e00 = sa0 + sb0; e01 = sa1 + sb1; e10 = sb0; e11 = sb1; }
-        else { e00 = sa0; e01 = sa1; e10 = -(sa0 + sb0); e11 = -(sa1 + sb1); }
-    }
+    // ph 0 holds {s0 + s1, s1}, ph 1 holds {s2, s2 + s3}; ph 0 keeps accumulator registers 0..7, ph 1 registers 8..15, and each
+    // sends the other its partials of the registers it gives away ([sender][slot][thread] float4). All of it in two-element
+    // vectors over neighbouring accumulator registers (= neighbouring tiles of one row), which are register pairs already, so the
+    // packed instructions need no moves; output addresses are a uniform base per register plus one per-lane offset.
+    const f32x16 sa0 = (acc[0] + acc[1]) + acc[2], sa1 = sub16(sub16(acc[1], acc[2], m1), acc[3], m1);
+    const f32x16 sb0 = (acc[4] + acc[5]) + acc[6], sb1 = sub16(sub16(acc[5], acc[6], m1), acc[7], m1);
+    const f32x16 t0 = sa0 + sb0, t1 = sa1 + sb1;
     const int co = co0 + cb * 32 + c;
     const float bv = a.bias[co];
-    auto finish = [&](auto PH) {
+    const f32x2 bv2 = {bv, bv};
+    const float floor_ = a.relu ? 0.f : -__builtin_inff();
+    const f32x2 fl2 = {floor_, floor_};
+    auto finish = [&](auto PH, const f32x16& e00, const f32x16& e01, const f32x16& e10, const f32x16& e11) {
         constexpr int P = decltype(PH)::value;
         constexpr int G = P == 0 ? 8 : 0;     // first register given away
         constexpr int K = P == 0 ? 0 : 8;     // first register kept
@@ -288,35 +315,62 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
 #undef IM_SX
         __syncthreads();
         const float4* xr = reinterpret_cast<const float4*>(sX) + ((P ^ 1) * 8) * 128 + (tid & 127);
+        // register r of the accumulator is tile (r >> 2, (r & 3) + 4 hh) of the block's 4 x 8 tile grid (acc_row)
+        const int Ho = POOL ? a.H >> 1 : a.H, Wo = POOL ? a.W >> 1 : a.W;         // output grid
+        constexpr int ST = POOL ? 1 : 2;                                          // output pixels per tile and axis
+        const int oy0 = POOL ? y0 >> 1 : y0, ox0 = POOL ? x0 >> 1 : x0;
+        float* const ubase = a.out + (((long)b * Ho + oy0) * Wo + ox0) * a.Cout;  // uniform
+        const unsigned lane_off = (unsigned)(ST * 4 * hh) * a.Cout + co;
+        const int rows_left = Ho - oy0, cols_left = Wo - ox0 - ST * 4 * hh;
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const float4 x00 = xr[(0 + k) * 128], x01 = xr[(2 + k) * 128], x10 = xr[(4 + k) * 128], x11 = xr[(6 + k) * 128];
-            const float a00[4] = {x00.x, x00.y, x00.z, x00.w}, a01[4] = {x01.x, x01.y, x01.z, x01.w};
-            const float a10[4] = {x10.x, x10.y, x10.z, x10.w}, a11[4] = {x11.x, x11.y, x11.z, x11.w};
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int r = K + 4 * k + q;
-                float y00 = e00[r] + a00[q] + bv, y01 = e01[r] + a01[q] + bv, y10 = e10[r] + a10[q] + bv, y11 = e11[r] + a11[q] + bv;
-                if (a.relu) { y00 = fmaxf(y00, 0.f); y01 = fmaxf(y01, 0.f); y10 = fmaxf(y10, 0.f); y11 = fmaxf(y11, 0.f); }
-                const int tl = acc_row(r, hh);
-                const int tyy = tl >> 3, txx = tl & 7;
-                const int oy = y0 + 2 * tyy, ox = x0 + 2 * txx;
-                if constexpr (POOL) {
-                    const int Ho = a.H >> 1, Wo = a.W >> 1;
-                    const int py = oy >> 1, px = ox >> 1;
-                    if (py < Ho && px < Wo) a.out[(((long)b * Ho + py) * Wo + px) * a.Cout + co] = fmaxf(fmaxf(y00, y01), fmaxf(y10, y11));
-                } else {
-                    float* o = a.out + (((long)b * a.H + oy) * a.W + ox) * a.Cout + co;
-                    if (oy < a.H && ox < a.W) o[0] = y00;
-                    if (oy < a.H && ox + 1 < a.W) o[a.Cout] = y01;
-                    if (oy + 1 < a.H && ox < a.W) o[(long)a.W * a.Cout] = y10;
-                    if (oy + 1 < a.H && ox + 1 < a.W) o[(long)a.W * a.Cout + a.Cout] = y11;
+            for (int h = 0; h < 2; ++h) {
+                const int r = K + 4 * k + 2 * h;                                  // registers r, r + 1
+                const f32x2 a00 = h ? f32x2{x00.z, x00.w} : f32x2{x00.x, x00.y}, a01 = h ? f32x2{x01.z, x01.w} : f32x2{x01.x, x01.y};
+                const f32x2 a10 = h ? f32x2{x10.z, x10.w} : f32x2{x10.x, x10.y}, a11 = h ? f32x2{x11.z, x11.w} : f32x2{x11.x, x11.y};
+                f32x2 y00 = (f32x2{e00[r], e00[r + 1]} + a00) + bv2, y01 = (f32x2{e01[r], e01[r + 1]} + a01) + bv2;
+                f32x2 y10, y11;
+                if constexpr (P == 0) {        // own s1 minus the other's s2 + s3
+                    y10 = __builtin_elementwise_fma(a10, m1, f32x2{e10[r], e10[r + 1]}) + bv2;
+                    y11 = __builtin_elementwise_fma(a11, m1, f32x2{e11[r], e11[r + 1]}) + bv2;
+                } else {                       // the other's s1 minus own s2 + s3
+                    y10 = __builtin_elementwise_fma(f32x2{e10[r], e10[r + 1]}, m1, a10) + bv2;
+                    y11 = __builtin_elementwise_fma(f32x2{e11[r], e11[r + 1]}, m1, a11) + bv2;
+                }
+                if constexpr (!POOL) {
+                    y00 = __builtin_elementwise_max(y00, fl2); y01 = __builtin_elementwise_max(y01, fl2);
+                    y10 = __builtin_elementwise_max(y10, fl2); y11 = __builtin_elementwise_max(y11, fl2);
+                }
+                const int trow = (K + 4 * k) >> 2 & 3;                            // r >> 2
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int tcol = 2 * h + e;                                   // (r + e) & 3
+                    const float v00 = e ? y00.y : y00.x, v01 = e ? y01.y : y01.x, v10 = e ? y10.y : y10.x, v11 = e ? y11.y : y11.x;
+                    if constexpr (POOL) {      // relu(max) = max(relu)
+                        float* const up = ubase + ((long)trow * Wo + tcol) * a.Cout;
+                        const float m = __builtin_fmaxf(__builtin_fmaxf(v00, v01), v10);
+                        if (trow < rows_left && tcol < cols_left) up[lane_off] = __builtin_fmaxf(__builtin_fmaxf(m, v11), floor_);
+                    } else {
+                        float* const up = ubase + ((long)(2 * trow) * Wo + 2 * tcol) * a.Cout;
+                        float* const dn = up + (long)Wo * a.Cout;
+                        const bool c0 = 2 * tcol < cols_left, c1 = 2 * tcol + 1 < cols_left;
+                        if (2 * trow < rows_left) {
+                            if (c0) up[lane_off] = v00;
+                            if (c1) up[lane_off + a.Cout] = v01;
+                        }
+                        if (2 * trow + 1 < rows_left) {
+                            if (c0) dn[lane_off] = v10;
+                            if (c1) dn[lane_off + a.Cout] = v11;
+                        }
+                    }
                 }
             }
         }
     };
-    if (ph == 0) finish(std::integral_constant<int, 0>{});
-    else finish(std::integral_constant<int, 1>{});
+    if (ph == 0) finish(std::integral_constant<int, 0>{}, t0, t1, sb0, sb1);
+    else finish(std::integral_constant<int, 1>{}, sa0, sa1, t0, t1);
 }
 
 

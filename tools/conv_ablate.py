@@ -20,27 +20,24 @@ ABL = {
     # one block per CU instead of two (LDS request padded past half of the 160 KB)
     "one_block": [("    const size_t lds = (S_LDS_FLOATS + (FUSE ? S_FUSE : 0)) * sizeof(float);",
                    "    const size_t lds = (S_LDS_FLOATS + (FUSE ? S_FUSE : 0)) * sizeof(float) + 16384;")],
-    # no input transform: the 12 patch reads and 32 packed adds are replaced by 2 reads (the MFMA operands are whatever they hold)
-    "no_xform": [("                    const float4 d0 = IM_SD(0, j_), d1 = IM_SD(1, j_), d2 = IM_SD(2, j_);               \\\n                    t0[j_] = sub4(d0, d2); t1[j_] = add4(d1, d2);                                       \\",
-                  "                    t0[j_] = IM_SD(0, 0); t1[j_] = IM_SD(1, 0);                                         \\"),
-                 ("                    const float4 d1 = IM_SD(0, j_), d2 = IM_SD(1, j_), d3 = IM_SD(2, j_);               \\\n                    t0[j_] = sub4(d2, d1); t1[j_] = sub4(d1, d3);                                       \\",
-                  "                    t0[j_] = IM_SD(0, 0); t1[j_] = IM_SD(1, 0);                                         \\"),
-                 ("            v[0] = sub4(t0[0], t0[2]); v[1] = add4(t0[1], t0[2]); v[2] = sub4(t0[2], t0[1]); v[3] = sub4(t0[1], t0[3]); \\\n            v[4] = sub4(t1[0], t1[2]); v[5] = add4(t1[1], t1[2]); v[6] = sub4(t1[2], t1[1]); v[7] = sub4(t1[1], t1[3]); \\",
-                  "            v[0] = t0[0]; v[1] = t0[1]; v[2] = t0[2]; v[3] = t0[3]; v[4] = t1[0]; v[5] = t1[1]; v[6] = t1[2]; v[7] = t1[3]; \\")],
+    # no input transform: the packed adds are dropped (the MFMA operands are whatever two patch reads hold)
+    "no_xform": [("t0[j_] = sub4(d0, d2, m1); t1[j_] = add4(d1, d2);", "t0[j_] = IM_SD(0, 0); t1[j_] = IM_SD(1, 0);"),
+                 ("t0[j_] = sub4(d2, d1, m1); t1[j_] = sub4(d1, d3, m1);", "t0[j_] = IM_SD(0, 0); t1[j_] = IM_SD(1, 0);"),
+                 ("v[0] = sub4(t0[0], t0[2], m1); v[1] = add4(t0[1], t0[2]); v[2] = sub4(t0[2], t0[1], m1); v[3] = sub4(t0[1], t0[3], m1);",
+                  "v[0] = t0[0]; v[1] = t0[1]; v[2] = t0[2]; v[3] = t0[3];"),
+                 ("v[4] = sub4(t1[0], t1[2], m1); v[5] = add4(t1[1], t1[2]); v[6] = sub4(t1[2], t1[1], m1); v[7] = sub4(t1[1], t1[3], m1);",
+                  "v[4] = t1[0]; v[5] = t1[1]; v[6] = t1[2]; v[7] = t1[3];")],
     # one U read per slab instead of eight
     "no_uread": [("        _Pragma(\"unroll\") for (int p_ = 0; p_ < 8; ++p_) u[p_] = ua[p_ * 128];                          \\",
                   "        _Pragma(\"unroll\") for (int p_ = 0; p_ < 8; ++p_) u[p_] = ua[0];                                 \\")],
     # no MFMA: operands are consumed by a cheap asm so that the loads and the transform stay
-    "no_mfma": [("        _Pragma(\"unroll\") for (int p_ = 0; p_ < 8; ++p_) acc[p_] = mfma32(v[p_].x, u[p_].x, acc[p_]);   \\\n        _Pragma(\"unroll\") for (int p_ = 0; p_ < 8; ++p_) acc[p_] = mfma32(v[p_].y, u[p_].y, acc[p_]);   \\\n        _Pragma(\"unroll\") for (int p_ = 0; p_ < 8; ++p_) acc[p_] = mfma32(v[p_].z, u[p_].z, acc[p_]);   \\\n        _Pragma(\"unroll\") for (int p_ = 0; p_ < 8; ++p_) acc[p_] = mfma32(v[p_].w, u[p_].w, acc[p_]);   \\",
-                 "        _Pragma(\"unroll\") for (int p_ = 0; p_ < 8; ++p_) { asm volatile(\"\" :: \"v\"(v[p_].x), \"v\"(v[p_].y), \"v\"(v[p_].z), \"v\"(v[p_].w), \"v\"(u[p_].x), \"v\"(u[p_].y), \"v\"(u[p_].z), \"v\"(u[p_].w)); } \\")],
+    "no_mfma": [("acc[p_] = mfma32(v[p_].x, u[p_].x, (FIRST) ? f32x16{} : acc[p_]);",
+                 "{ if (FIRST) acc[p_] = f32x16{}; asm volatile(\"\" :: \"v\"(v[p_].x), \"v\"(v[p_].y), \"v\"(v[p_].z), \"v\"(v[p_].w), \"v\"(u[p_].x), \"v\"(u[p_].y), \"v\"(u[p_].z), \"v\"(u[p_].w)); }"),
+                ("acc[p_] = mfma32(v[p_].y, u[p_].y, acc[p_]);", ";"), ("acc[p_] = mfma32(v[p_].z, u[p_].z, acc[p_]);", ";"),
+                ("acc[p_] = mfma32(v[p_].w, u[p_].w, acc[p_]);", ";")],
     # no epilogue: the accumulators are consumed, nothing is exchanged or stored
-    "no_epi": [("    f32x16 e00, e01, e10, e11;\n",
-                "    { float keep_ = 0.f; _Pragma(\"unroll\") for (int p_ = 0; p_ < 8; ++p_) keep_ += acc[p_][0] + acc[p_][15]; if (keep_ == 12345.678f) a.out[0] = keep_; return; }\n    f32x16 e00, e01, e10, e11;\n")],
-    # epilogue without its global stores (values consumed by an empty asm)
-    "no_store": [("                    if (py < Ho && px < Wo) a.out[(((long)b * Ho + py) * Wo + px) * a.Cout + co] = fmaxf(fmaxf(y00, y01), fmaxf(y10, y11));",
-                  "                    { float k_ = fmaxf(fmaxf(y00, y01), fmaxf(y10, y11)); asm volatile(\"\" :: \"v\"(k_), \"v\"(py), \"v\"(px)); }"),
-                 ("                    if (oy < a.H && ox < a.W) o[0] = y00;\n                    if (oy < a.H && ox + 1 < a.W) o[a.Cout] = y01;\n                    if (oy + 1 < a.H && ox < a.W) o[(long)a.W * a.Cout] = y10;\n                    if (oy + 1 < a.H && ox + 1 < a.W) o[(long)a.W * a.Cout + a.Cout] = y11;",
-                  "                    asm volatile(\"\" :: \"v\"(y00), \"v\"(y01), \"v\"(y10), \"v\"(y11), \"v\"(o));")],
+    "no_epi": [("    const f32x16 sa0 = (acc[0] + acc[1]) + acc[2],",
+                "    { float keep_ = 0.f; _Pragma(\"unroll\") for (int p_ = 0; p_ < 8; ++p_) keep_ += acc[p_][0] + acc[p_][15]; if (keep_ == 12345.678f) a.out[0] = keep_; return; }\n    const f32x16 sa0 = (acc[0] + acc[1]) + acc[2],")],
     # epilogue without the LDS exchange between the two V-row halves (own partials used twice, no barrier)
     "no_xchg": [("        __syncthreads();\n        const float4* xr = reinterpret_cast<const float4*>(sX) + ((P ^ 1) * 8) * 128 + (tid & 127);",
                  "        const float4* xr = reinterpret_cast<const float4*>(sX) + (P * 8) * 128 + (tid & 127);")],
