@@ -101,9 +101,8 @@ static constexpr float M_SLACK = 8.f;
 
 // Compiler-visible since round 3 (rounds 1-2 had `asm("v_max3_f32 ...")` / `asm("v_pk_add_f32 ...")` here): an asm VALU write next to
 // MFMAs is invisible to the hazard recogniser - in conv_wino.hip that produced wrong results as soon as the register allocation
-// changed. The compiler still forms v_max3_f32 from the nested maxima and v_pk_add_f32 for about half of the
-// two-element operations (it scalarises the rest: +240 v_add_f32 in the listing); measured cost 0.3 % of the kernel (2.334 against
-// 2.328 ms per pair over the nine self-attention launches), results bit-identical.
+// changed. The compiler forms v_max3_f32 from the nested maxima and v_pk_add_f32 from the two-element operations;
+// the packed adds stay packed only where no MFMA precedes them closely (see the scheduling fences in softmax_tile).
 __device__ __forceinline__ float max3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
 __device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) { return a + b; }
 __device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) { return a - b; }
@@ -141,6 +140,11 @@ __device__ __forceinline__ void softmax_tile(f32x16& sa, f32x16& sb, int kb, int
     const float m_use = (TAIL && m_run == -INFINITY) ? 0.f : m_run;
     const f32x2 mm = {m_use, m_use};
     f32x2 acc[4];
+    // The exp2 / row-sum section is fenced off from the scheduler on both sides: interleaved with the MFMAs of the neighbouring
+    // products, the compiler's late "unpack packed instructions in the shadow of an MFMA" peephole turns every v_pk_add_f32 that lands
+    // behind an MFMA into two v_add_f32 (it assumes VALU work is free there; on this part it is not, tools/mfma_peak.hip): 62 scalar
+    // + 31 packed adds per two tiles became 62 packed ones, 222 -> 191 vector instructions per two tiles, 236 -> 206 VGPRs, -1 %.
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         f32x2 pa = pk_sub(IM_PAIR(sa, i), mm), pb = pk_sub(IM_PAIR(sb, i), mm);
@@ -152,6 +156,7 @@ __device__ __forceinline__ void softmax_tile(f32x16& sa, f32x16& sb, int kb, int
         acc[i & 3] = i < 4 ? ps : pk_add(acc[i & 3], ps);
     }
     const f32x2 t2 = pk_add(pk_add(acc[0], acc[1]), pk_add(acc[2], acc[3]));
+    __builtin_amdgcn_sched_barrier(0);
     float rs = t2.x + t2.y;
     rs += __shfl_xor(rs, 32);
     l_run += rs;

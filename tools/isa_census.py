@@ -20,6 +20,8 @@ def main():
             seg.append((name, cur)); cur = []; name = l.split(":")[0]
         elif l.startswith("\t") and not l.strip().startswith((".", ";")):
             cur.append(l.strip())
+            if l.strip().startswith(("s_cbranch", "s_branch")):      # what follows a branch is another block (the fall-through)
+                seg.append((name, cur)); cur = []; name = name.split("+")[0] + "+"
     seg.append((name, cur))
     tot = collections.Counter()
     for n, c in seg:
