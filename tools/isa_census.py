@@ -13,7 +13,7 @@ def main():
     path, sym = sys.argv[1], sys.argv[2]
     lines = open(path).read().split("\n")
     start = next(i for i, l in enumerate(lines) if re.match(r"^_Z\w*" + re.escape(sym), l))
-    end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith("s_endpgm"))
+    end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
     seg, cur, name = [], [], "entry"
     for l in lines[start:end]:
         if re.match(r"^\.LBB\d+_\d+:", l):
