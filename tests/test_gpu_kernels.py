@@ -85,27 +85,31 @@ def test_gemm_asymmetric_layout(ctx):
     assert torch.equal(dc.cpu(), w.t())
 
 
+@pytest.mark.parametrize("relu", [1, 0])
 @pytest.mark.parametrize("cin,cout,h,w,pool", [(16, 64, 8, 32, 0), (64, 64, 37, 70, 0), (64, 128, 40, 64, 1), (128, 256, 17, 33, 0), (64, 64, 31, 47, 1)])
-def test_conv3x3(ctx, cin, cout, h, w, pool):
+def test_conv3x3(ctx, cin, cout, h, w, pool, relu):
     from icepy4d_amd._lib import ptr, stream_ptr
     g = torch.Generator().manual_seed(cin + cout + h)
     x = torch.randn(2, cin, h, w, generator=g)
     wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
     b = torch.randn(cout, generator=g)
-    ref = F.relu(F.conv2d(x.double(), wt.double(), b.double(), padding=1))
+    ref = F.conv2d(x.double(), wt.double(), b.double(), padding=1)
+    if relu:
+        ref = F.relu(ref)
     if pool:
         ref = F.max_pool2d(ref, 2, 2)
     dx = dev(x.permute(0, 2, 3, 1))
     ho, wo = ref.shape[-2:]
     dout = torch.full((2, ho, wo, cout), float("nan"), device="cuda")
-    ctx.call("im_conv3x3", ptr(dx), ptr(wt.contiguous()), ptr(b), ptr(dout), 2, h, w, cin, cout, 1, pool, stream_ptr())
+    ctx.call("im_conv3x3", ptr(dx), ptr(wt.contiguous()), ptr(b), ptr(dout), 2, h, w, cin, cout, relu, pool, stream_ptr())
     torch.cuda.synchronize()
     err = (dout.cpu().permute(0, 3, 1, 2).double() - ref).abs().max().item()
     assert err < 2e-5, err
 
 
+@pytest.mark.parametrize("relu", [1, 0])
 @pytest.mark.parametrize("cin,cout,h,w,pool", [(16, 64, 8, 32, 0), (64, 64, 37, 70, 0), (64, 128, 40, 64, 1), (128, 256, 17, 33, 0), (64, 64, 31, 47, 1)])
-def test_conv3x3_winograd(ctx, cin, cout, h, w, pool):
+def test_conv3x3_winograd(ctx, cin, cout, h, w, pool, relu):
     """Winograd F(2x2, 3x3) on the matrix cores against an fp64 direct convolution; its rounding error is a few 1e-6
     on O(1) outputs (the direct kernel is ~1e-6), far inside the 1e-4 budget of the path."""
     from icepy4d_amd._lib import ptr, stream_ptr
@@ -113,13 +117,15 @@ def test_conv3x3_winograd(ctx, cin, cout, h, w, pool):
     x = torch.randn(2, cin, h, w, generator=g)
     wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
     b = torch.randn(cout, generator=g)
-    ref = F.relu(F.conv2d(x.double(), wt.double(), b.double(), padding=1))
+    ref = F.conv2d(x.double(), wt.double(), b.double(), padding=1)
+    if relu:
+        ref = F.relu(ref)
     if pool:
         ref = F.max_pool2d(ref, 2, 2)
     dx = dev(x.permute(0, 2, 3, 1))
     ho, wo = ref.shape[-2:]
     dout = torch.full((2, ho, wo, cout), float("nan"), device="cuda")
-    ctx.call("im_conv3x3_winograd", ptr(dx), ptr(wt.contiguous()), ptr(b), ptr(dout), 2, h, w, cin, cout, 1, pool, stream_ptr())
+    ctx.call("im_conv3x3_winograd", ptr(dx), ptr(wt.contiguous()), ptr(b), ptr(dout), 2, h, w, cin, cout, relu, pool, stream_ptr())
     torch.cuda.synchronize()
     err = (dout.cpu().permute(0, 3, 1, 2).double() - ref).abs().max().item()
     assert err < 2e-5, err
