@@ -1,10 +1,18 @@
 #!/usr/bin/env python3
 """Experiment (build_abl copy): conv_wino.hip's slab step with the LDS operand reads written as inline asm, so that the compiler
 does not order them behind the LDS-DMA of the next slab with `s_waitcnt vmcnt(0)`: the transfer issued at the top of a step stays
-in flight during the step's reads, transform and MFMAs and is waited for at the barrier only."""
+in flight during the step's reads, transform and MFMAs and is waited for at the barrier only.
+The kernel source is taken from git revision b135164 (the version this experiment was written against).
+"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = open(os.path.join(ROOT, "icepy4d_amd", "csrc", "conv_wino.hip")).read()
+def kernel_source_at(rev):
+    """conv_wino.hip as it was at `rev`: the patches of this experiment are text replacements against that version of the kernel."""
+    import subprocess
+    return subprocess.run(["git", "-C", ROOT, "show", f"{rev}:icepy4d_amd/csrc/conv_wino.hip"], check=True, capture_output=True, text=True).stdout
+
+
+src = kernel_source_at("b135164")
 a = src.index("#define IM_SD(i, j) pa[a_slot")
 b = src.index("    const int nslab = a.Cin / WCC;")
 NEW = r'''    // LDS byte addresses of this lane's operand slots in stage 0 (stage 1: + S_SP * 4 resp. + W_SU * 4)

@@ -1,9 +1,18 @@
 #!/usr/bin/env python3
 """Experiment (build_abl copies only): the slab step of conv_wino.hip with the stage of slab + 1 issued AFTER the LDS reads of slab,
-with optional delays, to find out why that order gave wrong results in round 3."""
+with optional delays, to find out why that order gave wrong results in round 3.
+The kernel source is taken from git revision b135164 (the version this experiment was written against; needs the git history, i.e.
+the build step runs in the development container, the built libraries travel to the GPU box).
+"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src0 = open(os.path.join(ROOT, "icepy4d_amd", "csrc", "conv_wino.hip")).read()
+def kernel_source_at(rev):
+    """conv_wino.hip as it was at `rev`: the patches of this experiment are text replacements against that version of the kernel."""
+    import subprocess
+    return subprocess.run(["git", "-C", ROOT, "show", f"{rev}:icepy4d_amd/csrc/conv_wino.hip"], check=True, capture_output=True, text=True).stdout
+
+
+src0 = kernel_source_at("b135164")
 a = src0.index("#define IM_SMMA(slab)")
 b = src0.index("#undef IM_SSTAGE")
 NEW = r'''#define IM_SREAD(slab)                                                                                  \

@@ -8,9 +8,19 @@ wave 0 of every block records s_memtime
     D  behind the wait for the next slab's transfer,
     (next A) behind the barrier
 and the script prints the median lengths of the four segments in cycles.
-    python tools/conv_stamps.py build ; python tools/conv_stamps.py time [one_block]"""
+    python tools/conv_stamps.py build ; python tools/conv_stamps.py time [one_block]
+The kernel source is taken from git revision 956540c (the kernel the stamps were taken on: asm LDS-DMA, before the epilogue rewrite).
+"""
 import ctypes as C, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def kernel_source_at(rev):
+    """conv_wino.hip as it was at `rev`: the patches of this experiment are text replacements against that version of the kernel."""
+    import subprocess
+    return subprocess.run(["git", "-C", ROOT, "show", f"{rev}:icepy4d_amd/csrc/conv_wino.hip"], check=True, capture_output=True, text=True).stdout
+
+
 OUT = os.path.join(ROOT, "build_abl", "conv_stamps")
 
 
@@ -57,7 +67,7 @@ def build():
         for f in os.listdir(os.path.join(ROOT, "icepy4d_amd", "csrc")):
             if f.endswith(".h"):
                 open(os.path.join(out, "src", f), "w").write(open(os.path.join(ROOT, "icepy4d_amd", "csrc", f)).read().replace("../../include/icematch.h", os.path.join(ROOT, "include", "icematch.h")))
-        open(os.path.join(out, "src", "conv_wino.hip"), "w").write(patch(open(os.path.join(ROOT, "icepy4d_amd", "csrc", "conv_wino.hip")).read(), ob, ap))
+        open(os.path.join(out, "src", "conv_wino.hip"), "w").write(patch(kernel_source_at("956540c"), ob, ap))
         r = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-c", "conv_wino.hip", "-o", "conv_wino.o"], cwd=os.path.join(out, "src"), capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-3000:]
         objs = [os.path.join(ROOT, "icepy4d_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "icepy4d_amd", "csrc")) if f.endswith(".o") and f != "conv_wino.o"]
