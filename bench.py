@@ -34,6 +34,11 @@ H, W, KPTS = 1080, 1920, 4096
 H5, W5, KPTS5 = 3000, 4000, 16384
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix peak
 PEAK_HBM_GBS = 8000.0          # same guide: HBM3E spec peak (6.3 TB/s is what a copy kernel reaches)
+# Pairs per launch of the timed region (`--batch`): the batch dimension over pairs inside the kernels. Measured on one MI355X with two
+# launch groups in flight (round 3, three boxes): 2 -> 105.8, 4 -> 107.3, 5 -> 107.5, 8 -> 108.1, 10 -> 107.0-108 (the maximum on every box),
+# 16 -> 106.6, 25 -> 106.3 pairs/s; with the round driver's `--steps 20 --warmup 5`: 2 -> 104.1, 4 -> 106.0, 5 -> 106.2, 10 -> 106.9.
+# 10 divides the default 50 steps and the driver's 20. tests/test_gpu_fullsize.py checks this very mode against one pair per launch.
+DEFAULT_PAIRS_PER_LAUNCH = 10
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-derived HBM bytes per launch (latest round)
 
 
@@ -128,8 +133,8 @@ def main():
                          "case); translated = pure translation by (40, 8) px, ~2500 matches per pair")
     ap.add_argument("--no-graph", action="store_true", help="enqueue launches directly instead of replaying a HIP graph")
     ap.add_argument("--streams", type=int, default=2, help="launch groups in flight per GPU (independent contexts on separate HIP streams)")
-    ap.add_argument("--batch", type=int, default=2, help="pairs per launch (batch dimension over pairs inside the kernels); measured on "
-                                                         "one MI355X: 1 x 3 streams 98.6, 2 x 2 streams 103.0, 4 x 2 streams 95.1 pairs/s")
+    ap.add_argument("--batch", type=int, default=DEFAULT_PAIRS_PER_LAUNCH,
+                    help="pairs per launch (batch dimension over pairs inside the kernels); see DEFAULT_PAIRS_PER_LAUNCH for the measured sweep")
     ap.add_argument("--no-side-measurements", action="store_true", help="skip the short untimed-side runs (other launch mode, translated pairs)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: spawn / rendezvous / sharding / gather / JSON only")
     args = ap.parse_args()
@@ -225,7 +230,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # untimed warm-up: at least W steps, then batches of 16 pairs until the batch time stops falling (two consecutive
+    # untimed warm-up: at least W steps, then batches of >= 16 pairs (whole launch groups) until the batch time stops falling (two consecutive
     # batches within 2 %) or 20 s have passed. A cold MI355X needs seconds of sustained load, not milliseconds, to
     # settle its clocks: the first process on a fresh box measured 62-67 pairs/s after a 3 s warm-up and 83-85 in every
     # later process, with identical per-kernel durations at the end of both.
@@ -237,7 +242,8 @@ def main():
     sm.synchronize()
     t_w = time.perf_counter()
     prev, stable = None, 0
-    nb = 2 if cfg5 else 16
+    g_ = max(1, args.batch * n_streams)
+    nb = 2 if cfg5 else ((16 + g_ - 1) // g_) * g_      # whole launch groups: a partial group runs directly, not as the timed mode does
     while time.perf_counter() - t_w < 20.0 and stable < 2:
         t_b = time.perf_counter()
         for _ in range(nb):
@@ -299,7 +305,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": workload, "height": h, "width": w, "max_keypoints": kpts, "pairs_per_step": 1,
                    "pair_synthesis": args.pairs if not cfg5 else "translated", "hip_graph": not args.no_graph,
-                   "pairs_in_flight": n_streams, "pairs_per_launch": args.batch,
+                   "launch_groups_in_flight": n_streams, "pairs_per_launch": args.batch,
                    "attention": "fp32 MFMA",
                    "mean_keypoints": n0, "mean_matches": nm},
         "host_enqueue_ms_per_step": 1e3 * t_enq / args.steps, "untimed_pairs_before_timing": warm_pairs,
@@ -324,14 +330,15 @@ def main():
     if rank == 0 and world == 1 and not cfg5 and not args.no_side_measurements:
         # side measurements (not `value`): the other launch mode, and a pool of pairs on which the seeded weights DO find matches
         alt_b, alt_s = (1, 3) if args.batch > 1 else (2, 2)
+        n_side = ((48 + args.batch * n_streams - 1) // (args.batch * n_streams)) * args.batch * n_streams   # whole launch groups only
         alt = PairPipeline(make_engine, h, w, kpts, n_streams=alt_s, use_graph=not args.no_graph, matcher=m_name, pairs_per_launch=alt_b)
         r_alt, _ = quick_rate(alt, pool, 48)
         alt.close()
         tr_pool = [torch.from_numpy(np.stack(synthetic.translated_pair(j, h, w, 40, 8))).cuda().contiguous() for j in range(2)]
-        r_tr, m_tr = quick_rate(sm, tr_pool, 48)
+        r_tr, m_tr = quick_rate(sm, tr_pool, n_side)
         # the same pairs handed over in HOST memory (what the reference's epoch loop holds after imread): page-locked staging
         # ring + asynchronous upload on the launch stream, PCIe inside the measured time
-        r_host, _ = quick_rate(sm, host_pairs, 48, host=True)
+        r_host, _ = quick_rate(sm, host_pairs, n_side, host=True)
         adaptive = {}
         for variant in ("earlystop", "prune"):   # weights whose token confidences stop early / whose matchabilities prune points
             v_sd = synthetic.lightglue_state_dict(0, variant)
@@ -343,27 +350,27 @@ def main():
                 return e
             vp = PairPipeline(make_variant_engine, h, w, kpts, n_streams=n_streams, use_graph=not args.no_graph, matcher=m_name,
                               pairs_per_launch=args.batch)
-            side = new_table(48, kpts, eng.device)
-            for j in range(12):
+            side = new_table(n_side, kpts, eng.device)
+            for j in range(args.batch * n_streams):
                 vp.match_pair(tr_pool[j % 2], j, side, j)
             vp.flush(); vp.synchronize()
             t_v = time.perf_counter()
-            for j in range(48):
+            for j in range(n_side):
                 vp.match_pair(tr_pool[j % 2], j, side, j)
             vp.flush(); vp.synchronize()
-            adaptive[variant] = {"pairs_per_s": 48 / (time.perf_counter() - t_v), "mean_stop_layer": side[:, 4].float().mean().item(),
-                                 "mean_matches": side[:, 3].float().mean().item(), "pairs": 48}
+            adaptive[variant] = {"pairs_per_s": n_side / (time.perf_counter() - t_v), "mean_stop_layer": side[:, 4].float().mean().item(),
+                                 "mean_matches": side[:, 3].float().mean().item(), "pairs": n_side}
             vp.close()
         result["side_measurements"] = {
             "adaptive_depth_and_width": dict(adaptive, note="the same launches with seeded weights built so that the early-stop criterion "
                                              "(`lightglue.py:571-579`) resp. point pruning (`:563-568`) DO trigger on the translated pairs: the "
                                              "device-side stop flag skips the remaining layers' kernels, pruned images run on the live rows only"),
-            "other_launch_mode": {"pairs_per_launch": alt_b, "pairs_in_flight": alt_s, "pairs_per_s": r_alt, "pairs": 48},
-            "host_inputs_pairs_per_s": {"pairs_per_s": r_host, "pairs": 48,
+            "other_launch_mode": {"pairs_per_launch": alt_b, "launch_groups_in_flight": alt_s, "pairs_per_s": r_alt, "pairs": 48},
+            "host_inputs_pairs_per_s": {"pairs_per_s": r_host, "pairs": n_side,
                                         "note": "PCIe-inclusive: every pair starts as a numpy uint8 array in pageable host memory, is copied "
                                                 "into a page-locked staging ring and uploaded asynchronously on the launch stream "
                                                 "(`PairPipeline.match_host_pair`); never `value`"},
-            "translated_pairs": {"pairs_per_s": r_tr, "mean_matches": m_tr, "pairs": 48,
+            "translated_pairs": {"pairs_per_s": r_tr, "mean_matches": m_tr, "pairs": n_side,
                                  "note": "pairs related by a pure (40, 8) px translation: the seeded weights match ~1000 keypoints "
                                          "per pair on them (8 on the homography-warped pairs of `value`); same launches, no pruning or "
                                          "early exit triggers with seeded weights either way"}}

@@ -96,20 +96,24 @@ def test_config5_12mp_superglue_properties():
 
 
 def test_config3_timed_launch_mode_equals_direct_launches_and_the_oracle():
-    """BASELINE configs[2] in EXACTLY the launch mode `bench.py` times - `PairPipeline(pairs_per_launch=2, n_streams=2,
-    use_graph=True)`: two pairs share every launch, two launch groups in flight on separate streams, HIP-graph replay - at full
-    size (1080 x 1920, 4096 keypoints), over 8 distinct epochs (six of the sequence's homography-warped pairs, two translated
+    """BASELINE configs[2] in EXACTLY the launch mode `bench.py` times - `PairPipeline(pairs_per_launch=bench.DEFAULT_PAIRS_PER_LAUNCH,
+    n_streams=2, use_graph=True)`: ten pairs share every launch, two launch groups in flight on separate streams, HIP-graph replay -
+    at full size (1080 x 1920, 4096 keypoints), over 20 distinct epochs (18 of the sequence's homography-warped pairs, two translated
     pairs with ~1000 matches): the match table is bit-identical to one pair per direct launch on one stream, and two of its
     records decode to the oracle's matches (reference loop: `main_dev.py:60`, matcher call `main_dev.py:115-132`)."""
+    import bench
     from icepy4d_amd.engine import Engine
     from icepy4d_amd import sequence as sq
     from margins import assert_same_matches
     from oracle import ref_cpu as o
     lg_sd = synthetic.lightglue_state_dict(0, "passthrough")
     H, W, K = 1080, 1920, 4096
-    pairs_np = [synthetic.stereo_pair(e, H, W) for e in range(6)] + [synthetic.translated_pair(s, H, W, 40, 8) for s in (6, 7)]
+    P = bench.DEFAULT_PAIRS_PER_LAUNCH
+    n_st = 2 * P - 2
+    pairs_np = [synthetic.stereo_pair(e, H, W) for e in range(n_st)] + [synthetic.translated_pair(s, H, W, 40, 8) for s in (6, 7)]
     pairs = [torch.from_numpy(np.stack(p)).cuda() for p in pairs_np]
-    epochs = list(range(100, 108))
+    epochs = list(range(100, 100 + len(pairs)))
+    checked = (2, len(pairs) - 1)                          # a homography-warped pair and a translated one
 
     def make_engine():
         e = Engine(0)
@@ -117,7 +121,7 @@ def test_config3_timed_launch_mode_equals_direct_launches_and_the_oracle():
         e.load_state_dict("lightglue", lg_sd)
         return e
 
-    pipe = sq.PairPipeline(make_engine, H, W, K, n_streams=2, use_graph=True, pairs_per_launch=2)
+    pipe = sq.PairPipeline(make_engine, H, W, K, n_streams=2, use_graph=True, pairs_per_launch=P)
     timed = sq.new_table(len(pairs), K, pipe.device)
     for _ in range(2):                                      # the second pass replays graphs whose buffers hold the first pass
         for row, (p, ep) in enumerate(zip(pairs, epochs)):
@@ -133,14 +137,14 @@ def test_config3_timed_launch_mode_equals_direct_launches_and_the_oracle():
     kp_dev = {}
     for row, (p, ep) in enumerate(zip(pairs, epochs)):
         direct.match_pair(p, ep, ref_tab, row)
-        if row in (2, 7):
+        if row in checked:
             torch.cuda.synchronize()
             kp_dev[row] = (e.features_to_host(0)[0], e.features_to_host(1)[0])
     torch.cuda.synchronize()
     assert torch.equal(timed, ref_tab.cpu())
     assert timed[:, 0].tolist() == epochs and (timed[:, 1] == K).all() and (timed[:, 2] == K).all() and (timed[:, 4] == 9).all()
     torch.set_num_threads(min(32, torch.get_num_threads()))
-    for row in (2, 7):
+    for row in checked:
         rec = sq.decode_record(timed[row].numpy(), K)
         F0, F1, m0, mconf, ref = o.match_images_lightglue(*pairs_np[row], SP_SD, lg_sd, max_keypoints=K)
         k0, k1 = kp_dev[row]
@@ -151,7 +155,7 @@ def test_config3_timed_launch_mode_equals_direct_launches_and_the_oracle():
             import margins
             ours, theirs = margins.match_pairs(k0, k1, rec["matches0"]), margins.match_pairs(F0[0], F1[0], m0)
             assert len(ours & theirs) >= len(theirs) - 8 and len(ours) <= len(theirs) + 8
-        assert rec["n_matches"] > (500 if row == 7 else 0)
+        assert rec["n_matches"] > (500 if row == checked[1] else 0)
     e.close()
 
 
@@ -159,7 +163,7 @@ def test_config3_timed_launch_mode_equals_direct_launches_and_the_oracle():
                                    ["--steps", "4", "--warmup", "2", "--config", "4", "--pool", "2"]])
 def test_bench_line_with_odd_step_counts(flags):
     """`python bench.py --gpus 1 --steps K --warmup W` as the round driver types it, with counts that do not fill the launch
-    groups of two pairs: one JSON line with the contract fields, every step recorded, a throughput in the range of the device
+    groups (ten pairs each by default): one JSON line with the contract fields, every step recorded, a throughput in the range of the device
     (an odd warm-up once left a parked pair behind and shifted every timed group: 93 instead of 102 pairs/s at K = 20, W = 5)."""
     import json
     import os

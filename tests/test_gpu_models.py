@@ -891,15 +891,15 @@ def test_lightglue_pairs_share_launches_bit_identically():
 
 
 def test_sequence_pairs_per_launch_equals_one_by_one():
-    """SequenceMatcher / PairPipeline with pairs_per_launch = 2 (graph and direct): records bit-identical to one pair per
-    launch, including a partial last group (5 pairs)."""
+    """SequenceMatcher / PairPipeline with pairs_per_launch = 2, 5 and 10 (graph and direct): records bit-identical to one pair per
+    launch, including a partial last group (5 pairs: 2 + 2 + 1, one full group of 5, half a group of 10)."""
     from icepy4d_amd.engine import Engine
     from icepy4d_amd import sequence as sq
     lg_sd = synthetic.lightglue_state_dict(0, "passthrough")
     pairs = [torch.from_numpy(np.stack(synthetic.translated_pair(s, 136, 200))).cuda() for s in (1, 2, 3, 4, 5)]
     epochs = [20, 21, 22, 23, 24]
     tabs = []
-    for P, use_graph in ((1, False), (2, False), (2, True)):
+    for P, use_graph in ((1, False), (2, False), (2, True), (5, True), (10, True)):
         e = Engine(0)
         e.load_state_dict("superpoint", SP_SD)
         e.load_state_dict("lightglue", lg_sd)
@@ -907,7 +907,7 @@ def test_sequence_pairs_per_launch_equals_one_by_one():
         tabs.append(sm.run(pairs, epochs).cpu())
         torch.cuda.synchronize()
         e.close()
-    assert torch.equal(tabs[0], tabs[1]) and torch.equal(tabs[0], tabs[2])
+    assert all(torch.equal(tabs[0], t) for t in tabs[1:])
     assert tabs[0][:, 0].tolist() == epochs and (tabs[0][:, 3] > 20).all()
 
 
