@@ -18,7 +18,7 @@ python3 $root/bench.py --config 3 --no-cpu-baseline > $out/bench_config3.json 2>
 # (c) two ranks sharing cuda:0 over gloo (IM_BENCH_ONE_DEVICE=1): the N > 1 code path end to end with real GPU work
 python3 $root/bench.py --config 4 --steps 256 --no-cpu-baseline --no-side-measurements > $out/bench_config4_1gpu_256epochs.json 2> $out/bench_config4.err
 IM_BENCH_FORCE_DIST=1 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 $root/bench.py --gpus 1 --config 4 --steps 64 --no-cpu-baseline --no-side-measurements > $out/bench_config4_nccl_world1.json 2> $out/bench_config4_nccl.err
-IM_BENCH_ONE_DEVICE=1 python3 $root/bench.py --gpus 2 --steps 24 --warmup 4 --no-cpu-baseline --no-side-measurements > $out/bench_2ranks_one_device_gloo.json 2> $out/bench_2ranks.err
+IM_BENCH_ONE_DEVICE=1 python3 $root/bench.py --gpus 2 --steps 40 --warmup 10 --no-cpu-baseline --no-side-measurements > $out/bench_2ranks_one_device_gloo.json 2> $out/bench_2ranks.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_config5 -- python3 $root/bench.py --config 5 --steps 3 --warmup 1 > $out/bench_config5_under_rocprof.json 2> /dev/null
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_lg_$c -- python3 $root/tools/run_pair_once.py lightglue 2 > /dev/null 2>&1
