@@ -349,19 +349,23 @@ __device__ __forceinline__ AssignArgs for_pair(AssignArgs a, int pr) {
     return a;
 }
 
-// 16 values of row `p` (chunk base c0): columns c0 + q * 256 + lane * 4 + e; entries >= n read as AS_NEG
+// 16 values of row `p` (chunk base c0): columns c0 + q * 256 + lane * 4 + e; entries >= n read as AS_NEG. Branch-free: a quad that
+// starts past the row's end is loaded from the row's last quad instead and masked (n = 0 masks the whole row: callers pass that for
+// rows past the strip's end). With the loads behind `if (j < n)` every load was a basic block of its own, the compiler collected the
+// loads of all 16 rows of a strip at the top of the chunk loop, and the sweeps needed 284-320 registers: one wave per SIMD.
 template <bool VEC>
 __device__ __forceinline__ void load_row16(const float* __restrict__ p, int c0, int lane, int n, float (&x)[16]) {
+    const int last = max(n - 1, 0);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int j = c0 + q * 256 + lane * 4;
         if constexpr (VEC) {
-            float4 v = make_float4(AS_NEG, AS_NEG, AS_NEG, AS_NEG);
-            if (j < n) v = *reinterpret_cast<const float4*>(p + j);      // ld % 4 == 0: the quad lies inside the row's storage
-            x[4 * q] = v.x; x[4 * q + 1] = (j + 1 < n) ? v.y : AS_NEG; x[4 * q + 2] = (j + 2 < n) ? v.z : AS_NEG; x[4 * q + 3] = (j + 3 < n) ? v.w : AS_NEG;
+            const float4 v = *reinterpret_cast<const float4*>(p + min(j, last & ~3));   // ld % 4 == 0: the quad lies inside the row's storage
+            x[4 * q] = (j < n) ? v.x : AS_NEG; x[4 * q + 1] = (j + 1 < n) ? v.y : AS_NEG;
+            x[4 * q + 2] = (j + 2 < n) ? v.z : AS_NEG; x[4 * q + 3] = (j + 3 < n) ? v.w : AS_NEG;
         } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) x[4 * q + e] = (j + e < n) ? p[j + e] : AS_NEG;
+            for (int e = 0; e < 4; ++e) x[4 * q + e] = (j + e < n) ? p[min(j + e, last)] : AS_NEG;
         }
     }
 }
@@ -370,9 +374,13 @@ __device__ __forceinline__ void load_row16(const float* __restrict__ p, int c0, 
 // sweeps below evaluate 2.3 of them per matrix entry). Relative error <= 2^-22 for |x| < 16, growing with |x| * 2^-24.
 __device__ __forceinline__ float fexp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
 
+// The running (max, sum) of the strip's 16 rows live in LDS between row groups ([row][thread]: every thread touches its own slots only,
+// no synchronisation), so that the row groups are a real loop - four rows of loads in flight, then their arithmetic - instead of 16 rows
+// of registers: 320 -> 118 registers (four waves per SIMD instead of one), same operations in the same order (results bit-identical).
 template <bool VEC>
-__global__ __launch_bounds__(256) void lse_stats_kernel(AssignArgs aa) {
+__global__ __launch_bounds__(256, 4) void lse_stats_kernel(AssignArgs aa) {
     __shared__ float2 rs[AS_ROWS][4];
+    __shared__ float2 rst[AS_ROWS][256];
     const AssignArgs a = for_pair(aa, blockIdx.y);
     const float* __restrict__ sim = a.sim;
     const int ld = a.ld, kmax = a.n_max;
@@ -383,38 +391,32 @@ __global__ __launch_bounds__(256) void lse_stats_kernel(AssignArgs aa) {
     if (i0 >= m || n <= 0) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nrow = min(AS_ROWS, m - i0);
-    float rM[AS_ROWS], rS[AS_ROWS];
 #pragma unroll
-    for (int r = 0; r < AS_ROWS; ++r) { rM[r] = AS_NEG; rS[r] = 0.f; }
+    for (int r = 0; r < AS_ROWS; ++r) rst[r][tid] = make_float2(AS_NEG, 0.f);
     for (int c0 = wave * AS_CHUNK; c0 < n; c0 += 4 * AS_CHUNK) {
         float cM[16], cS[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) { cM[e] = AS_NEG; cS[e] = 0.f; }
-#pragma unroll
+#pragma unroll 1
         for (int g = 0; g < AS_ROWS / 4; ++g) {
             float x[4][16];
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
-                const int r = 4 * g + rr;
-                if (r < nrow) load_row16<VEC>(sim + (long)(i0 + r) * ld, c0, lane, n, x[rr]);
-                else {
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) x[rr][e] = AS_NEG;
-                }
+                const int r = 4 * g + rr;      // rows past the strip's end: clamped address, every column masked
+                load_row16<VEC>(sim + (long)min(i0 + r, m - 1) * ld, c0, lane, r < nrow ? n : 0, x[rr]);
             }
             // rows: one online step per row with the lane's 16 entries
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
-                const int r = 4 * g + rr;
+                const float2 st = rst[4 * g + rr][tid];
                 float mx = x[rr][0];
 #pragma unroll
                 for (int e = 1; e < 16; ++e) mx = fmaxf(mx, x[rr][e]);
-                const float nm = fmaxf(rM[r], mx);
+                const float nm = fmaxf(st.x, mx);
                 float acc = 0.f;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc += fexp(x[rr][e] - nm);
-                rS[r] = rS[r] * fexp(rM[r] - nm) + acc;
-                rM[r] = nm;
+                rst[4 * g + rr][tid] = make_float2(nm, st.y * fexp(st.x - nm) + acc);
             }
             // columns: one online step per column with these four rows
 #pragma unroll
@@ -434,10 +436,11 @@ __global__ __launch_bounds__(256) void lse_stats_kernel(AssignArgs aa) {
                 if (j < n) cp[j] = make_float2(cM[4 * q + e], cS[4 * q + e]);   // rows >= nrow contributed exp(AS_NEG - max) = 0
             }
     }
-#pragma unroll
+#pragma unroll 4
     for (int r = 0; r < AS_ROWS; ++r) {
-        const float M = wave_max(rM[r]);
-        const float S = wave_sum(rS[r] * fexp(rM[r] - M));
+        const float2 st = rst[r][tid];
+        const float M = wave_max(st.x);
+        const float S = wave_sum(st.y * fexp(st.x - M));
         if (lane == 0) rs[r][wave] = make_float2(M, S);
     }
     __syncthreads();
@@ -514,10 +517,12 @@ __device__ __forceinline__ float assign_score(float x, float rm, float rl, float
 // One sweep: row arg-max (first column among ties: torch.max semantics) complete per block; per-strip column arg-max keys
 // (ordered score bits, ~row): a larger key = a larger score or, at equal score, a lower row.
 template <int MODE, bool VEC>
-__global__ __launch_bounds__(256) void best_sweep_kernel(AssignArgs aa) {
+__global__ __launch_bounds__(256, 3) void best_sweep_kernel(AssignArgs aa) {
     __shared__ float rb_v[AS_ROWS][4];
     __shared__ int rb_j[AS_ROWS][4];
     __shared__ float sh_rm[AS_ROWS], sh_rl[AS_ROWS], sh_l0[AS_ROWS];
+    __shared__ float pbv[AS_ROWS][256];     // the lanes' running row maxima between row groups (as lse_stats_kernel's rst)
+    __shared__ int pbj[AS_ROWS][256];
     const AssignArgs a = for_pair(aa, blockIdx.y);
     const float* __restrict__ sim = a.sim;
     const int ld = a.ld, kmax = a.n_max;
@@ -537,11 +542,9 @@ __global__ __launch_bounds__(256) void best_sweep_kernel(AssignArgs aa) {
         sh_rl[tid] = MODE == 0 ? rlog[i] : rlog[0];
         sh_l0[tid] = MODE == 0 ? lz0[i] : 0.f;
     }
-    __syncthreads();
-    float bv[AS_ROWS];
-    int bj[AS_ROWS];
 #pragma unroll
-    for (int r = 0; r < AS_ROWS; ++r) { bv[r] = -INFINITY; bj[r] = 0x7fffffff; }
+    for (int r = 0; r < AS_ROWS; ++r) { pbv[r][tid] = -INFINITY; pbj[r][tid] = 0x7fffffff; }
+    __syncthreads();
     for (int c0 = wave * AS_CHUNK; c0 < n; c0 += 4 * AS_CHUNK) {
         float cm[16], cl[16], l1[16], cbv[16];
         int cbi[16];
@@ -556,18 +559,20 @@ __global__ __launch_bounds__(256) void best_sweep_kernel(AssignArgs aa) {
                 cbv[4 * q + e] = -INFINITY;
                 cbi[4 * q + e] = -1;
             }
+#pragma unroll 1
+        for (int g = 0; g < AS_ROWS / 2; ++g) {      // two rows per trip: 155 registers = three waves per SIMD (four rows: 187 = two)
+            if (2 * g >= nrow) break;     // block-uniform
+            float x[2][16];
 #pragma unroll
-        for (int g = 0; g < AS_ROWS / 4; ++g) {
-            if (4 * g >= nrow) break;     // block-uniform
-            float x[4][16];
+            for (int rr = 0; rr < 2; ++rr)      // two rows = 8 sixteen-byte loads in flight per lane
+                load_row16<VEC>(sim + (long)min(i0 + 2 * g + rr, m - 1) * ld, c0, lane, n, x[rr]);
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr)      // four rows = 16 sixteen-byte loads in flight per lane
-                load_row16<VEC>(sim + (long)min(i0 + 4 * g + rr, m - 1) * ld, c0, lane, n, x[rr]);
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const int r = 4 * g + rr;
+            for (int rr = 0; rr < 2; ++rr) {
+                const int r = 2 * g + rr;
                 if (r >= nrow) break;     // block-uniform
                 const float rm = sh_rm[r], rl = sh_rl[r], l0 = sh_l0[r];
+                float bv = pbv[r][tid];
+                int bj = pbj[r][tid];
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -576,10 +581,12 @@ __global__ __launch_bounds__(256) void best_sweep_kernel(AssignArgs aa) {
                         const int k = 4 * q + e;
                         const float v = assign_score<MODE>(x[rr][k], rm, rl, cm[k], cl[k], l0, l1[k]);
                         if (j < n) {
-                            if (v > bv[r] || bj[r] == 0x7fffffff) { bv[r] = v; bj[r] = j; }      // ascending j in a lane's visit order
+                            if (v > bv || bj == 0x7fffffff) { bv = v; bj = j; }      // ascending j in a lane's visit order
                             if (v > cbv[k] || cbi[k] < 0) { cbv[k] = v; cbi[k] = i0 + r; }
                         }
                     }
+                pbv[r][tid] = bv;
+                pbj[r][tid] = bj;
             }
         }
         unsigned long long* cb = cbpart + (long)blockIdx.x * kmax;
@@ -592,10 +599,10 @@ __global__ __launch_bounds__(256) void best_sweep_kernel(AssignArgs aa) {
             }
     }
     // rows: lanes / chunks visit columns out of order, so ties resolve on the column index explicitly
-#pragma unroll
+#pragma unroll 4
     for (int r = 0; r < AS_ROWS; ++r) {
-        float v = bv[r];
-        int j = bj[r];
+        float v = pbv[r][tid];
+        int j = pbj[r][tid];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             const float ov = __shfl_xor(v, off);
