@@ -378,7 +378,7 @@ __device__ __forceinline__ float fexp(float x) { return __builtin_amdgcn_exp2f(x
 // no synchronisation), so that the row groups are a real loop - four rows of loads in flight, then their arithmetic - instead of 16 rows
 // of registers: 320 -> 118 registers (four waves per SIMD instead of one), same operations in the same order (results bit-identical).
 template <bool VEC>
-__global__ __launch_bounds__(256, 4) void lse_stats_kernel(AssignArgs aa) {
+__global__ __launch_bounds__(256, VEC ? 4 : 3) void lse_stats_kernel(AssignArgs aa) {
     __shared__ float2 rs[AS_ROWS][4];
     __shared__ float2 rst[AS_ROWS][256];
     const AssignArgs a = for_pair(aa, blockIdx.y);
