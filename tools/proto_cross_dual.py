@@ -133,7 +133,7 @@ def time_it():
     from icepy4d_amd import _lib
     from icepy4d_amd._lib import ptr, stream_ptr
     ctx = _lib.Context(0)
-    n, B = 4096, 4                                    # two pairs per launch, as bench.py's default mode
+    n, B = 4096, 4                                    # two pairs per launch, bench.py's default mode when this was measured
     q = torch.randn(B, 4, n, 64, device="cuda"); v = torch.randn_like(q)
     out = torch.empty(B, n, 256, device="cuda")
     dn = torch.full((B,), n, dtype=torch.int32, device="cuda")
