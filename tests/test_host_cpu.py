@@ -605,3 +605,30 @@ def test_engine_reserve_failure_forgets_the_stale_workspace():
     assert (e.max_h, e.max_w, e.max_images, e.max_kpts) == (0, 0, 0, 0) and e.graphs == {} and e.generation > gen
     e.reserve(32, 32, 2, 64)                        # smaller than the stale sizes: must still call the library
     assert len(e.ctx.calls) == 3 and e.ctx.calls[-1][1] == (32, 32, 2, 64) and e.max_kpts == 64
+
+
+def test_kernels_keep_their_register_budget(tmp_path):
+    """Occupancy is a property of the compiled code, not of the source: the assignment sweeps once needed 284-320 registers (every row
+    load a basic block of its own, all of a strip's loads collected at the top of the loop) and ran at one wave per SIMD whatever the
+    grid. Compile the HBM / latency-bound kernels' file for gfx950 (no GPU needed) and hold every kernel to the budget its launch
+    bounds promise: no scratch spills, `lse_stats` <= 128 VGPRs (four waves per SIMD), `best_sweep` <= 168 (three)."""
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    out = tmp_path / "lg_misc.s"
+    r = subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only", "-I" + os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "icepy4d_amd", "csrc", "lg_misc.hip"), "-o", str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    seen = {}
+    for blk in re.split(r"\n  - \.agpr_count:", out.read_text())[1:]:
+        def field(k):
+            m = re.search(r"\." + k + r":\s+(\S+)", blk)
+            return m.group(1) if m else "0"
+        seen[field("name")] = (int(field("vgpr_count")), int(field("vgpr_spill_count")))
+    assert len(seen) >= 20
+    assert all(spill == 0 for _, spill in seen.values()), {k: v for k, v in seen.items() if v[1]}
+    lse = [v for k, v in seen.items() if "lse_stats_kernelILb1" in k]
+    best = [v for k, v in seen.items() if "best_sweep_kernel" in k]
+    assert lse and best
+    assert all(v <= 128 for v, _ in lse), lse
+    assert all(v <= 168 for v, _ in best), best
