@@ -39,6 +39,7 @@ PEAK_HBM_GBS = 8000.0          # same guide: HBM3E spec peak (6.3 TB/s is what a
 # 16 -> 106.6, 25 -> 106.3 pairs/s; with the round driver's `--steps 20 --warmup 5`: 2 -> 104.1, 4 -> 106.0, 5 -> 106.2, 10 -> 106.9.
 # 10 divides the default 50 steps and the driver's 20. tests/test_gpu_fullsize.py checks this very mode against one pair per launch.
 DEFAULT_PAIRS_PER_LAUNCH = 10
+SIDE_CONFIG3_EPOCHS = 60         # distinct epochs of the default line's `side_measurements.config3_distinct_epochs`
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-derived HBM bytes per launch (latest round)
 
 
@@ -98,16 +99,21 @@ def _make_pair(job):
     return np.stack([a, b])
 
 
-def make_pairs(kind, epochs, h, w, world):
-    """Host-side synthesis of the input pairs (about 1-2 s each at 1080p). MUST run before this process initialises the GPU:
-    the workers are forked."""
-    jobs = [(kind, e, h, w) for e in epochs]
+def make_pairs(jobs, world):
+    """Host-side synthesis of the input pairs, jobs = [(kind, epoch, h, w)] (about 1-2 s each at 1080p, ~10 s at 12 MP). MUST run
+    before this process initialises the GPU: the workers are forked."""
+    jobs = list(jobs)
     workers = max(1, min(len(jobs), 32, (os.cpu_count() or 1) // max(world, 1)))
     if workers == 1:
         return [_make_pair(j) for j in jobs]
     import multiprocessing as mp
+    order = sorted(range(len(jobs)), key=lambda i: -jobs[i][2] * jobs[i][3])     # the 12 MP pair first: it is the longest job
     with mp.get_context("fork").Pool(workers) as pool:
-        return pool.map(_make_pair, jobs)
+        made = pool.map(_make_pair, [jobs[i] for i in order], chunksize=1)
+    out = [None] * len(jobs)
+    for i, m in zip(order, made):
+        out[i] = m
+    return out
 
 
 def cpu_model():
@@ -161,18 +167,42 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # IM_BENCH_ISOLATE_DEVICES=1 (default off; the fallback if a plain N > 1 run faults on a device index other than 0): every rank
+    # sees ONLY its own GPU, as device 0 - i.e. it runs exactly the single-GPU path every test exercises. Decided here, before
+    # anything in this process has touched the HIP runtime (torch is not even imported yet); never by re-executing the process.
+    isolate = os.environ.get("IM_BENCH_ISOLATE_DEVICES") == "1" and world > 1
+    if isolate:
+        seen = [d for d in os.environ.get("HIP_VISIBLE_DEVICES", "").split(",") if d.strip() != ""]
+        mine = seen[local_rank] if seen else str(local_rank)       # index into a list the launcher may already have narrowed
+        os.environ["HIP_VISIBLE_DEVICES"] = mine
+        local_rank = 0
 
     from icepy4d_amd.sequence import shard_epochs
     total = args.warmup + args.steps
     epochs = shard_epochs(total * world, rank, world)           # this rank's epochs: e = rank (mod world)
     cfg5 = args.config == 5
     h, w, kpts = (H5, W5, KPTS5) if cfg5 else (H, W, KPTS)
+    # side measurements of the default line (rank 0 of a one-rank run, headline config only): their inputs are synthesised here too,
+    # BEFORE the GPU is initialised (forked workers)
+    side_on = world == 1 and args.config == 2 and not args.no_side_measurements and not args.dry_run
+    side_inputs = {}
     if args.dry_run:
         host_pairs = []
     elif args.config == 3:
-        host_pairs = make_pairs(args.pairs, epochs, h, w, world)                           # every epoch distinct
+        host_pairs = make_pairs([(args.pairs, e, h, w) for e in epochs], world)            # every epoch distinct
     else:
-        host_pairs = make_pairs("translated" if cfg5 else args.pairs, epochs[:min(args.pool, total)], h, w, world)
+        jobs = [("translated" if cfg5 else args.pairs, e, h, w) for e in epochs[:min(args.pool, total)]]
+        n_main = len(jobs)
+        if side_on:
+            g_side = max(1, args.batch * args.streams)
+            n_c3 = ((SIDE_CONFIG3_EPOCHS + g_side - 1) // g_side) * g_side                  # whole launch groups only
+            jobs += [("stereo", e, H, W) for e in range(n_c3)]                              # configs[2]: distinct epochs 0 .. n_c3 - 1
+            jobs += [("translated", j, H, W) for j in range(2)]
+            jobs += [("translated", 0, H5, W5)]                                             # configs[4]: one 12 MP pair
+        made = make_pairs(jobs, world)
+        host_pairs = made[:n_main]
+        if side_on:
+            side_inputs = {"config3": made[n_main:n_main + n_c3], "translated": made[n_main + n_c3:n_main + n_c3 + 2], "config5": made[-1]}
 
     import numpy as np
     import torch
@@ -282,6 +312,7 @@ def main():
         # what lets a reader verify that N ranks really took part: every rank reports its own pair count, its own time to finish
         # them and its time inside the all-gather (one more tiny all-gather, outside the timed region)
         ranks = rank_report(dist, rank, world, args, t_own, t_gather, torch.cuda.current_device(), dev_, table, full, cpu_group)
+        ranks["device_names"] = sorted({torch.cuda.get_device_name(torch.cuda.current_device())})
     n_pairs = args.steps * world
     assert full.shape[0] == n_pairs, (full.shape, n_pairs)
     nm = full[:, 3].float().mean().item()
@@ -314,31 +345,41 @@ def main():
     if ranks is not None:
         result["ranks"] = ranks
 
-    def quick_rate(pipe, inputs, n, host=False):
-        """Untimed-warm, short side measurement on this rank: pairs/s of `pipe` over n pairs of `inputs`."""
-        side = new_table(n, kpts, eng.device, with_kp)
+    def quick_rate(pipe, inputs, n, host=False, epoch0=0, keep=None):
+        """Untimed-warm, short side measurement on this rank: pairs/s of `pipe` over n pairs of `inputs` (whole launch groups of
+        warm-up first). `keep`: a table that receives the timed records."""
+        side = keep if keep is not None else new_table(n, kpts, eng.device, with_kp)
         feed = pipe.match_host_pair if host else pipe.match_pair
-        for j in range(min(n, 12)):
-            feed(inputs[j % len(inputs)], j, side, j)
+        for j in range(min(n, len(pipe.slots) * pipe.slots[0][2].P)):
+            feed(inputs[j % len(inputs)], epoch0 + j, side, j)
         pipe.flush(); pipe.synchronize()
         t = time.perf_counter()
         for j in range(n):
-            feed(inputs[j % len(inputs)], j, side, j)
+            feed(inputs[j % len(inputs)], epoch0 + j, side, j)
         pipe.flush(); pipe.synchronize()
         return n / (time.perf_counter() - t), side[:, 3].float().mean().item()
 
-    if rank == 0 and world == 1 and not cfg5 and not args.no_side_measurements:
+    if rank == 0 and side_on:
         # side measurements (not `value`): the other launch mode, and a pool of pairs on which the seeded weights DO find matches
+        t_side = time.perf_counter()
         alt_b, alt_s = (1, 3) if args.batch > 1 else (2, 2)
         n_side = ((48 + args.batch * n_streams - 1) // (args.batch * n_streams)) * args.batch * n_streams   # whole launch groups only
-        alt = PairPipeline(make_engine, h, w, kpts, n_streams=alt_s, use_graph=not args.no_graph, matcher=m_name, pairs_per_launch=alt_b)
+        alt = PairPipeline(make_engine, h, w, kpts, n_streams=alt_s, use_graph=not args.no_graph, matcher=m_name, pairs_per_launch=alt_b,
+                           with_keypoints=with_kp)
         r_alt, _ = quick_rate(alt, pool, 48)
         alt.close()
-        tr_pool = [torch.from_numpy(np.stack(synthetic.translated_pair(j, h, w, 40, 8))).cuda().contiguous() for j in range(2)]
+        tr_pool = [torch.from_numpy(p).cuda().contiguous() for p in side_inputs["translated"]]
         r_tr, m_tr = quick_rate(sm, tr_pool, n_side)
         # the same pairs handed over in HOST memory (what the reference's epoch loop holds after imread): page-locked staging
         # ring + asynchronous upload on the launch stream, PCIe inside the measured time
         r_host, _ = quick_rate(sm, host_pairs, n_side, host=True)
+        # configs[2]: the timed launch mode over DISTINCT epochs (seeds 1234 + 2e / 1235 + 2e, slowly varying homography), whole
+        # launch groups; inputs resident in HBM like the headline's
+        c3_pool = [torch.from_numpy(p).cuda().contiguous() for p in side_inputs["config3"]]
+        c3_table = new_table(len(c3_pool), kpts, eng.device, with_kp)
+        r_c3, m_c3 = quick_rate(sm, c3_pool, len(c3_pool), keep=c3_table)
+        c3_epochs = c3_table[:, 0].tolist()
+        del c3_pool
         adaptive = {}
         for variant in ("earlystop", "prune"):   # weights whose token confidences stop early / whose matchabilities prune points
             v_sd = synthetic.lightglue_state_dict(0, variant)
@@ -349,8 +390,8 @@ def main():
                 e.load_state_dict("lightglue", v_sd)
                 return e
             vp = PairPipeline(make_variant_engine, h, w, kpts, n_streams=n_streams, use_graph=not args.no_graph, matcher=m_name,
-                              pairs_per_launch=args.batch)
-            side = new_table(n_side, kpts, eng.device)
+                              pairs_per_launch=args.batch, with_keypoints=with_kp)
+            side = new_table(n_side, kpts, eng.device, with_kp)
             for j in range(args.batch * n_streams):
                 vp.match_pair(tr_pool[j % 2], j, side, j)
             vp.flush(); vp.synchronize()
@@ -368,39 +409,27 @@ def main():
             "other_launch_mode": {"pairs_per_launch": alt_b, "launch_groups_in_flight": alt_s, "pairs_per_s": r_alt, "pairs": 48},
             "host_inputs_pairs_per_s": {"pairs_per_s": r_host, "pairs": n_side,
                                         "note": "PCIe-inclusive: every pair starts as a numpy uint8 array in pageable host memory, is copied "
-                                                "into a page-locked staging ring and uploaded asynchronously on the launch stream "
-                                                "(`PairPipeline.match_host_pair`); never `value`"},
+                                                "into a page-locked staging ring and uploaded asynchronously on its launch group's stream "
+                                                "(`PairPipeline.match_host_pair`; one group's upload runs beside the other group's "
+                                                "kernels); never `value`"},
             "translated_pairs": {"pairs_per_s": r_tr, "mean_matches": m_tr, "pairs": n_side,
                                  "note": "pairs related by a pure (40, 8) px translation: the seeded weights match ~1000 keypoints "
                                          "per pair on them (8 on the homography-warped pairs of `value`); same launches, no pruning or "
-                                         "early exit triggers with seeded weights either way"}}
+                                         "early exit triggers with seeded weights either way"},
+            "config3_distinct_epochs": {"pairs_per_s": r_c3, "ms_per_pair": 1e3 / r_c3, "pairs": len(c3_epochs), "mean_matches": m_c3,
+                                        "epochs_distinct_and_in_order": c3_epochs == list(range(len(c3_epochs))),
+                                        "note": "BASELINE configs[2] at reduced length: the timed launch mode of `value` over "
+                                                f"{len(c3_epochs)} DISTINCT synthetic epochs (SURVEY 8d config 3 seeds), every pair "
+                                                "computed once after one launch group per stream of warm-up; `python bench.py --config 3` "
+                                                "runs all 256"}}
+        result["side_measurements"]["config5"] = config5_side(args, local_rank, sp_sd, side_inputs["config5"])
+        result["side_measurements"]["match_call_ms"] = match_call_side(local_rank, sp_sd, m_sd, host_pairs[0])
+        result["side_measurements"]["seconds_spent"] = round(time.perf_counter() - t_side, 1)
 
     if rank == 0:
         # ---- roofline of the dominant kernel: HIP events around every launch (library-side, on the launch stream)
-        lib = eng.ctx
         prof_steps = 1 if cfg5 else 4
-        _, pstream, psm = sm.slots[0]
-        psm.use_graph = False  # per-launch events need direct launches (same kernels, same stream, one pair in flight)
-        psm.P = 1
-        with torch.cuda.stream(pstream):
-            # untimed pairs in this launch mode first: the side measurements above end with an idle gap, and directly launched
-            # kernels (host-paced, unlike the graph replays of the timed region) need a moment to bring the clocks back up
-            for i in range(1 if cfg5 else 3):
-                psm.match_pair(pool[i % len(pool)], epochs[i % len(epochs)], scratch, 0)
-            pstream.synchronize()
-            lib.call("im_profile_begin")
-            for i in range(prof_steps):
-                psm.match_pair(pool[i % len(pool)], epochs[i % len(epochs)], scratch, 0)
-            pstream.synchronize()
-        buf = ctypes.create_string_buffer(1 << 16)
-        lib.call("im_profile_end", buf, len(buf))
-        prof = json.loads(buf.value.decode())
-        # an event pair around nothing still reads a few microseconds (two packets for the command processor): the library
-        # measures that on the same stream and it is subtracted per launch, so the durations are the kernels' own
-        cal = prof.pop("_empty_event_pair", None)
-        ev_overhead_ms = cal["total_ms"] / cal["count"] if cal and cal["count"] else 0.0
-        for v in prof.values():
-            v["total_ms"] = max(v["total_ms"] - v["count"] * ev_overhead_ms, 0.0)
+        prof, ev_overhead_ms = event_profile(sm.slots[0], pool, epochs, scratch, 1 if cfg5 else 3, prof_steps)
         tot = sum(v["total_ms"] for v in prof.values())
         try:
             with open(TRAFFIC_FILE) as fh:
@@ -479,13 +508,117 @@ def main():
         dist.destroy_process_group()
 
 
+def config5_side(args, local_rank, sp_sd, host_pair):
+    """`side_measurements.config5` of the default line: BASELINE configs[4] (12 MP pair, 16384 keypoints, SuperPoint nms 3 +
+    SuperGlue with 20 Sinkhorn iterations) on three pairs - pairs/s, the attention kernel against the fp32 MFMA peak and the
+    Sinkhorn solve against HBM. `python bench.py --config 5` is the full line."""
+    import torch
+    from icepy4d_amd import synthetic
+    from icepy4d_amd.engine import Engine
+    from icepy4d_amd.sequence import PairPipeline, new_table
+    sg_sd = synthetic.superglue_state_dict(0, "passthrough")
+
+    def make_engine5():
+        e = Engine(local_rank)
+        e.load_state_dict("superpoint", sp_sd)
+        e.load_state_dict("superglue", sg_sd)
+        return e
+    p5 = PairPipeline(make_engine5, H5, W5, KPTS5, n_streams=1, use_graph=not args.no_graph, matcher="superglue", pairs_per_launch=1)
+    dev = p5.device
+    pair = torch.from_numpy(host_pair).to(dev).contiguous()
+    side = new_table(3, KPTS5, dev)
+    p5.match_pair(pair, 0, side, 0)
+    p5.flush(); p5.synchronize()
+    t = time.perf_counter()
+    for j in range(3):
+        p5.match_pair(pair, j, side, j)
+    p5.flush(); p5.synchronize()
+    dt = time.perf_counter() - t
+    n0, n1 = side[:, 1].float().mean().item(), side[:, 2].float().mean().item()
+    prof, _ = event_profile(p5.slots[0], [pair], [0], side, 1, 1)
+    out = {"pairs_per_s": 3 / dt, "ms_per_pair": 1e3 * dt / 3, "pairs": 3, "mean_keypoints": n0, "mean_matches": side[:, 3].float().mean().item(),
+           "workload": "configs[4]: 3000x4000 gray pair (the same pair three times), SuperPoint (16384 kpts, nms 3, threshold 0.001) + "
+                       "SuperGlue (18 layers, 20 Sinkhorn iterations, match threshold 0.3), seeded weights, one pair per launch"}
+    ms = sum(prof[k]["total_ms"] for k in ("flash_attn_self", "flash_attn_cross") if k in prof)
+    cnt = sum(prof[k]["count"] for k in ("flash_attn_self", "flash_attn_cross") if k in prof)
+    fl = sum(kernel_flops(k, 2, n0, n1, H5, W5, True) * prof[k]["count"] for k in ("flash_attn_self", "flash_attn_cross") if k in prof)
+    if cnt:
+        out["attention"] = {"avg_launch_ms": ms / cnt, "achieved_tflops": fl / (ms * 1e-3) / 1e12,
+                            "frac_of_fp32_mfma_peak": fl / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}
+    if "sinkhorn" in prof and prof["sinkhorn"]["count"]:
+        sk = prof["sinkhorn"]
+        solve_ms = sk["total_ms"] / sk["count"]
+        moved = 20.0 * (n0 + 1) * (n1 + 1) * 4      # the fused kernel reads the couplings ONCE per iteration
+        out["sinkhorn"] = {"solve_ms": solve_ms, "bytes_moved_per_solve": moved, "moved_gb_per_s": moved / (solve_ms * 1e-3) / 1e9,
+                           "frac_of_hbm_peak_moved": moved / (solve_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                           "survey_8d_bytes_per_solve": 2 * moved, "survey_8d_gb_per_s": 2 * moved / (solve_ms * 1e-3) / 1e9,
+                           "note": "bytes moved = 20 iterations x one read of the (M+1)(N+1) fp32 couplings (u, v and partials "
+                                   "are < 4 % more: profiles/traffic.json); SURVEY 8d counts two reads per iteration"}
+    out["kernel_ms_per_pair"] = {k: round(v["total_ms"], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])[:8]}
+    p5.close()
+    return out
+
+
+def match_call_side(local_rank, sp_sd, lg_sd, host_pair):
+    """`side_measurements.match_call_ms`: ONE `matcher.match(image0, image1)` at 1080p / 4096 keypoints through the plugin API -
+    numpy uint8 arrays in (pageable host memory), numpy results out, upload / graph replay / download and the host code of
+    `match()` inside the measured time (`matchers.py:139-261`, the call of `main_dev.py:115-132` without tiles)."""
+    import statistics
+    from icepy4d_amd import matching
+    m = matching.LightGlueMatcher({"state_dicts": {"superpoint": sp_sd, "lightglue": lg_sd}, "device": local_rank})
+    a, b = host_pair[0], host_pair[1]
+    ts = []
+    for r in range(13):
+        t = time.perf_counter()
+        m.match(a, b, quality=matching.Quality.HIGH, tile_selection=matching.TileSelection.NONE, max_keypoints=KPTS,
+                geometric_verification=matching.GeometricVerification.NONE)
+        ts.append(1e3 * (time.perf_counter() - t))
+    ts = ts[3:]     # the first calls capture the HIP graph and size the workspace
+    return {"median": statistics.median(ts), "min": min(ts), "max": max(ts), "calls": len(ts),
+            "keypoints": int(len(m.mkpts0)), "note": "LightGlueMatcher.match(image0, image1, quality=HIGH, tile_selection=NONE, "
+            "max_keypoints=4096, geometric_verification=NONE), host arrays in / numpy out, 10 calls after 3 untimed ones"}
+
+
+def event_profile(slot, inputs, epochs, scratch, warm, steps):
+    """Per-launch durations of one launch group's kernels: HIP events recorded by the library around every launch on the launch
+    stream (`im_profile_begin / end`), direct launches with ONE pair in flight. Returns ({launch class: {count, total_ms}}, the
+    duration of an empty event pair in ms - already subtracted per launch)."""
+    import torch
+    eng, pstream, psm = slot
+    lib = eng.ctx
+    psm.use_graph = False  # per-launch events need direct launches (same kernels, same stream, one pair in flight)
+    psm.P = 1
+    with torch.cuda.stream(pstream):
+        # untimed pairs in this launch mode first: the side measurements end with an idle gap, and directly launched
+        # kernels (host-paced, unlike the graph replays of the timed region) need a moment to bring the clocks back up
+        for i in range(warm):
+            psm.match_pair(inputs[i % len(inputs)], epochs[i % len(epochs)], scratch, 0)
+        pstream.synchronize()
+        lib.call("im_profile_begin")
+        for i in range(steps):
+            psm.match_pair(inputs[i % len(inputs)], epochs[i % len(epochs)], scratch, 0)
+        pstream.synchronize()
+    buf = ctypes.create_string_buffer(1 << 16)
+    lib.call("im_profile_end", buf, len(buf))
+    prof = json.loads(buf.value.decode())
+    # an event pair around nothing still reads a few microseconds (two packets for the command processor): the library
+    # measures that on the same stream and it is subtracted per launch, so the durations are the kernels' own
+    cal = prof.pop("_empty_event_pair", None)
+    ev_overhead_ms = cal["total_ms"] / cal["count"] if cal and cal["count"] else 0.0
+    for v in prof.values():
+        v["total_ms"] = max(v["total_ms"] - v["count"] * ev_overhead_ms, 0.0)
+    return prof, ev_overhead_ms
+
+
 def rank_report(dist, rank, world, args, t_own, t_gather, device_index, dev_, table, full, cpu_group):
     """The `ranks` object of an N > 1 line: every rank reports its own pair count, its own time to finish them and its time inside
     the table all-gather (one more tiny all-gather, outside the timed region), so that a reader can verify that N ranks on N
     devices took part and that the gathered table holds every epoch."""
     import torch
     from icepy4d_amd.sequence import shard_epochs
-    mine = torch.tensor([float(rank), float(args.steps), t_own, t_gather, float(device_index)], dtype=torch.float64, device=dev_)
+    vis = os.environ.get("HIP_VISIBLE_DEVICES", "")
+    vis_id = float(vis) if vis.strip().lstrip("-").isdigit() else -1.0          # a single index (IM_BENCH_ISOLATE_DEVICES=1), else -1
+    mine = torch.tensor([float(rank), float(args.steps), t_own, t_gather, float(device_index), vis_id], dtype=torch.float64, device=dev_)
     every = [torch.zeros_like(mine) for _ in range(world)]
     dist.all_gather(every, mine)
     every = sorted((e.tolist() for e in every), key=lambda r: r[0])
@@ -499,6 +632,8 @@ def rank_report(dist, rank, world, args, t_own, t_gather, device_index, dev_, ta
     want = sorted(e for r in range(world) for e in shard_epochs(total * world, r, world)[args.warmup:])
     return {"world": dist.get_world_size(), "backend": dist.get_backend(), "nccl_version": nccl_version,
             "pairs_per_rank": [int(r[1]) for r in every], "device_per_rank": [int(r[4]) for r in every],
+            "devices_isolated": os.environ.get("IM_BENCH_ISOLATE_DEVICES") == "1",
+            "hip_visible_device_per_rank": [int(r[5]) for r in every],
             "per_rank_pairs_per_s": [r[1] / max(r[2], 1e-9) for r in every], "all_gather_ms": [1e3 * r[3] for r in every],
             "record_bytes": int(table.shape[1]) * 4, "gathered_table_bytes": int(full.numel()) * 4,
             "epochs_in_gathered_table": int(full.shape[0]), "epochs_complete_and_sorted": bool(full[:, 0].tolist() == want)}

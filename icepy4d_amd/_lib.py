@@ -49,6 +49,8 @@ SIGNATURES = {
     "im_superglue_forward": [_P, _P, _P, _P, _P, _P, C.POINTER(SuperGlueConf), _P, _P, _P, _P],
     "im_pack_record": [_P, _P, _P, _P, _P, _I, _P, _P],
     "im_debug_read": [_P, C.c_char_p, _P, C.c_size_t, _P],
+    "im_debug_guard_failures": [],
+    "im_debug_guard_selftest": [_P, _P],
     "im_pyr_down": [_P, _P, _P, _I, _I, _I, _I, _P],
     "im_pyr_up": [_P, _P, _P, _I, _I, _I, _I, _P],
     "im_gemm_nt": [_P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _P],
@@ -108,9 +110,11 @@ def ptr(t) -> int:
     return t.ctypes.data
 
 
-def stream_ptr() -> Optional[int]:
+def stream_ptr(device=None) -> Optional[int]:
+    """The current HIP stream of `device` (a torch device or index; None = the process's current device). Callers that hold an
+    engine pass its device: the stream must belong to the device the context's buffers live on, whatever device is current."""
     import torch
-    return torch.cuda.current_stream().cuda_stream
+    return torch.cuda.current_stream(device).cuda_stream
 
 
 class Context:

@@ -3,6 +3,7 @@
 #include "ctx.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 using namespace im;
@@ -18,6 +19,8 @@ int im_ctx_create(int device, im_ctx** out) {
     if (hipSetDevice(device) != hipSuccess) return -3;
     im_ctx* c = new im_ctx();
     c->device = device;
+    const char* g = getenv("IM_DEBUG_GUARDS");
+    c->guards_on = g && g[0] == '1';
     *out = c;
     return 0;
 }
@@ -134,14 +137,15 @@ int im_flash_attn(im_ctx* ctx, const float* d_q, const float* d_k, const float* 
     const size_t nf = attn_part_floats(n_max, batch, heads), ni = attn_counter_ints(n_max, batch, heads);
     if (nf > ctx->stage_attn_floats || ni > ctx->stage_attn_ints) {
         IM_HIP(ctx, hipDeviceSynchronize());
-        float* p = ctx->dalloc<float>(nf);
-        int* c = ctx->dalloc<int>(ni);
+        float* p = ctx->dalloc<float>(nf, "stage_attn_part");
+        int* c = ctx->dalloc<int>(ni, "stage_attn_cnt");
         if (!p || !c) return ctx->fail(-11, "im_flash_attn: out of device memory");
         IM_HIP(ctx, hipMemset(c, 0, ni * sizeof(int)));
         ctx->stage_attn_part = p; ctx->stage_attn_cnt = c; ctx->stage_attn_floats = nf; ctx->stage_attn_ints = ni;
     }
     a.part = ctx->stage_attn_part; a.counters = ctx->stage_attn_cnt;
     IM_HIP(ctx, launch_flash_attn(a, (hipStream_t)stream));
+    IM_GUARD_CHECK(ctx, (hipStream_t)stream, "im_flash_attn");
     return 0;
 }
 

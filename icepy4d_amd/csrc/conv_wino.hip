@@ -80,7 +80,6 @@ __device__ __forceinline__ float4 sub4(float4 x, float4 y, f32x2 m1) {
     return make_float4(r0.x, r0.y, r1.x, r1.y);
 }
 // max(v, floor) as one v_med3_f32 (fmaxf of two values of unknown origin costs two canonicalising v_max besides the max itself)
-__device__ __forceinline__ float relu_floor(float v, float floor_) { return __builtin_amdgcn_fmed3f(v, floor_, __builtin_inff()); }
 __device__ __forceinline__ f32x16 sub16(const f32x16& x, const f32x16& y, f32x2 m1) {
     f32x16 r;
 #pragma unroll
@@ -120,7 +119,7 @@ __device__ __forceinline__ wu32x4 wmake_rsrc4(const void* base, unsigned bytes) 
 }
 __device__ __forceinline__ void dma16(wu32x4 rsrc, unsigned lds_byte_addr, unsigned voff, unsigned soff) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                 :: "s"(lds_byte_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+                 :: "s"(lds_byte_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory", "m0");
 }
 #define IM_DMA_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 

@@ -105,12 +105,23 @@ struct im_ctx {
         err = buf;
         return code;
     }
+    // ---- IM_DEBUG_GUARDS=1 (read when the context is created; debugging aid, GPU AddressSanitizer is not available on this
+    // pool): every device buffer the library allocates gets 256 bytes of guard words in front of it and behind it; a small kernel
+    // compares them after every forward (and before a buffer is freed), a changed word fails the call with -90 naming the buffer.
+    struct Guard { void* base; unsigned* lo; unsigned* hi; std::string name; };
+    bool guards_on = false;
+    std::vector<Guard> guards;
+    bool guards_dirty = false;            // the device-side table of guard blocks is older than `guards`
+    unsigned** d_guard_blocks = nullptr;  // [2 * guards.size()] device pointers: lo, hi of every buffer
+    int* d_guard_flag = nullptr;          // 0, or 1 + index of the first changed block seen
+    size_t guard_table_cap = 0;
+    void* galloc(size_t bytes, const char* name, std::vector<void*>& owner);   // hipMalloc (+ guards); owner gets the base pointer
+    void gfree(void* base);                                                    // hipFree (+ forget its guards)
+    int guards_check(hipStream_t s, const char* where);                        // 0 ok / not enabled; < 0 with `err` set
+
     template <typename T>
-    T* dalloc(size_t n) {
-        void* p = nullptr;
-        if (hipMalloc(&p, n * sizeof(T) + 256) != hipSuccess) return nullptr;
-        (cur_model ? *cur_model : allocs).push_back(p);
-        return reinterpret_cast<T*>(p);
+    T* dalloc(size_t n, const char* name = "dalloc") {
+        return reinterpret_cast<T*>(galloc(n * sizeof(T), name, cur_model ? *cur_model : allocs));
     }
     float* upload(const std::vector<float>& v) {
         float* p = dalloc<float>(v.size());
@@ -119,6 +130,15 @@ struct im_ctx {
     }
     void free_all();
 };
+
+// at the end of a forward: compare the guard words (no-op unless IM_DEBUG_GUARDS=1)
+#define IM_GUARD_CHECK(ctx, stream, where)                                   \
+    do {                                                                     \
+        if ((ctx)->guards_on) {                                              \
+            const int _g = (ctx)->guards_check((stream), (where));           \
+            if (_g) return _g;                                               \
+        }                                                                    \
+    } while (0)
 
 #define IM_CHECK_CTX(ctx)                                \
     do {                                                 \

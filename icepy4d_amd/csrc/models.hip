@@ -266,7 +266,7 @@ int im_finalize_weights(im_ctx* ctx, const char* model) {
         return ctx->fail(-23, "im_finalize_weights: unknown model '%s'", m.c_str());
     IM_HIP(ctx, hipDeviceSynchronize());
     std::vector<void*>& mine = ctx->model_allocs[m];
-    for (void* p : mine) hipFree(p);   // a reload replaces the previous device copy of this model
+    for (void* p : mine) ctx->gfree(p);   // a reload replaces the previous device copy of this model
     mine.clear();
     ctx->cur_model = &mine;
     int rc;
@@ -291,7 +291,8 @@ int im_ctx_reserve(im_ctx* ctx, int max_h, int max_w, int max_images, int max_kp
     if (ctx->ws && max_h <= ctx->max_h && max_w <= ctx->max_w && max_images <= ctx->max_images && max_kpts <= ctx->max_kpts) return 0;
     IM_HIP(ctx, hipDeviceSynchronize());
     if (ctx->ws) {
-        for (void* p : ctx->ws->allocs) hipFree(p);
+        IM_GUARD_CHECK(ctx, nullptr, "the last use of the workspace that im_ctx_reserve replaces");
+        for (void* p : ctx->ws->allocs) ctx->gfree(p);
         delete ctx->ws;
         ctx->ws = nullptr;
     }
@@ -303,13 +304,12 @@ int im_ctx_reserve(im_ctx* ctx, int max_h, int max_w, int max_images, int max_kp
     const long B = max_images;
     const long H8 = (max_h / 8) * 8, W8 = (max_w / 8) * 8, cells = (H8 / 8) * (W8 / 8), K = max_kpts;
     bool ok = true;
-    auto A = [&](auto*& p, size_t n) {
+    auto alloc_named = [&](auto*& p, size_t n, const char* name) {
         using T = std::remove_reference_t<decltype(*p)>;
-        void* q = nullptr;
-        if (hipMalloc(&q, n * sizeof(T) + 256) != hipSuccess) { ok = false; p = nullptr; return; }
-        ws->allocs.push_back(q);
-        p = reinterpret_cast<T*>(q);
+        p = reinterpret_cast<T*>(ctx->galloc(n * sizeof(T), name, ws->allocs));
+        if (!p) ok = false;
     };
+#define A(ptr, n) alloc_named(ptr, n, #ptr)
     A(ws->act0, (size_t)B * (max_h / 2) * (max_w / 2) * 64);  // conv1a is fused: nothing is stored at full resolution
     A(ws->act1, (size_t)B * (max_h / 2) * (max_w / 2) * 64);
     A(ws->logits, (size_t)B * cells * 65);
@@ -346,9 +346,10 @@ int im_ctx_reserve(im_ctx* ctx, int max_h, int max_w, int max_images, int max_kp
     A(ws->ridx, NP * ws->vec_ps); A(ws->rval, NP * ws->vec_ps); A(ws->cbest, NP * ws->vec_ps);
     A(ws->st, NP); A(ws->sel, NP + 3);
     A(ws->uv, (size_t)4 * (K + 8));
+#undef A
     ws->n_pairs = (int)NP;
     if (!ok) {
-        for (void* p : ws->allocs) hipFree(p);
+        for (void* p : ws->allocs) ctx->gfree(p);
         delete ws;
         ctx->max_h = ctx->max_w = ctx->max_images = ctx->max_kpts = 0;   // no workspace any more: the next call starts from its own sizes
         return ctx->fail(-31, "im_ctx_reserve: out of device memory (%d x %d, %d images, %d keypoints)", max_h, max_w, max_images, max_kpts);
@@ -429,6 +430,7 @@ int im_superpoint_forward(im_ctx* ctx, const uint8_t* d_img, int n_images, int h
         IM_LAUNCH(ctx, "convDb_gemm", s, launch_gemm(g, s));
         IM_LAUNCH(ctx, "sample_desc", s, launch_sample_desc(ws->dense, B, hc, wc, d_kpts, d_n, K, d_desc, s));
     }
+    IM_GUARD_CHECK(ctx, s, "im_superpoint_forward");
     return 0;
 }
 
@@ -583,6 +585,7 @@ static int lightglue_forward(im_ctx* ctx, int n_pairs, const float* d_kpts, cons
     a.out_ps = 2L * K; a.state_ps = ST_INTS;
     IM_LAUNCH(ctx, "assign", s, launch_assign(a, s));
     IM_HIP(ctx, hipMemcpyAsync(d_prune, ws->prune, sizeof(int) * NI * K, hipMemcpyDeviceToDevice, s));
+    IM_GUARD_CHECK(ctx, s, "im_lightglue_forward");
     return 0;
 }
 
@@ -647,6 +650,7 @@ int im_nms(im_ctx* ctx, const float* d_scores, float* d_out, int n_images, int h
     if (!ws || (long)n_images * h * w > (long)ctx->max_images * ((ctx->max_h / 8) * 8) * ((ctx->max_w / 8) * 8))
         return ctx->fail(-41, "im_nms: exceeds the reserved workspace");
     IM_HIP(ctx, launch_nms(d_scores, d_out, ws->mask, ws->supp, ws->rest, n_images, h, w, radius, (hipStream_t)stream));
+    IM_GUARD_CHECK(ctx, (hipStream_t)stream, "im_nms");
     return 0;
 }
 
@@ -658,6 +662,7 @@ int im_select_topk(im_ctx* ctx, const float* d_nms, int n_images, int h, int w, 
         return ctx->fail(-41, "im_select_topk: exceeds the reserved workspace");
     IM_HIP(ctx, launch_select_topk(d_nms, n_images, h, w, border, threshold, max_kpts, ctx->max_kpts, ws->kpsel, d_kpts, d_scores, d_n,
                                    (hipStream_t)stream));
+    IM_GUARD_CHECK(ctx, (hipStream_t)stream, "im_select_topk");
     return 0;
 }
 
@@ -691,6 +696,7 @@ int im_assign_from_sim(im_ctx* ctx, const float* d_sim, int m, int n, int ld, co
     a.out_m0 = d_m0; a.out_m1 = d_m1; a.out_s0 = d_ms0; a.out_s1 = d_ms1;
     a.n_pairs = 1;
     IM_HIP(ctx, launch_assign(a, s));
+    IM_GUARD_CHECK(ctx, s, "im_assign_from_sim");
     return 0;
 }
 

@@ -620,6 +620,7 @@ int im_superglue_forward(im_ctx* ctx, const float* d_kpts, const float* d_scores
     a.out_m0 = d_matches; a.out_m1 = d_matches + K; a.out_s0 = d_mscores; a.out_s1 = d_mscores + K;
     IM_LAUNCH(ctx, "assign", s, launch_assign(a, s));
     IM_HIP(ctx, launch_lg_select_layer(st, 1, 0, ws->sel, d_info, s));
+    IM_GUARD_CHECK(ctx, s, "im_superglue_forward");
     return 0;
 }
 
@@ -642,6 +643,7 @@ int im_log_optimal_transport(im_ctx* ctx, const float* d_scores, int m, int n, i
     const long total = (long)(m + 1) * (n + 1);
     hipLaunchKernelGGL(ot_materialize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d_scores, ld, m, n, bin_score, u, v, d_out);
     IM_HIP(ctx, hipGetLastError());
+    IM_GUARD_CHECK(ctx, s, "im_log_optimal_transport");
     return 0;
 }
 

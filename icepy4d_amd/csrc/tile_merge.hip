@@ -135,10 +135,10 @@ int im_merge_tile_matches(im_ctx* ctx, int n_pairs, int max_kpts, const int32_t*
     MergeScratch& ms = *ctx->merge;
     if (cap > ms.cap) {
         IM_HIP(ctx, hipDeviceSynchronize());
-        ms.key = ctx->dalloc<unsigned long long>(cap);
-        ms.skey = ctx->dalloc<unsigned long long>(cap);
-        ms.seq = ctx->dalloc<unsigned>(cap);
-        if (!ms.count) ms.count = ctx->dalloc<int>(4);
+        ms.key = ctx->dalloc<unsigned long long>(cap, "merge.key");
+        ms.skey = ctx->dalloc<unsigned long long>(cap, "merge.skey");
+        ms.seq = ctx->dalloc<unsigned>(cap, "merge.seq");
+        if (!ms.count) ms.count = ctx->dalloc<int>(4, "merge.count");
         if (!ms.key || !ms.skey || !ms.seq || !ms.count) return ctx->fail(-71, "im_merge_tile_matches: out of device memory");
         ms.cap = cap;
     }
@@ -153,6 +153,7 @@ int im_merge_tile_matches(im_ctx* ctx, int n_pairs, int max_kpts, const int32_t*
                        d_idx0, d_idx1, d_kp0, d_kp1);
     IM_HIP(ctx, hipGetLastError());
     IM_HIP(ctx, hipMemcpyAsync(d_count, ms.count + 1, sizeof(int), hipMemcpyDeviceToDevice, s));
+    IM_GUARD_CHECK(ctx, s, "im_merge_tile_matches");
     return 0;
 }
 

@@ -38,17 +38,124 @@ std::vector<float> pack_conv3x3_wino(const float* w, int cout, int cin) {
 
 }  // namespace im
 
+// ------------------------------------------------------------------------------------------------ IM_DEBUG_GUARDS
+static constexpr unsigned GUARD_WORDS = 64;                  // 256 bytes on each side
+static constexpr unsigned GUARD_PATTERN = 0xA5C3F00Du;
+static int g_guard_failures = 0;                             // process-wide tally (im_debug_guard_failures)
+
+__global__ void guard_fill_kernel(unsigned* lo, unsigned* hi) {
+    lo[threadIdx.x] = GUARD_PATTERN ^ threadIdx.x;
+    hi[threadIdx.x] = GUARD_PATTERN ^ threadIdx.x;
+}
+
+__global__ void guard_check_kernel(unsigned* const* blocks, int* flag) {
+    if (blocks[blockIdx.x][threadIdx.x] != (GUARD_PATTERN ^ threadIdx.x)) atomicCAS(flag, 0, (int)blockIdx.x + 1);
+}
+
+void* im_ctx::galloc(size_t bytes, const char* name, std::vector<void*>& owner) {
+    void* base = nullptr;
+    if (!guards_on) {
+        if (hipMalloc(&base, bytes + 256) != hipSuccess) return nullptr;
+        owner.push_back(base);
+        return base;
+    }
+    const size_t body = (bytes + 15) & ~(size_t)15;          // the guard behind starts at the first 16-byte boundary past the buffer
+    if (hipMalloc(&base, 256 + body + 256 + 256) != hipSuccess) return nullptr;   // (+ the slack every allocation of the library has)
+    owner.push_back(base);
+    Guard g{base, reinterpret_cast<unsigned*>(base), reinterpret_cast<unsigned*>(static_cast<char*>(base) + 256 + body), name};
+    guard_fill_kernel<<<1, GUARD_WORDS, 0, nullptr>>>(g.lo, g.hi);
+    hipStreamSynchronize(nullptr);
+    guards.push_back(g);
+    guards_dirty = true;
+    return static_cast<char*>(base) + 256;
+}
+
+void im_ctx::gfree(void* base) {
+    if (guards_on)
+        for (size_t i = 0; i < guards.size(); ++i)
+            if (guards[i].base == base) { guards.erase(guards.begin() + i); guards_dirty = true; break; }
+    hipFree(base);
+}
+
+int im_ctx::guards_check(hipStream_t s, const char* where) {
+    if (!guards_on || guards.empty()) return 0;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    hipStreamIsCapturing(s, &cap);
+    const bool capturing = cap != hipStreamCaptureStatusNone;
+    if (guards_dirty) {
+        if (capturing) return 0;                              // no allocation inside a capture: the next plain call checks
+        hipDeviceSynchronize();
+        std::vector<unsigned*> h;
+        for (const Guard& g : guards) { h.push_back(g.lo); h.push_back(g.hi); }
+        if (h.size() > guard_table_cap) {
+            if (d_guard_blocks) hipFree(d_guard_blocks);
+            guard_table_cap = h.size() + 64;
+            if (hipMalloc((void**)&d_guard_blocks, guard_table_cap * sizeof(unsigned*)) != hipSuccess) return fail(-91, "IM_DEBUG_GUARDS: table allocation failed");
+        }
+        if (!d_guard_flag) {
+            if (hipMalloc((void**)&d_guard_flag, sizeof(int)) != hipSuccess) return fail(-91, "IM_DEBUG_GUARDS: flag allocation failed");
+            hipMemset(d_guard_flag, 0, sizeof(int));
+        }
+        hipMemcpy(d_guard_blocks, h.data(), h.size() * sizeof(unsigned*), hipMemcpyHostToDevice);
+        guards_dirty = false;
+    }
+    guard_check_kernel<<<(unsigned)(2 * guards.size()), GUARD_WORDS, 0, s>>>(d_guard_blocks, d_guard_flag);
+    if (capturing) return 0;                                  // the check is part of the graph; its flag is read by a later plain call
+    int flag = 0;
+    if (hipStreamSynchronize(s) != hipSuccess || hipMemcpy(&flag, d_guard_flag, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
+        return fail(-92, "IM_DEBUG_GUARDS: reading the flag failed after %s", where);
+    if (!flag) return 0;
+    hipMemset(d_guard_flag, 0, sizeof(int));
+    ++g_guard_failures;
+    const Guard& g = guards[(size_t)(flag - 1) / 2];
+    fprintf(stderr, "IM_DEBUG_GUARDS: guard words %s buffer '%s' were overwritten (seen after %s)\n", (flag - 1) % 2 ? "BEHIND" : "IN FRONT OF",
+            g.name.c_str(), where);
+    return fail(-90, "IM_DEBUG_GUARDS: guard words %s buffer '%s' were overwritten (seen after %s)", (flag - 1) % 2 ? "behind" : "in front of",
+                g.name.c_str(), where);
+}
+
+extern "C" int im_debug_guard_failures(void) { return g_guard_failures; }
+
+__global__ void guard_poke_kernel(unsigned* word, unsigned value) { *word = value; }
+
+// Self-test of the mechanism: one stray 4-byte store right behind the first workspace buffer (what an off-by-one row of a kernel
+// would do) must fail the check with -90; the word is restored and the tally decremented, so a passing self-test leaves no trace.
+extern "C" int im_debug_guard_selftest(im_ctx* ctx, void* stream) {
+    if (!ctx) return -1;
+    if (hipSetDevice(ctx->device) != hipSuccess) return ctx->fail(-3, "hipSetDevice failed");
+    if (!ctx->guards_on) return ctx->fail(-93, "im_debug_guard_selftest: the context was created without IM_DEBUG_GUARDS=1");
+    if (ctx->guards.empty()) return ctx->fail(-93, "im_debug_guard_selftest: nothing allocated yet (call im_ctx_reserve first)");
+    hipStream_t s = (hipStream_t)stream;
+    int rc = ctx->guards_check(s, "im_debug_guard_selftest (before)");
+    if (rc) return rc;
+    unsigned* w = ctx->guards.back().hi;                      // first word behind the newest buffer
+    guard_poke_kernel<<<1, 1, 0, s>>>(w, 0xDEADBEEFu);
+    rc = ctx->guards_check(s, "im_debug_guard_selftest (the stray store is deliberate)");
+    guard_poke_kernel<<<1, 1, 0, s>>>(w, GUARD_PATTERN ^ 0u);
+    hipStreamSynchronize(s);
+    if (rc != -90) return ctx->fail(-94, "im_debug_guard_selftest: a stray store behind '%s' went unnoticed", ctx->guards.back().name.c_str());
+    --g_guard_failures;
+    return ctx->guards_check(s, "im_debug_guard_selftest (after)");
+}
+
 void im_ctx::free_all() {
-    for (void* p : allocs) hipFree(p);
+    if (guards_on) {
+        hipDeviceSynchronize();
+        guards_check(nullptr, "im_ctx_destroy");
+    }
+    for (void* p : allocs) gfree(p);
     allocs.clear();
     for (auto& kv : model_allocs)
-        for (void* p : kv.second) hipFree(p);
+        for (void* p : kv.second) gfree(p);
     model_allocs.clear();
     if (ws) {
-        for (void* p : ws->allocs) hipFree(p);
+        for (void* p : ws->allocs) gfree(p);
         delete ws;
         ws = nullptr;
     }
+    if (d_guard_blocks) hipFree(d_guard_blocks);
+    if (d_guard_flag) hipFree(d_guard_flag);
+    d_guard_blocks = nullptr; d_guard_flag = nullptr; guard_table_cap = 0;
     delete merge;
     merge = nullptr;
 }

@@ -61,6 +61,13 @@ class Engine:
         self._loaded: Dict[str, str] = {}     # model -> fingerprint of the weights on the device
         self.graphs: Dict[tuple, object] = {}  # captured whole-pair HIP graphs, keyed by (shape, K, settings, generation)
 
+    def stream_ptr(self) -> int:
+        """The current HIP stream of THIS engine's device (not of whatever device is current in the process)."""
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def synchronize(self) -> None:
+        torch.cuda.synchronize(self.device)
+
     # ------------------------------------------------------------------ weights
     def load_state_dict(self, model: str, state_dict: Dict[str, torch.Tensor]) -> None:
         """Pass a state dict with the official key names (`lightglue/superpoint.py:118-137`,
@@ -143,13 +150,13 @@ class Engine:
         self._last_sp = (slot, B)
         self.ctx.call("im_superpoint_forward", ptr(gray_u8), B, H, W, C_, int(nms_radius), float(threshold), int(border), k,
                       int(flavour), ptr(self.kpts[slot:]), ptr(self.scores[slot:]), ptr(self.desc[slot:]), ptr(self.n[slot:]),
-                      _lib.stream_ptr())
+                      self.stream_ptr())
 
     def candidates(self) -> list:
         """Candidate counts (before the top-k / capacity cut) of the images of the last `superpoint` call. Synchronises."""
         slot, B = self._last_sp
         h = np.zeros(B, dtype=np.int32)
-        self.ctx.call("im_superpoint_candidates", B, h.ctypes.data, _lib.stream_ptr())
+        self.ctx.call("im_superpoint_candidates", B, h.ctypes.data, self.stream_ptr())
         return h.tolist()
 
     def lightglue(self, size0: Tuple[float, float], size1: Tuple[float, float], depth_confidence: float = 0.95,
@@ -169,7 +176,7 @@ class Engine:
         size = np.array([size0[0], size0[1], size1[0], size1[1]], dtype=np.float32)
         assert 1 <= n_pairs and 2 * n_pairs <= self.matches.shape[0], (n_pairs, self.matches.shape)
         self.ctx.call("im_lightglue_forward_pairs", int(n_pairs), ptr(kpts), ptr(desc), ptr(n), size.ctypes.data, C.byref(conf),
-                      ptr(self.matches), ptr(self.mscores), ptr(self.prune), ptr(self.info), _lib.stream_ptr())
+                      ptr(self.matches), ptr(self.mscores), ptr(self.prune), ptr(self.info), self.stream_ptr())
 
     def superglue(self, shape0: Tuple[int, int], shape1: Tuple[int, int], sinkhorn_iterations: int = 20,
                   match_threshold: float = 0.3, n_layers: int = 18, kpts=None, scores=None, desc=None, n=None) -> None:
@@ -181,7 +188,7 @@ class Engine:
         conf = SuperGlueConf(int(sinkhorn_iterations), float(match_threshold), int(n_layers))
         shp = np.array([shape0[0], shape0[1], shape1[0], shape1[1]], dtype=np.float32)
         self.ctx.call("im_superglue_forward", ptr(kpts), ptr(scores), ptr(desc), ptr(n), shp.ctypes.data, C.byref(conf),
-                      ptr(self.matches), ptr(self.mscores), ptr(self.info), _lib.stream_ptr())
+                      ptr(self.matches), ptr(self.mscores), ptr(self.info), self.stream_ptr())
 
     # ------------------------------------------------------------------ results to host (synchronises)
     def features_to_host(self, image: int, channels_first: bool = False):

@@ -63,9 +63,19 @@ MAGSAC_SIGMA_MAX, MAGSAC_K, MAGSAC_CONF, MAGSAC_ITERS = 0.5, 3.64, 0.999, 100000
 DEVICE_BATCH = 1024                                                               # hypotheses per launch pair
 
 
+NEEDED_CAP = 1 << 30   # "keep sampling until max_iters": what the criterion says when (almost) nothing is an inlier yet
+
+
 def _needed(confidence: float, w: float) -> int:
-    w = min(max(w, 1e-9), 1 - 1e-9)
-    return int(np.ceil(np.log(max(1 - confidence, 1e-12)) / np.log(1 - w ** 8)))
+    """Hypotheses needed so that, with inlier ratio w, one all-inlier 8-point sample has been drawn with probability
+    `confidence`: log(1 - confidence) / log(1 - w^8). For w below ~1 % the denominator underflows (w^8 < 1e-16): log1p keeps
+    it exact down to the smallest positive double, and a zero denominator (w = 0) answers NEEDED_CAP instead of dividing."""
+    w = min(max(float(w), 0.0), 1 - 1e-9)
+    den = np.log1p(-(w ** 8))
+    if not den < 0.0:
+        return NEEDED_CAP
+    need = np.log(max(1 - confidence, 1e-12)) / den
+    return int(min(np.ceil(need), NEEDED_CAP))
 
 
 def geometric_verification(mkpts0: np.ndarray = None, mkpts1: np.ndarray = None,
@@ -246,7 +256,7 @@ def _finish(p0, p1, best_mask, thr2, method, n, degeneracy_check=True, seed=0):
 def _ransac_on_device(engine, mkpts0: np.ndarray, mkpts1: np.ndarray, threshold: float, n_hyp: int, seed: int) -> np.ndarray:
     """All hypotheses in one launch pair (`im_ransac_fundamental`); returns the inlier mask of the best one."""
     import torch
-    from .._lib import ptr, stream_ptr
+    from .._lib import ptr
     dev = engine.device
     d0 = torch.from_numpy(np.ascontiguousarray(mkpts0, dtype=np.float32)).to(dev)
     d1 = torch.from_numpy(np.ascontiguousarray(mkpts1, dtype=np.float32)).to(dev)
@@ -255,5 +265,5 @@ def _ransac_on_device(engine, mkpts0: np.ndarray, mkpts1: np.ndarray, threshold:
     dmask = torch.empty(n, dtype=torch.uint8, device=dev)
     dinfo = torch.empty(2, dtype=torch.int32, device=dev)
     engine.ctx.call("im_ransac_fundamental", ptr(d0), ptr(d1), n, int(n_hyp), float(threshold), int(seed) & 0xFFFFFFFF,
-                    ptr(dF), ptr(dmask), ptr(dinfo), stream_ptr())
+                    ptr(dF), ptr(dmask), ptr(dinfo), engine.stream_ptr())
     return dmask.cpu().numpy().astype(bool)

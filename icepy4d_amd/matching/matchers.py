@@ -10,9 +10,14 @@ copies the results back once.
 
 Observable quirks of the reference are kept where downstream code can depend on them (q1: LightGlueMatcher with
 TileSelection.NONE stores the *unfiltered* keypoints; q4: tiles lose their last row/column; q5: `mconf` of
-SuperGlue / tile modes is the keypoint score; q6: tile matches are re-ordered by `np.unique`), and fixed where
-they are plain bugs that cannot be relied on (q2: `min_matches_per_tile` is honoured; q7: no bare `except`;
-q9: no Tk import). Weights: the reference downloads / reads `.pth` files at construction; here a state dict (official
+SuperGlue / tile modes is the keypoint score; q6: tile matches are re-ordered by `np.unique`). Two more are plain bugs,
+but they change RESULTS, so they are reproduced by default and can be switched off together with `opt["reference_quirks"] =
+False`: q2 - the reference hands its options to `_tile_selection` as ONE keyword (`config=config`, `matchers.py:353-355`), so
+`min_matches_per_tile` is never found there and the preselection threshold is always 5 (`:502`), whatever the caller passes
+(`main_dev.py:127` passes 3); q7 - a bare `except` around `extract(..., resize=)` silently retries without `resize`
+(`:1262-1267`). With the switch off `min_matches_per_tile` is honoured and errors of the resize path propagate. The golden
+`tests/golden/g8_preselection.npz` (the reference's own `match()` in PRESELECTION mode) pins the default. q9 (Tk import at
+module load) is not reproduced. Weights: the reference downloads / reads `.pth` files at construction; here a state dict (official
 key names) is passed through `opt["state_dicts"]` or `opt["weights_dir"]`.
 """
 from __future__ import annotations
@@ -61,6 +66,18 @@ def get_engine(device: int = 0, state_dicts: Optional[Dict[str, dict]] = None, p
     for m, sd in (state_dicts or {}).items():
         eng.load_state_dict(m, sd)
     return eng
+
+
+def _on_engine_device(method):
+    """Runs a matcher method with the engine's device as torch's current device (streams, allocations, graph replays and
+    synchronisation then refer to that device whatever the caller's current device is: one process may hold matchers on several GPUs)."""
+    import functools
+
+    @functools.wraps(method)
+    def wrapped(self, *args, **kwargs):
+        with torch.cuda.device(self.engine.device):
+            return method(self, *args, **kwargs)
+    return wrapped
 
 
 def check_dict_keys(dict: dict, keys: List[str]):
@@ -193,6 +210,8 @@ class ImageMatcherBase(ImageMatcherABC):
         if not isinstance(opt, dict):
             raise TypeError("opt must be a dictionary")
         self._opt = dict(opt)
+        # True (default): results identical to the reference also where it ignores an option by accident (q2, q7: module docstring)
+        self._reference_quirks = bool(opt.get("reference_quirks", True))
         if opt.get("force_cpu"):
             logger.warning("force_cpu is ignored: the MI355X build has no CPU path")
         self._device_index = int(opt.get("device", 0))
@@ -227,6 +246,7 @@ class ImageMatcherBase(ImageMatcherABC):
     mconf = property(lambda self: self._mconf)
 
     @timeit
+    @_on_engine_device
     def match(self, image0: np.ndarray, image1: np.ndarray, quality: Quality = Quality.HIGH,
               tile_selection: TileSelection = TileSelection.NONE, **config) -> bool:
         """Matches images and performs geometric verification (`matchers.py:139-261`)."""
@@ -338,7 +358,15 @@ class ImageMatcherBase(ImageMatcherABC):
             rect = np.asarray(rect)
             return np.all(points > rect[:2], axis=1) & np.all(points < rect[2:], axis=1)
 
-        min_matches_per_tile = config.get("min_matches_per_tile", MIN_MATCHES_PER_TILE)
+        if self._reference_quirks:
+            # q2: the reference's caller passes `config=config` (`matchers.py:353-355`), so this lookup never finds the option there
+            # (`:502`) and the threshold is always MIN_MATCHES_PER_TILE = 5 - also for `main_dev.py:127`'s min_matches_per_tile=3
+            if config.get("min_matches_per_tile", MIN_MATCHES_PER_TILE) != MIN_MATCHES_PER_TILE:
+                logger.info(f"min_matches_per_tile={config['min_matches_per_tile']} is ignored as in the reference (threshold "
+                            f"{MIN_MATCHES_PER_TILE}); pass opt['reference_quirks']=False to honour it")
+            min_matches_per_tile = MIN_MATCHES_PER_TILE
+        else:
+            min_matches_per_tile = config.get("min_matches_per_tile", MIN_MATCHES_PER_TILE)
         if method == TileSelection.EXHAUSTIVE:
             return sorted(product(t0_lims.keys(), t1_lims.keys()))
         if method == TileSelection.GRID:
@@ -419,6 +447,16 @@ class ImageMatcherBase(ImageMatcherABC):
         path.mkdir(parents=True, exist_ok=True)
         np.savetxt(path / "keypoints_0.txt", self.mkpts0, delimiter=delimiter, newline="\n", header=header)
         np.savetxt(path / "keypoints_1.txt", self.mkpts1, delimiter=delimiter, newline="\n", header=header)
+
+    # ------------------------------------------------------------------ visualisation entry points (out of scope: accepted, skipped)
+    def viz_matches_mpl(self, *args, **kwargs) -> None:
+        """`matchers.py:702-737` draws with matplotlib; visualisation is outside the hot-path scope: accepted and skipped with a
+        warning, so that scripts written against the reference keep running."""
+        logger.warning("viz_matches_mpl(): nothing is drawn (visualisation is out of scope of icepy4d_amd)")
+
+    def viz_matches_cv2(self, *args, **kwargs) -> None:
+        """`matchers.py:739-800` (OpenCV drawing): accepted and skipped with a warning."""
+        logger.warning("viz_matches_cv2(): nothing is drawn (visualisation is out of scope of icepy4d_amd)")
 
     # ------------------------------------------------------------------ per-tile feature cache (tile modes)
     def _sp_params(self, **config):
@@ -504,7 +542,7 @@ class ImageMatcherBase(ImageMatcherABC):
         # one library call for the whole tail of the loop (`im_merge_tile_matches`): selection of the valid matches of every
         # pair, the two fp32 origin shifts, `np.unique(axis=0, return_index=True)` (lexicographic order, first occurrence) by
         # counting ranks on the device; then row gathers of descriptors / scores for the surviving matches only
-        from .._lib import ptr, stream_ptr
+        from .._lib import ptr
         slots = torch.tensor([[slot[(0, a)], slot[(1, b)]] for a, b in tile_pairs], dtype=torch.int32, device=dev)
         off = torch.tensor([[float(t0_lims[a][0]), float(t0_lims[a][1]), float(t1_lims[b][0]), float(t1_lims[b][1])]
                             for a, b in tile_pairs], dtype=torch.float32, device=dev)
@@ -517,12 +555,12 @@ class ImageMatcherBase(ImageMatcherABC):
         kp1 = torch.empty(cap, 2, device=dev)
         NN32 = NN.to(torch.int32)
         eng.ctx.call("im_merge_tile_matches", P, K, ptr(M), ptr(slots), ptr(off), origin.ctypes.data, ptr(KP), ptr(NN32), ptr(count),
-                     ptr(idx0), ptr(idx1), ptr(kp0), ptr(kp1), stream_ptr())
+                     ptr(idx0), ptr(idx1), ptr(kp0), ptr(kp1), eng.stream_ptr())
         S = int(count.item())                                       # the only host round trip of the tile loop
         out = []
         for idx, cols, bank in ((idx0, 256, DE), (idx1, 256, DE), (idx0, 1, SC), (idx1, 1, SC)):
             dst = torch.empty(S, cols, device=dev)
-            eng.ctx.call("im_gather_rows", ptr(bank), cols, ptr(idx), S, ptr(dst), stream_ptr())
+            eng.ctx.call("im_gather_rows", ptr(bank), cols, ptr(idx), S, ptr(dst), eng.stream_ptr())
             out.append(dst)
         d0, d1, sc0, sc1 = out
         features0 = FeaturesBase(keypoints=kp0[:S].cpu().numpy(), descriptors=np.ascontiguousarray(d0.cpu().numpy().T),
@@ -589,6 +627,10 @@ class SuperGlueMatcher(ImageMatcherBase):
         sp_keys, sg_keys = ("nms_radius", "keypoint_threshold", "max_keypoints"), ("weights", "sinkhorn_iterations", "match_threshold")
         return {"superpoint": {k: o[k] for k in sp_keys}, "superglue": {k: o[k] for k in sg_keys}, "force_cpu": o["force_cpu"]}
 
+    def viz_matches(self, *args, **kwargs) -> None:
+        """`matchers.py:942-1002` (SuperGlue's own plot): accepted and skipped with a warning."""
+        logger.warning("viz_matches(): nothing is drawn (visualisation is out of scope of icepy4d_amd)")
+
     def _sp_params(self, **config):
         sp = self._cfg["superpoint"]
         return sp["nms_radius"], sp["keypoint_threshold"], 4, int(sp["max_keypoints"]), 1
@@ -600,11 +642,12 @@ class SuperGlueMatcher(ImageMatcherBase):
 
     def _match_cached(self, c0: dict, c1: dict, **config):
         self._enqueue_cached(c0, c1, **config)
-        torch.cuda.synchronize()
+        self.engine.synchronize()
         f0, f1, out = self._features_from_engine()
         matches0 = out["matches0"]
         return f0, f1, matches0, f0.scores[matches0 > -1]
 
+    @_on_engine_device
     def _match_images(self, image0: np.ndarray, image1: np.ndarray, **config):
         """`SuperGlueMatcher._match_images` (`matchers.py:892-940`) on the GPU."""
         g0, g1 = _as_device_image(image0), _as_device_image(image1)
@@ -629,7 +672,7 @@ class SuperGlueMatcher(ImageMatcherBase):
             cap = max(n_cand)
             logger.info(f"SuperPoint found {cap} candidates: growing the keypoint workspace from {eng.max_kpts}")
         eng.superglue(g0.shape[:2], g1.shape[:2], sg["sinkhorn_iterations"], sg["match_threshold"])
-        torch.cuda.synchronize()
+        self.engine.synchronize()
         k0, d0, s0 = eng.features_to_host(0, channels_first=True)
         k1, d1, s1 = eng.features_to_host(1, channels_first=True)
         out = eng.matches_to_host(len(k0), len(k1))
@@ -638,6 +681,16 @@ class SuperGlueMatcher(ImageMatcherBase):
         matches0 = out["matches0"]
         mconf = features0.scores[matches0 > -1]  # q5 (`matchers.py:936-938`)
         return features0, features1, matches0, mconf
+
+
+class LOFTRMatcher(ImageMatcherBase):
+    """The reference's kornia-hosted LoFTR matcher (`matchers.py:1005-1200`) is outside the hot-path scope (BASELINE north_star names
+    SuperPoint / SuperGlue / LightGlue). The NAME exists, as in the reference's `from .matchers import *`, so that imports keep
+    working; constructing one fails loudly instead of silently matching with something else."""
+
+    def __init__(self, opt: dict = {}) -> None:
+        raise NotImplementedError("LOFTRMatcher is not part of icepy4d_amd (the MI355X build covers SuperGlueMatcher and "
+                                  "LightGlueMatcher); use the reference implementation for LoFTR")
 
 
 class LightGlueMatcher(ImageMatcherBase):
@@ -675,18 +728,24 @@ class LightGlueMatcher(ImageMatcherBase):
 
     def _match_cached(self, c0: dict, c1: dict, **config):
         self._enqueue_cached(c0, c1, **config)
-        torch.cuda.synchronize()
+        self.engine.synchronize()
         f0, f1, out = self._features_from_engine()
         matches0 = out["matches0"]
         self._last = out
         return f0, f1, matches0, out["matching_scores0"][matches0 > -1]
 
+    @_on_engine_device
     def _match_images(self, image0: np.ndarray, image1: np.ndarray, **config):
         """`LightGlueMatcher._match_images` (`matchers.py:1226-1304`) on the GPU: returns
         (FeaturesBase, FeaturesBase, matches0 [K] int64, mconf [S] = scores of the valid matches)."""
         max_keypoints = config.get("max_keypoints", 10240)
         if config.get("resize", None) is not None:
-            return self._match_images_resized(image0, image1, int(config["resize"]), int(max_keypoints))
+            if not self._reference_quirks:
+                return self._match_images_resized(image0, image1, int(config["resize"]), int(max_keypoints))
+            try:
+                return self._match_images_resized(image0, image1, int(config["resize"]), int(max_keypoints))
+            except Exception as e:   # q7 (`matchers.py:1262-1267`): any failure of the resize path silently extracts without it
+                logger.debug(f"extract(resize={config['resize']!r}) failed ({e}): retrying without resize, as the reference does")
         g0, g1 = _as_device_image(image0), _as_device_image(image1)
         eng = self.engine
         eng.reserve(max(g0.shape[0], g1.shape[0]), max(g0.shape[1], g1.shape[1]), 2, int(max_keypoints))
@@ -715,7 +774,7 @@ class LightGlueMatcher(ImageMatcherBase):
             for slot, up in enumerate(self._upload_pair(g0, g1)):   # one batched launch, or one per image if the sizes differ
                 eng.superpoint(up, 4, 0.0005, 4, int(max_keypoints), flavour=0, slot=slot)
             eng.lightglue((g0.shape[1], g0.shape[0]), (g1.shape[1], g1.shape[0]), **self._lg_conf)
-        torch.cuda.synchronize()
+        self.engine.synchronize()
         k0, d0, s0 = eng.features_to_host(0, channels_first=True)
         k1, d1, s1 = eng.features_to_host(1, channels_first=True)
         out = eng.matches_to_host(len(k0), len(k1))
@@ -739,7 +798,7 @@ class LightGlueMatcher(ImageMatcherBase):
             s_ = torch.from_numpy(sc[slot]).to(eng.device)
             eng.kpts[slot] = (eng.kpts[slot] + 0.5) / s_[None, :] - 0.5
         eng.lightglue((image0.shape[1], image0.shape[0]), (image1.shape[1], image1.shape[0]), **self._lg_conf)
-        torch.cuda.synchronize()
+        self.engine.synchronize()
         f0, f1, out = self._features_from_engine()
         matches0 = out["matches0"]
         self._last = out

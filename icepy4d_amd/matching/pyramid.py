@@ -22,7 +22,7 @@ def _levels(engine, image: np.ndarray, levels: int) -> np.ndarray:
             else:
                 oh, ow = 2 * h, 2 * w
             out = torch.empty((oh, ow, c), dtype=torch.uint8, device=engine.device)
-            engine.ctx.call("im_pyr_down" if levels > 0 else "im_pyr_up", _lib.ptr(cur), _lib.ptr(out), 1, h, w, c, _lib.stream_ptr())
+            engine.ctx.call("im_pyr_down" if levels > 0 else "im_pyr_up", _lib.ptr(cur), _lib.ptr(out), 1, h, w, c, engine.stream_ptr())
             cur, h, w = out, oh, ow
         res = cur.cpu().numpy()
     return res[:, :, 0] if image.ndim == 2 else res

@@ -44,12 +44,15 @@ def new_table(n_rows: int, max_kpts: int, device, with_keypoints: bool = False) 
 
 def write_records(table: torch.Tensor, row: int, first_epoch: int, n_pairs: int, engine) -> None:
     """Rows row .. row + n_pairs - 1 of `table` from the outputs of the engine's last `lightglue(n_pairs=...)`: one kernel."""
-    from ._lib import ptr, stream_ptr
+    from ._lib import ptr
     K = engine.max_kpts
-    assert table.shape[1] in (HEADER + 2 * K, HEADER + 6 * K) and table.is_contiguous() and row + n_pairs <= table.shape[0]
+    if table.shape[1] not in (HEADER + 2 * K, HEADER + 6 * K):
+        raise ValueError(f"match table rows are {table.shape[1]} words wide; records of this engine (K = {K}) are {HEADER + 2 * K} "
+                         f"or, with keypoints, {HEADER + 6 * K}")
+    assert table.is_contiguous() and row + n_pairs <= table.shape[0]
     kpts = ptr(engine.kpts) if table.shape[1] == HEADER + 6 * K else None     # keypoint payload: engine.kpts [2 P][K][2]
     engine.ctx.call("im_pack_records", int(n_pairs), ptr(engine.n), ptr(engine.matches), ptr(engine.mscores), ptr(engine.info),
-                    int(first_epoch), table[row].data_ptr(), kpts, stream_ptr())
+                    int(first_epoch), table[row].data_ptr(), kpts, engine.stream_ptr())
 
 
 def write_record(table: torch.Tensor, row: int, epoch: int, n: torch.Tensor, matches0: torch.Tensor,
@@ -58,10 +61,10 @@ def write_record(table: torch.Tensor, row: int, epoch: int, n: torch.Tensor, mat
     by one library kernel (`im_pack_record`); the torch indexing path is the CPU twin used by the gloo tests."""
     K = matches0.shape[0]
     if engine is not None and table.is_cuda:
-        from ._lib import ptr, stream_ptr
+        from ._lib import ptr
         assert table.shape[1] == HEADER + 2 * K and table.is_contiguous()
         engine.ctx.call("im_pack_record", ptr(n), ptr(matches0), ptr(mscores0), ptr(info), int(epoch),
-                        table[row].data_ptr(), stream_ptr())
+                        table[row].data_ptr(), engine.stream_ptr())
         return
     r = table[row]
     r[0:1].fill_(epoch)   # a fill kernel (a scalar assignment would be a host->device copy: not capturable)
@@ -192,19 +195,21 @@ class SequenceMatcher:
         write_records(table, row, epoch, n_pairs, self.e)
 
     def _capture(self) -> None:
-        cur = torch.cuda.current_stream()
-        side = torch.cuda.Stream(device=self.e.device)
-        side.wait_stream(cur)
-        with torch.cuda.stream(side):  # warm-up outside capture: lazy kernel attributes, allocator pools
-            for _ in range(2):
+        dev = self.e.device
+        with torch.cuda.device(dev):       # the capture stream torch creates belongs to the CURRENT device: make that the engine's
+            cur = torch.cuda.current_stream(dev)
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):  # warm-up outside capture: lazy kernel attributes, allocator pools
+                for _ in range(2):
+                    self._enqueue(self._inp)
+                    self._record(self._rec, 0, 0, self.P)
+            cur.wait_stream(side)
+            torch.cuda.synchronize(dev)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
                 self._enqueue(self._inp)
                 self._record(self._rec, 0, 0, self.P)
-        cur.wait_stream(side)
-        torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            self._enqueue(self._inp)
-            self._record(self._rec, 0, 0, self.P)
         self._graph = g
 
     def _run_group(self) -> None:
@@ -221,6 +226,10 @@ class SequenceMatcher:
                 self._capture()
             self._graph.replay()
         for j, (epoch, table, row) in enumerate(pend):
+            if table.shape[1] != self._rec.shape[1]:
+                raise ValueError(f"match table rows are {table.shape[1]} words wide, this matcher writes records of {self._rec.shape[1]} "
+                                 f"(with_keypoints={self._rec.shape[1] == record_words(self.e.max_kpts, True)}): build the table with "
+                                 "new_table(..., with_keypoints=) to match the matcher's")
             table[row].copy_(self._rec[j], non_blocking=True)
             table[row, 0:1].fill_(epoch)
 
@@ -243,9 +252,10 @@ class SequenceMatcher:
         """The same for a pair in HOST memory (what the reference's loop has after `cv2.imread`, `core/images.py:44-93` ->
         `main_dev.py:115-132`): numpy uint8 [2, H, W] (or [2, H, W, 3]). The pair is copied into a page-locked staging buffer
         (a ring of 2 P + 2 buffers, so that the host never rewrites a buffer whose upload may still be in flight) and uploaded
-        with an asynchronous copy on the CURRENT stream, in front of the launches that read it: no synchronisation, the
-        upload of one pair overlaps the kernels of the previous one. Before a staging buffer is reused its last upload is
-        waited for through an event - by then two launch groups old."""
+        with an asynchronous copy on the CURRENT stream, in front of the launches that read it: no host synchronisation. On ONE
+        stream the copy is ordered behind the launches already enqueued there (it does not overlap them); overlap of uploads and
+        kernels comes from `PairPipeline`'s other slots, whose streams run kernels while this slot's copy is in flight. Before a
+        staging buffer is reused its last upload is waited for through an event - by then two launch groups old."""
         if self._pinned is None:
             shape = tuple(self._inp.shape[1:])
             self._pinned = [[torch.empty((2,) + shape, dtype=torch.uint8).pin_memory(), None] for _ in range(2 * self.P + 2)]
@@ -259,7 +269,7 @@ class SequenceMatcher:
         j = len(self._pending) if (self.P > 1 or self.use_graph) else 0
         self._inp[2 * j:2 * j + 2].copy_(slot[0], non_blocking=True)
         slot[1] = torch.cuda.Event()
-        slot[1].record()
+        slot[1].record(torch.cuda.current_stream(self.e.device))
         if self.P == 1 and not self.use_graph:
             self._enqueue(self._inp)
             self._record(table, row, epoch, 1)

@@ -41,13 +41,13 @@ def triangulate_points_linear(P1, P2, x1, x2, engine=None) -> np.ndarray:
     P1, P2 = np.asarray(P1, np.float64), np.asarray(P2, np.float64)
     if engine is not None:
         import torch
-        from ._lib import ptr, stream_ptr
+        from ._lib import ptr
         n = len(x1)
         d1 = torch.from_numpy(np.ascontiguousarray(x1)).to(engine.device)
         d2 = torch.from_numpy(np.ascontiguousarray(x2)).to(engine.device)
         dX = torch.empty((n, 4), dtype=torch.float64, device=engine.device)
         p1, p2 = np.ascontiguousarray(P1.reshape(12)), np.ascontiguousarray(P2.reshape(12))
-        engine.ctx.call("im_triangulate_linear", p1.ctypes.data, p2.ctypes.data, ptr(d1), ptr(d2), n, ptr(dX), stream_ptr())
+        engine.ctx.call("im_triangulate_linear", p1.ctypes.data, p2.ctypes.data, ptr(d1), ptr(d2), n, ptr(dX), engine.stream_ptr())
         return dX.cpu().numpy()
     A = np.stack([x1[:, 0:1] * P1[2] - x1[:, 2:3] * P1[0], x1[:, 1:2] * P1[2] - x1[:, 2:3] * P1[1],
                   x2[:, 0:1] * P2[2] - x2[:, 2:3] * P2[0], x2[:, 1:2] * P2[2] - x2[:, 2:3] * P2[1]], axis=1)   # [n, 4, 4]
@@ -158,7 +158,7 @@ def _essential_ransac_on_device(engine, x0: np.ndarray, x1: np.ndarray, threshol
     until the confidence criterion holds for the best inlier ratio; then one refit on the inliers of the winner (8-point on all
     of them, projected onto the essential manifold) that is kept if it does not lose inliers. Returns (E, inlier mask)."""
     import torch
-    from ._lib import ptr, stream_ptr
+    from ._lib import ptr
     from .matching.geometric_verification import DEVICE_BATCH, _eight_point, _needed, _sampson
     dev = engine.device
     d0 = torch.from_numpy(np.ascontiguousarray(x0, dtype=np.float32)).to(dev)
@@ -171,7 +171,7 @@ def _essential_ransac_on_device(engine, x0: np.ndarray, x1: np.ndarray, threshol
     done, needed = 0, int(max_iters)
     while done < min(needed, int(max_iters)):
         engine.ctx.call("im_ransac_essential", ptr(d0), ptr(d1), n, DEVICE_BATCH, float(threshold), (int(seed) + done) & 0xFFFFFFFF,
-                        ptr(dE), ptr(dmask), ptr(dinfo), stream_ptr())
+                        ptr(dE), ptr(dmask), ptr(dinfo), engine.stream_ptr())
         done += DEVICE_BATCH
         cnt = int(dinfo[0].item())
         if cnt > best[0]:

@@ -126,6 +126,15 @@ int im_pack_records(im_ctx* ctx, int n_pairs, const int32_t* d_n, const int32_t*
 /* Copies an internal buffer of the last forward ("lg_x", "lg_cos", "lg_sin", "sim", "md", "sp_smap", "sp_nms") for
  * stage-level parity tests. */
 int im_debug_read(im_ctx* ctx, const char* name, float* d_dst, size_t nfloats, void* stream);
+/* Debugging aid (no reference counterpart; GPU AddressSanitizer is unavailable on the MI355X pool): with IM_DEBUG_GUARDS=1 in the
+ * environment when a context is created, every device buffer the library allocates (workspace of im_ctx_reserve, packed weights,
+ * scratch) carries 256 bytes of guard words on both sides; they are compared by a small kernel at the end of every forward /
+ * stage entry point, before a buffer is freed and in im_ctx_destroy. A changed word fails that call with -90 (im_last_error names
+ * the buffer and the side) and is counted here: number of guard failures seen by this process so far (0 when the mode is off). */
+int im_debug_guard_failures(void);
+/* Self-test of that mode: issues one stray 4-byte store right behind the newest library buffer, expects the check to fail with
+ * -90, restores the word. Returns 0 when the stray store was caught, -93 when the mode is off, -94 when it went unnoticed. */
+int im_debug_guard_selftest(im_ctx* ctx, void* stream);
 
 /* ---- stage entry points (what the stage-isolated parity tests call; also usable on their own) ----------- */
 /* C[m][n] = alpha * (sum_k A[m][k] W[n][k] + bias[n]); fp32 MFMA GEMM. bias may be NULL. big_tile: 128x128 tiles. */

@@ -22,3 +22,17 @@ def golden_dir():
 def load_golden(name):
     import numpy as np
     return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """IM_DEBUG_GUARDS=1 (tools/stress_gpu_suite.sh): a guard word the library found overwritten anywhere in the session fails
+    the run, also when the test that caused it swallowed the -90 (e.g. inside a destructor)."""
+    if os.environ.get("IM_DEBUG_GUARDS") != "1":
+        return
+    from icepy4d_amd import _lib
+    if _lib._lib is None:
+        return
+    n = _lib._lib.im_debug_guard_failures()
+    print(f"\nIM_DEBUG_GUARDS: {n} guard failure(s) in this session")
+    if n and session.exitstatus == 0:
+        session.exitstatus = 1

@@ -152,10 +152,13 @@ def run_case(eng, img0, img1, sp_sd, lg_sd, max_k, lg_conf=None, radius=4, thr=0
     return rep
 
 
-def run_case_superglue(eng, img0, img1, sp_sd, sg_sd, max_k, radius=3, thr=0.001, border=4, iters=20, match_thr=0.3):
+def run_case_superglue(eng, img0, img1, sp_sd, sg_sd, max_k, radius=3, thr=0.001, border=4, iters=20, match_thr=0.3, check_ot=False):
     """The same chain A-D for the SuperGlue flavour (`SuperGlueMatcher._match_images`, `matchers.py:892-940`): MagicLeap-flavour
     SuperPoint selection, keypoint encoder + 18 GNN layers + optimal transport + mutual filter; C uses the oracle's optimal
-    transport matrix of the DEVICE's features for the arg-max / threshold margins. The engine must hold `sg_sd`."""
+    transport matrix of the DEVICE's features for the arg-max / threshold margins. The engine must hold `sg_sd`.
+    check_ot: additionally (E) the device's score matrix (`superglue.py:279-280`) against the oracle's on the same features, and the
+    device's Sinkhorn (`im_log_optimal_transport`) against `o.log_optimal_transport` on the DEVICE's OWN score matrix
+    (`superglue.py:152-186`): max abs differences, at the full (n0 + 1) x (n1 + 1) size."""
     from oracle import ref_cpu as o
     h, w = img0.shape
     assert img1.shape == img0.shape
@@ -218,6 +221,25 @@ def run_case_superglue(eng, img0, img1, sp_sd, sg_sd, max_k, radius=3, thr=0.001
         "n_matches_oracle": int((m0_same > -1).sum()), "matches0_diff": exm["n_diff"], "diff_reasons": exm["reasons"],
         "unexplained": exm["unexplained"], "stop_device": 0, "stop_oracle": 0, "prune0_equal": True, "prune1_equal": True,
         "mscore_max_abs_err": float(np.abs(out["matching_scores0"][v] - same["matching_scores0"].numpy()[v]).max()) if v.any() else 0.0}
+    if check_ot:
+        from icepy4d_amd._lib import ptr
+        K, n0, n1 = eng.max_kpts, len(k0), len(k1)
+        sim_d = torch.empty(K * K, device=eng.device)
+        eng.ctx.call("im_debug_read", b"sim", sim_d.data_ptr(), K * K, eng.stream_ptr())      # the forward's own score matrix, row stride K
+        zout = torch.empty((n0 + 1) * (n1 + 1), device=eng.device)
+        eng.ctx.call("im_log_optimal_transport", ptr(sim_d), n0, n1, K, float(sg_sd["bin_score"]), iters, ptr(zout), eng.stream_ptr())
+        torch.cuda.synchronize()
+        sim_h = sim_d.view(K, K)[:n0, :n1].cpu().contiguous()
+        z_d = zout.view(n0 + 1, n1 + 1).cpu()
+        del sim_d, zout
+        with torch.inference_mode():
+            z_o = o.log_optimal_transport(sim_h[None], sg_sd["bin_score"], iters)[0]
+        rep["sinkhorn_on_device_scores"] = {
+            "rows": n0 + 1, "cols": n1 + 1, "iterations": iters,
+            "scores_max_abs_err_vs_oracle_same_features": float((sim_h - tr["scores"]).abs().max()),
+            "ot_max_abs_err": float((z_d - z_o).abs().max()),
+            "ot_max_abs_err_vs_oracle_same_features": float((z_d - tr["ot"]).abs().max())}
+        del z_o, z_d, sim_h
     ours = margins.match_pairs(k0, k1, out["matches0"])
     theirs = margins.match_pairs(feats_o[0][0].numpy(), feats_o[1][0].numpy(), e2e["matches0"].numpy())
     rep["end_to_end"] = {"pairs_device": len(ours), "pairs_oracle": len(theirs), "pairs_common": len(ours & theirs),
@@ -245,6 +267,9 @@ def main():
     ap.add_argument("--no-full", action="store_true")
     ap.add_argument("--epochs", type=int, default=0, help="additional configs[1] bench pairs (epochs 1..N), LightGlue")
     ap.add_argument("--superglue", action="store_true", help="SuperGlue-flavour cases (SuperPoint nms 3 + SuperGlue), incl. 1080p / 4096")
+    ap.add_argument("--config5", action="store_true", help="ONLY the BASELINE configs[4] size: 3000x4000 pair, 16384 keypoints, SuperGlue with 20 "
+                    "Sinkhorn iterations, incl. the Sinkhorn / score-matrix comparison at 16385 x 16385 (minutes of oracle time)")
+    ap.add_argument("--config5-mid", action="store_true", help="with --config5: also the 2000x3000 / 8192-keypoint case of the GPU suite")
     args = ap.parse_args()
     from icepy4d_amd.engine import Engine
     torch.set_num_threads(min(32, os.cpu_count() or 1))
@@ -254,7 +279,19 @@ def main():
     eng.load_state_dict("superpoint", sp_sd)
     eng.load_state_dict("lightglue", lg_sd)
     report = {"conv": "direct" if os.environ.get("IM_CONV_DIRECT") == "1" else "winograd", "cases": {}}
-    for name, a, b, k in cases(not args.no_full):
+    if args.config5:
+        sg_sd = synthetic.superglue_state_dict(0, "passthrough")
+        eng.load_state_dict("superglue", sg_sd)
+        big = []
+        if args.config5_mid:
+            big.append(("superglue: translated pair (2000x3000, K=8192)",) + synthetic.translated_pair(6, 2000, 3000, 48, 16) + (8192,))
+        big.append(("superglue: configs[4] translated pair (3000x4000, K=16384)",) + synthetic.translated_pair(5, 3000, 4000, 48, 16) + (16384,))
+        for name, a, b, k in big:
+            t = time.time()
+            report["cases"][name] = run_case_superglue(eng, a, b, sp_sd, sg_sd, k, check_ot=True)
+            report["cases"][name]["seconds"] = round(time.time() - t, 1)
+            print(name, json.dumps(report["cases"][name]), flush=True)
+    for name, a, b, k in ([] if args.config5 else cases(not args.no_full)):
         t = time.time()
         report["cases"][name] = run_case(eng, a, b, sp_sd, lg_sd, k)
         report["cases"][name]["seconds"] = round(time.time() - t, 1)

@@ -160,7 +160,8 @@ def test_config3_timed_launch_mode_equals_direct_launches_and_the_oracle():
 
 
 @pytest.mark.parametrize("flags", [["--steps", "5", "--warmup", "3"], ["--steps", "2", "--warmup", "0"],
-                                   ["--steps", "4", "--warmup", "2", "--config", "4", "--pool", "2"]])
+                                   ["--steps", "4", "--warmup", "2", "--config", "4", "--pool", "2"],
+                                   ["--steps", "10", "--warmup", "2", "SIDE"]])
 def test_bench_line_with_odd_step_counts(flags):
     """`python bench.py --gpus 1 --steps K --warmup W` as the round driver types it, with counts that do not fill the launch
     groups (ten pairs each by default): one JSON line with the contract fields, every step recorded, a throughput in the range of the device
@@ -171,8 +172,10 @@ def test_bench_line_with_odd_step_counts(flags):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", *flags, "--no-cpu-baseline", "--no-side-measurements"],
-                       env=env, capture_output=True, text=True, timeout=600)
+    side = "SIDE" in flags                  # the default line's side measurements (configs[2] / configs[4] / one match() call) ride along
+    flags = [f for f in flags if f != "SIDE"]
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", *flags, "--no-cpu-baseline",
+                        *([] if side else ["--no-side-measurements"])], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout
@@ -181,5 +184,13 @@ def test_bench_line_with_odd_step_counts(flags):
     assert d["config"]["mean_keypoints"] == 4096 and d["roofline"]["bound"] == "mfma" and 0.5 < d["roofline"]["frac"] < 1.0
     assert d["value"] > 5.0, d["value"]      # a sanity bound, not a performance threshold (a cold or shared device is slower)
     assert "all_gather_ms" in d and "traffic_source" in d["roofline"] and "pair_executed_mfma_utilisation" in d
+    if side:
+        sm = d["side_measurements"]
+        c3, c5, mc = sm["config3_distinct_epochs"], sm["config5"], sm["match_call_ms"]
+        assert c3["pairs"] >= 60 and c3["epochs_distinct_and_in_order"] and c3["pairs_per_s"] > 5.0
+        assert c5["pairs"] == 3 and c5["mean_keypoints"] == 16384 and c5["pairs_per_s"] > 0.5
+        assert 0.5 < c5["attention"]["frac_of_fp32_mfma_peak"] < 1.0 and 1.0 < c5["sinkhorn"]["solve_ms"] < 50.0
+        assert 1.0 < mc["median"] < 500.0 and mc["keypoints"] == 4096
+        assert sm["other_launch_mode"]["pairs_per_s"] > 5.0 and sm["host_inputs_pairs_per_s"]["pairs_per_s"] > 5.0
     if "--config" in flags:                 # configs[3] on one rank: 98 KB records (keypoints of both images ride along)
         assert "98 KB records" in d["config"]["workload"] and "configs[3]" in d["config"]["workload"]

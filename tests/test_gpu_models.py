@@ -822,6 +822,59 @@ def test_pyramid_kernels_bit_exact(shape):
     assert np.array_equal(pyramid.pyr_up(img, eng, 2), pyramid_cpu.pyr_up(pyramid_cpu.pyr_up(img)))
 
 
+def test_preselection_call_equals_the_reference_golden():
+    """G8 (`tests/golden/g8_preselection.npz`, written by the reference's own `match()`): the production call of
+    `main_dev.py:115-132` - TileSelection.PRESELECTION, a grid, an overlap, `min_matches_per_tile=3` - gives the reference's arrays.
+    Pins quirk q2 (`matchers.py:353-355, 502`: the option never reaches `_tile_selection`, the threshold is always 5): the
+    fixture holds three tile pairs with 4-5 preselection matches that the reference does NOT match. With
+    opt["reference_quirks"] = False the option is honoured and exactly those pairs join."""
+    from icepy4d_amd.matching import GeometricVerification, LightGlueMatcher, Quality, TileSelection
+    from icepy4d_amd.matching.tiling import Tiler
+    from icepy4d_amd.utils import AverageTimer
+    g = load_golden("g8_preselection")
+    sds = {"superpoint": SP_SD, "lightglue": synthetic.lightglue_state_dict(0, "passthrough")}
+    kw = dict(grid=g["grid"].tolist(), overlap=int(g["overlap"]), min_matches_per_tile=int(g["min_matches_per_tile"]),
+              max_keypoints=int(g["max_keypoints"]))
+    counts = g["preselection_counts"]
+    want_ref = [tuple(int(x) for x in r[:2]) for r in counts if r[2] > 5]
+    want_fixed = [tuple(int(x) for x in r[:2]) for r in counts if r[2] > kw["min_matches_per_tile"]]
+    assert want_ref == [tuple(int(x) for x in r) for r in g["tile_pairs"]] and len(want_fixed) > len(want_ref)   # the fixture shows q2
+    m = LightGlueMatcher({"state_dicts": sds})
+    m.timer = AverageTimer()
+    t = Tiler(grid=kw["grid"], overlap=kw["overlap"])
+    l0, _ = t.compute_limits_by_grid(g["image0"])
+    l1, _ = t.compute_limits_by_grid(g["image1"])
+    assert m._tile_selection(g["image0"], g["image1"], l0, l1, TileSelection.PRESELECTION, **kw) == want_ref
+    assert m.match(g["image0"], g["image1"], quality=Quality.HIGH, tile_selection=TileSelection.PRESELECTION,
+                   geometric_verification=GeometricVerification.NONE, **kw) is True
+    pairs = {(tuple(a), tuple(b)) for a, b in zip(m.mkpts0, m.mkpts1)}
+    refp = {(tuple(a), tuple(b)) for a, b in zip(g["mkpts0"], g["mkpts1"])}
+    assert pairs == refp, (len(pairs & refp), len(refp), len(pairs))
+    assert np.array_equal(m.mkpts0, g["mkpts0"]) and np.array_equal(m.mkpts1, g["mkpts1"])          # q6 ordering included
+    assert np.abs(m.descriptors0 - g["descriptors0"]).max() < 1e-4 and np.abs(m.descriptors1 - g["descriptors1"]).max() < 1e-4
+    assert np.abs(m.scores0 - g["scores0"]).max() < 1e-5 and np.abs(m.scores1 - g["scores1"]).max() < 1e-5
+    assert np.abs(m.mconf - g["mconf"]).max() < 1e-5
+    fixed = LightGlueMatcher({"state_dicts": sds, "reference_quirks": False})
+    fixed.timer = AverageTimer()
+    assert fixed._tile_selection(g["image0"], g["image1"], l0, l1, TileSelection.PRESELECTION, **kw) == want_fixed
+
+
+def test_resize_failure_is_retried_without_resize_like_the_reference():
+    """q7 (`matchers.py:1262-1267`): the reference wraps `extract(..., resize=resize)` in a bare `except` and silently extracts
+    without `resize` when that fails. Default: reproduced (a `resize` the preprocessor cannot use gives the plain result);
+    opt["reference_quirks"] = False: the error reaches the caller."""
+    from icepy4d_amd.matching import LightGlueMatcher
+    sds = {"superpoint": SP_SD, "lightglue": synthetic.lightglue_state_dict(0, "passthrough")}
+    a, b = synthetic.translated_pair(3, 200, 304)
+    m = LightGlueMatcher({"state_dicts": sds})
+    f0, f1, m0, conf = m._match_images(a, b, max_keypoints=256)
+    g0, g1, n0, conf2 = m._match_images(a, b, max_keypoints=256, resize="not a size")
+    assert np.array_equal(f0.keypoints, g0.keypoints) and np.array_equal(m0, n0) and np.array_equal(conf, conf2)
+    strict = LightGlueMatcher({"state_dicts": sds, "reference_quirks": False})
+    with pytest.raises(Exception):
+        strict._match_images(a, b, max_keypoints=256, resize="not a size")
+
+
 def test_preselection_selects_the_oracle_tile_pairs():
     """TileSelection.PRESELECTION (`matchers.py:513-560`): pyramid down, one low-resolution match with 4096 keypoints, keypoints
     scaled back by 2^n, a tile pair is kept when MORE than `min_matches_per_tile` matches fall strictly inside both tiles. The
@@ -839,7 +892,7 @@ def test_preselection_selects_the_oracle_tile_pairs():
     ha, hb = synthetic.translated_pair(21, 200, 304, 24, 8, noise=0.0)
     a, b = np.kron(ha, np.ones((2, 2), np.uint8)), np.kron(hb, np.ones((2, 2), np.uint8))
     lg_sd = synthetic.lightglue_state_dict(0, "passthrough")
-    m = LightGlueMatcher({"state_dicts": {"superpoint": SP_SD, "lightglue": lg_sd}})
+    m = LightGlueMatcher({"state_dicts": {"superpoint": SP_SD, "lightglue": lg_sd}, "reference_quirks": False})   # the option is honoured
     from icepy4d_amd.utils import AverageTimer
     m.timer = AverageTimer()
     t = Tiler(grid=[2, 3], overlap=10)
@@ -1060,3 +1113,50 @@ def test_host_feeder_equals_device_resident_inputs():
     v = rec["matches0"] > -1
     d = rec["keypoints1"][rec["matches0"][v]] - rec["keypoints0"][v]       # matched point pairs straight from the gathered record
     assert v.sum() > 20 and np.mean(np.all(np.abs(d - np.array([40, 8])) < 1.5, 1)) > 0.6     # most follow the true (40, 8) px translation
+
+
+def test_debug_guards_catch_a_stray_store_and_stay_silent_otherwise():
+    """IM_DEBUG_GUARDS=1 (the substitute for GPU AddressSanitizer, unavailable on this pool): 256 bytes of guard words around every
+    device buffer of the library, compared after each forward. In a process of its own: a whole pair (SuperPoint + LightGlue, then
+    the SuperGlue flavour, then a captured-graph replay) runs with zero guard failures, and the self-test's deliberate 4-byte
+    store behind a buffer is caught (-90) and named."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import numpy as np, torch\n"
+        "from icepy4d_amd import synthetic, _lib\n"
+        "from icepy4d_amd.engine import Engine\n"
+        "from icepy4d_amd.sequence import SequenceMatcher, new_table\n"
+        "e = Engine(0)\n"
+        "e.load_state_dict('superpoint', synthetic.superpoint_state_dict(0))\n"
+        "e.load_state_dict('lightglue', synthetic.lightglue_state_dict(0, 'passthrough'))\n"
+        "e.load_state_dict('superglue', synthetic.superglue_state_dict(0, 'passthrough'))\n"
+        "a, b = synthetic.translated_pair(1, 240, 320)\n"
+        "pair = torch.from_numpy(np.stack([a, b])).cuda()\n"
+        "e.reserve(240, 320, 2, 512)\n"
+        "e.superpoint(pair, 4, 0.0005, 4, 512); e.lightglue((320, 240), (320, 240)); torch.cuda.synchronize()\n"
+        "n_lg = int((e.matches[0] > -1).sum())\n"
+        "e.superpoint(pair, 3, 0.001, 4, 512, flavour=1); e.superglue((240, 320), (240, 320)); torch.cuda.synchronize()\n"
+        "sm = SequenceMatcher(e, 240, 320, 512)\n"
+        "t = new_table(3, e.max_kpts, e.device)\n"
+        "for i in range(3): sm.match_pair(pair, i, t, i)\n"
+        "torch.cuda.synchronize()\n"
+        "assert t[:, 3].tolist() == [n_lg] * 3, (t[:, 3].tolist(), n_lg)\n"
+        "e.superpoint(pair, 4, 0.0005, 4, 512); torch.cuda.synchronize()   # a plain call reads the flag the graph replays left\n"
+        "assert _lib.load().im_debug_guard_failures() == 0\n"
+        "e.ctx.call('im_debug_guard_selftest', _lib.stream_ptr())\n"
+        "assert _lib.load().im_debug_guard_failures() == 0\n"
+        "e.close()\n"
+        "print('GUARDS_OK', n_lg)\n")
+    env = dict(os.environ, IM_DEBUG_GUARDS="1", PYTHONPATH=root)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0 and "GUARDS_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "deliberate" in r.stderr          # the self-test's stray store was reported on stderr by the library
+    # without the mode the self-test refuses (and nothing else changes)
+    code2 = ("from icepy4d_amd.engine import Engine\nfrom icepy4d_amd import _lib\ne = Engine(0)\ne.reserve(64, 64, 2, 64)\n"
+             "try:\n    e.ctx.call('im_debug_guard_selftest', _lib.stream_ptr())\nexcept RuntimeError as x:\n    print('REFUSED', x)\n")
+    env2 = {k: v for k, v in env.items() if k != "IM_DEBUG_GUARDS"}
+    r2 = subprocess.run([sys.executable, "-c", code2], env=env2, capture_output=True, text=True, timeout=600, cwd=root)
+    assert "REFUSED" in r2.stdout and "-93" in r2.stdout, r2.stdout + r2.stderr[-2000:]

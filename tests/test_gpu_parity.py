@@ -142,6 +142,35 @@ def test_superglue_flavour_exact_or_explained(case):
     e.close()
 
 
+@pytest.mark.parametrize("size", ["1080p_4096", "6mp_8192"])
+def test_superglue_flavour_large_sizes_against_the_oracle(size):
+    """The SuperGlue flavour towards BASELINE configs[4] (12 MP / 16384 keypoints / 20 Sinkhorn iterations; that size itself is
+    `tests/parity_report.py --config5`, report under profiles/): 1080p / 4096 and 2000 x 3000 / 8192 keypoints - attention walks 128 key
+    tiles and splits / merges, the Sinkhorn strip partials span 8193 columns, the score matrix is 268 MB. Keypoints and match
+    indices exact or margin-explained, match scores within 1e-4 (`superglue.py:250-305`), the device's score matrix within 1e-4 of
+    the oracle's on the same features (`:279-280`), and the device's Sinkhorn within 1e-4 of `o.log_optimal_transport` on the
+    device's own scores (`:152-186`)."""
+    from icepy4d_amd.engine import Engine
+    sg_sd = synthetic.superglue_state_dict(0, "passthrough")
+    e = Engine(0)
+    e.load_state_dict("superpoint", SP_SD)
+    e.load_state_dict("superglue", sg_sd)
+    if size == "1080p_4096":
+        a, b = synthetic.translated_pair(0, 1080, 1920, 40, 8)
+        k = 4096
+    else:
+        a, b = synthetic.translated_pair(6, 2000, 3000, 48, 16)
+        k = 8192
+    rep = parity_report.run_case_superglue(e, a, b, SP_SD, sg_sd, k, check_ot=True)
+    e.close()
+    assert_exact_or_explained(rep)
+    assert rep["images"][0]["n_keypoints"] == k and rep["images"][1]["n_keypoints"] == k
+    c, ot = rep["matching_same_features"], rep["sinkhorn_on_device_scores"]
+    assert c["n_matches_oracle"] > 500 and c["mscore_max_abs_err"] < 1e-4
+    assert ot["rows"] == k + 1 and ot["cols"] == k + 1
+    assert ot["scores_max_abs_err_vs_oracle_same_features"] < 1e-4 and ot["ot_max_abs_err"] < 1e-4
+
+
 @pytest.mark.parametrize("variant,conf", [("earlystop", {}), ("prune", {"depth_confidence": -1}), ("passthrough", {"pruning_min_kpts": 200})])
 def test_adaptive_depth_and_width_from_pixels(variant, conf):
     """Early stop (token-confidence weights that satisfy the stop criterion after a few layers), point pruning (matchability

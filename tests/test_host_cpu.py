@@ -370,6 +370,81 @@ def test_bench_gpus2_as_typed_spawns_its_ranks_dry_run():
     assert r.returncode != 0
 
 
+def test_bench_gpus8_config4_dry_run_with_counts_that_do_not_divide():
+    """The shape of the first 8-GPU lease (BASELINE configs[3]: epochs sharded e = rank (mod 8), 98 KB records, one all-gather),
+    rehearsed on CPU: 8 gloo ranks, 37 steps + 3 warm-up pairs per rank (neither divides the ten pairs of a launch group), the
+    gathered table holds exactly the timed epochs in order. With IM_BENCH_ISOLATE_DEVICES=1 - the documented fallback if the plain
+    run faults on a device index other than 0 - every rank narrows HIP_VISIBLE_DEVICES to its own GPU before anything touches the
+    HIP runtime (an environment variable read at the top of the rank process, never a re-exec) and then runs as device 0."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "HIP_VISIBLE_DEVICES")}
+    env["OMP_NUM_THREADS"] = "1"
+    for isolate in ("0", "1"):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--config", "4", "--steps", "37", "--warmup", "3",
+                            "--dry-run"], env=dict(env, IM_BENCH_ISOLATE_DEVICES=isolate), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout
+        d = json.loads(lines[0])
+        rk = d["ranks"]
+        assert d["n_gpus"] == 8 and d["steps"] == 37 and rk["world"] == 8 and rk["pairs_per_rank"] == [37] * 8
+        assert rk["epochs_in_gathered_table"] == 8 * 37 and rk["epochs_complete_and_sorted"] is True
+        assert rk["record_bytes"] == 98336 and rk["gathered_table_bytes"] == 8 * 37 * 98336
+        assert rk["devices_isolated"] is (isolate == "1")
+        assert rk["hip_visible_device_per_rank"] == (list(range(8)) if isolate == "1" else [-1] * 8)
+    # a launcher that already narrowed the list: rank r takes the r-th entry of it
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run"],
+                       env=dict(env, IM_BENCH_ISOLATE_DEVICES="1", HIP_VISIBLE_DEVICES="5,3"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])["ranks"]["hip_visible_device_per_rank"] == [5, 3]
+
+
+def test_ransac_iteration_count_survives_tiny_inlier_ratios():
+    """`_needed` (shared by the fundamental- and the essential-matrix RANSAC): w^8 underflows below ~1 % inliers; the count saturates
+    instead of dividing by log(1) = 0 (OverflowError once the first batch of hypotheses found nothing)."""
+    from icepy4d_amd.matching.geometric_verification import NEEDED_CAP, _needed
+    assert _needed(0.9999, 0.0) == NEEDED_CAP and _needed(0.9999, 1e-3) == NEEDED_CAP and _needed(0.9999, 0.005) == NEEDED_CAP
+    assert _needed(0.9999, 0.5) == int(np.ceil(np.log(1e-4) / np.log(1 - 0.5 ** 8))) == 2354
+    assert _needed(0.9999, 1.0) == 1 and _needed(0.99, 0.2) < NEEDED_CAP
+    # the caller's loop `while done < min(needed, max_iters)` then simply runs to max_iters
+
+
+def test_out_of_scope_names_of_the_reference_exist_and_fail_loudly():
+    """`from icepy4d.matching import *` exports LOFTRMatcher (`matchers.py:1005`) and the matcher classes carry `viz_*` methods
+    (`:702, 739, 942`): scripts written against the reference must import and run - LoFTR fails at construction with a clear
+    message, the drawing methods are accepted and skipped with a warning."""
+    import logging
+    from icepy4d_amd import matching
+    from icepy4d_amd.matching import matchers
+    with pytest.raises(NotImplementedError, match="LOFTRMatcher"):
+        matching.LOFTRMatcher({})
+    for cls, names in ((matchers.ImageMatcherBase, ("viz_matches_mpl", "viz_matches_cv2")), (matchers.SuperGlueMatcher, ("viz_matches",))):
+        for n in names:
+            assert callable(getattr(cls, n))
+    obj = matchers.ImageMatcherBase.__new__(matchers.ImageMatcherBase)
+    assert obj.viz_matches_mpl(None, None, None, None, "x.png", hide_fig=True) is None and obj.viz_matches_cv2(None, None) is None
+
+
+def test_record_width_mismatch_is_an_error_with_a_message():
+    """A match table built without the keypoint payload handed to a matcher that writes 98 KB records (or the reverse) raises a
+    ValueError that says so (it used to surface as a size mismatch inside `Tensor.copy_`)."""
+    from icepy4d_amd import sequence as sq
+
+    class FakeEngine:
+        max_kpts = 16
+    with pytest.raises(ValueError, match="words wide"):
+        sq.write_records(torch.zeros(2, 8 + 3 * 16, dtype=torch.int32), 0, 0, 1, FakeEngine())
+    sm = sq.SequenceMatcher.__new__(sq.SequenceMatcher)
+    sm.e, sm.P, sm.use_graph = FakeEngine(), 1, False
+    sm._rec = sq.new_table(1, 16, "cpu", True)
+    sm._pending = [(0, sq.new_table(1, 16, "cpu", False), 0)]
+    sm._enqueue = lambda *a, **k: None
+    sm._record = lambda *a, **k: None
+    sm._inp = torch.zeros(2, 8, 8, dtype=torch.uint8)
+    with pytest.raises(ValueError, match="with_keypoints"):
+        sm._run_group()
+
+
 def test_margin_extractor_explains_perturbed_decisions():
     """tests/margins.py on the CPU: perturb the oracle's score map by +-d, redo the oracle's integer stages on the perturbed
     map, and every keypoint that changed must be traced to an oracle decision (NMS equality / threshold / top-k cut) with margin

@@ -149,3 +149,33 @@ def test_lightglue_pruning_threshold_and_missing_thresholds_buffer():
             assert np.array_equal(out[key].numpy(), g[key]), key
         close(out["matching_scores0"], g["matching_scores0"])
     assert (g["prune1"] == 1).all() and (g["prune0"] > 1).any()      # image 1 (257 points) was never pruned, image 0 was
+
+
+def test_preselection_counts_of_the_reference_call():
+    """G8 (the reference's own `match(..., tile_selection=PRESELECTION, min_matches_per_tile=3)`): the oracle's pyramid level and
+    low-resolution match (`matchers.py:513-545`) put the same number of matches into every tile pair as the reference's did, and
+    the reference selected the pairs with MORE THAN 5 of them - not more than the 3 its caller asked for (quirk q2, `:353-355, 502`)."""
+    from itertools import product
+    from icepy4d_amd import synthetic
+    from icepy4d_amd.matching.tiling import Tiler
+    from oracle import ref_cpu as o
+    from oracle.pyramid_cpu import pyr_down
+    g = load_golden("g8_preselection")
+    a, b = g["image0"], g["image1"]
+    assert int(g["n_down"]) == 1 and int(g["min_matches_per_tile"]) == 3
+    F0, F1, m0, _, _ = o.match_images_lightglue(pyr_down(a), pyr_down(b), synthetic.superpoint_state_dict(0),
+                                                synthetic.lightglue_state_dict(0, "passthrough"), max_keypoints=4096)
+    v = m0 > -1
+    assert int(v.sum()) == int(g["presel_n_matches"])
+    kp0, kp1 = F0[0][v] * 2, F1[0][m0[v]] * 2
+    t = Tiler(grid=g["grid"].tolist(), overlap=int(g["overlap"]))
+    l0, _ = t.compute_limits_by_grid(a)
+    l1, _ = t.compute_limits_by_grid(b)
+    counts = []
+    for t0, t1 in sorted(product(l0.keys(), l1.keys())):
+        r0, r1 = np.asarray(l0[t0]), np.asarray(l1[t1])
+        inside = (np.all(kp0 > r0[:2], 1) & np.all(kp0 < r0[2:], 1)) & (np.all(kp1 > r1[:2], 1) & np.all(kp1 < r1[2:], 1))
+        counts.append((t0, t1, int(inside.sum())))
+    assert np.array_equal(np.array(counts), g["preselection_counts"])
+    assert [c[:2] for c in counts if c[2] > 5] == [tuple(r) for r in g["tile_pairs"].tolist()]
+    assert len([c for c in counts if 3 < c[2] <= 5]) == 3         # what min_matches_per_tile=3 would have added

@@ -195,6 +195,113 @@ def gen_prune_threshold():
          matching_scores1=out["matching_scores1"][0], stop=out["stop"], prune0=out["prune0"][0], prune1=out["prune1"][0])
 
 
+# G8's input: a pair whose HALF-resolution pyramid level is textured and related by a translation (each pixel of a half-size
+# translated pair blown up to a 2 x 2 block: with seeded weights the doubly smoothed full-size noise would leave only a few dozen
+# low-resolution matches). Parameters found by `python tools/gen_golden.py preselection_search`: with them some tile pair holds 4 or
+# 5 preselection matches, so the reference's selection (quirk q2: threshold always 5) differs from what min_matches_per_tile=3 asks.
+G8_PARAMS = dict(seed=21, half_h=200, half_w=304, dx=8, dy=8, grid=[2, 2], overlap=11, min_matches_per_tile=3, max_keypoints=512)
+
+
+def g8_pair(seed, half_h, half_w, dx, dy, **_):
+    ha, hb = synthetic.translated_pair(seed, half_h, half_w, dx, dy, noise=0.0)
+    return np.kron(ha, np.ones((2, 2), np.uint8)), np.kron(hb, np.ones((2, 2), np.uint8))
+
+
+def run_reference_preselection(sp_sd, lg_sd, params):
+    """The reference's own `LightGlueMatcher.match(..., tile_selection=PRESELECTION, grid=, overlap=, min_matches_per_tile=)`
+    (`matchers.py:139-261, 304-469, 471-581`; the call of `main_dev.py:115-132`) on seeded weights. `cv2.pyrDown` - un-vendored,
+    absent here - is `oracle/pyramid_cpu.pyr_down` installed into the stub module, as G6 does for `cvtColor`. Returns the arrays of
+    the fixture: what `_tile_selection` returned, the preselection matches per tile pair, and the final result properties."""
+    from itertools import product
+    from icepy4d.thirdparty.LightGlue.lightglue import superpoint as r_sp, lightglue as r_lg
+    from icepy4d.matching import matchers as r_m
+    from icepy4d.matching.enums import GeometricVerification, Quality, TileSelection
+    from oracle.pyramid_cpu import pyr_down
+    sys.modules["cv2"].pyrDown = pyr_down
+    o_sp, o_lg = r_sp.SuperPoint.__init__, r_lg.LightGlue.__init__
+    o_sel, o_mi = r_m.LightGlueMatcher._tile_selection, r_m.LightGlueMatcher._match_images
+    seen = {"pairs": None, "calls": []}
+
+    def sp_init(self, **conf):
+        o_sp(self, **conf)
+        self.load_state_dict(sp_sd)
+
+    def lg_init(self, *a, **k):
+        o_lg(self, *a, **k)
+        self.load_state_dict(lg_sd)
+
+    def sel(self, *a, **k):
+        seen["pairs"] = o_sel(self, *a, **k)
+        return seen["pairs"]
+
+    def mi(self, i0, i1, **k):
+        out = o_mi(self, i0, i1, **k)
+        seen["calls"].append((i0.shape, i1.shape, out))
+        return out
+
+    r_sp.SuperPoint.__init__, r_lg.LightGlue.__init__ = sp_init, lg_init
+    r_m.LightGlueMatcher._tile_selection, r_m.LightGlueMatcher._match_images = sel, mi
+    import builtins
+    _print = builtins.print
+    builtins.print = lambda *a, **k: None
+    img0, img1 = g8_pair(**params)
+    try:
+        m = r_m.LightGlueMatcher({"force_cpu": True})
+        m.match(img0, img1, quality=Quality.HIGH, tile_selection=TileSelection.PRESELECTION, grid=params["grid"],
+                overlap=params["overlap"], min_matches_per_tile=params["min_matches_per_tile"],
+                geometric_verification=GeometricVerification.NONE, max_keypoints=params["max_keypoints"],
+                save_dir="/tmp/gen_golden_g8")
+    finally:
+        builtins.print = _print
+        r_sp.SuperPoint.__init__, r_lg.LightGlue.__init__ = o_sp, o_lg
+        r_m.LightGlueMatcher._tile_selection, r_m.LightGlueMatcher._match_images = o_sel, o_mi
+    # matches of the low-resolution call per tile pair, by the rule of `matchers.py:548-558` (diagnostic columns of the fixture:
+    # they show which pairs sit between the two thresholds)
+    f0, f1, mtc, _ = seen["calls"][0][2]
+    n_down = 3 if img0.shape[0] > 4000 else 2 if img0.shape[0] > 2000 else 1
+    v = mtc > -1
+    kp0, kp1 = f0.keypoints[v] * 2 ** n_down, f1.keypoints[mtc[v]] * 2 ** n_down
+    t = r_m.Tiler(grid=params["grid"], overlap=params["overlap"], origin=[0, 0])
+    l0, _ = t.compute_limits_by_grid(img0)
+    l1, _ = t.compute_limits_by_grid(img1)
+    counts = []
+    for a, b in sorted(product(l0.keys(), l1.keys())):
+        r0, r1 = np.asarray(l0[a]), np.asarray(l1[b])
+        ins = (np.all(kp0 > r0[:2], 1) & np.all(kp0 < r0[2:], 1)) & (np.all(kp1 > r1[:2], 1) & np.all(kp1 < r1[2:], 1))
+        counts.append((a, b, int(ins.sum())))
+    counts = np.array(counts, dtype=np.int64)
+    assert [tuple(r[:2]) for r in counts if r[2] > 5] == [tuple(p) for p in seen["pairs"]]      # q2: the threshold in force is 5
+    return dict(image0=img0, image1=img1, grid=np.array(params["grid"]), overlap=params["overlap"],
+                min_matches_per_tile=params["min_matches_per_tile"], max_keypoints=params["max_keypoints"], n_down=n_down,
+                tile_pairs=np.array(seen["pairs"], dtype=np.int64).reshape(-1, 2), preselection_counts=counts,
+                presel_n_matches=int(v.sum()), mkpts0=m.mkpts0, mkpts1=m.mkpts1, descriptors0=m.descriptors0,
+                descriptors1=m.descriptors1, scores0=m.scores0, scores1=m.scores1, mconf=m.mconf)
+
+
+def gen_preselection(sp_sd):
+    """G8: the production call (`main_dev.py:115-132`: PRESELECTION, a grid, an overlap, `min_matches_per_tile=3`) through the
+    reference's own `match()`; pins quirk q2 (`matchers.py:353-355, 502`: the option is never found, the threshold is always 5)."""
+    res = run_reference_preselection(sp_sd, synthetic.lightglue_state_dict(0, "passthrough"), G8_PARAMS)
+    c = res["preselection_counts"]
+    print(f"  preselection: {res['presel_n_matches']} low-resolution matches; tile pairs selected {len(res['tile_pairs'])} of {len(c)}, "
+          f"with 4-5 matches (selected only if the option were honoured): {[tuple(int(x) for x in r[:2]) for r in c if 3 < r[2] <= 5]}; "
+          f"final matches {len(res['mkpts0'])}")
+    save("g8_preselection", **res)
+
+
+def preselection_search(sp_sd):
+    """Parameter search behind G8_PARAMS (not part of fixture generation): first (dx, dy, overlap) for which some tile pair holds
+    4 or 5 preselection matches while the call still selects several pairs."""
+    lg_sd = synthetic.lightglue_state_dict(0, "passthrough")
+    for ov in (9, 10, 11, 12, 14):
+        for dx, dy in ((8, 0), (8, 8), (16, 8)):
+            p = dict(G8_PARAMS, dx=dx, dy=dy, overlap=ov)
+            res = run_reference_preselection(sp_sd, lg_sd, p)
+            c = res["preselection_counts"]
+            mid = [tuple(int(x) for x in r) for r in c if 3 < r[2] <= 5]
+            print(f"overlap {ov} d=({dx},{dy}): matches {res['presel_n_matches']} counts {c[:, 2].tolist()} between {mid} final {len(res['mkpts0'])}", flush=True)
+
+
 def main():
     global OUT
     if "--out" in sys.argv:     # e.g. `python tools/gen_golden.py --out /tmp/golden` to compare with the committed fixtures
@@ -214,6 +321,12 @@ def main():
         return
     if len(sys.argv) > 1 and sys.argv[1] == "prune_threshold":
         gen_prune_threshold()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "preselection":
+        gen_preselection(synthetic.superpoint_state_dict(0))
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "preselection_search":
+        preselection_search(synthetic.superpoint_state_dict(0))
         return
     from icepy4d.thirdparty.LightGlue.lightglue import superpoint as r_sp, lightglue as r_lg
     from icepy4d.thirdparty.SuperGlue.models import superpoint as r_sgsp, superglue as r_sg
@@ -395,6 +508,7 @@ def main():
     gen_colour(sp_sd)
     gen_prune_threshold()
     gen_features_pickle()
+    gen_preselection(sp_sd)
     save("g5_assets", gray0=g0, gray1=g1, keypoints0=f0["keypoints"][0], keypoints1=f1["keypoints"][0],
          scores0=f0["keypoint_scores"][0], scores1=f1["keypoint_scores"][0],
          desc0_sha=sha(f0["descriptors"][0]), desc0_sample=f0["descriptors"][0][::16],
