@@ -70,7 +70,7 @@ def check_keypoints(kp, sc, ref_kp, ref_sc):
         assert a == b, f"tie group {v}"
 
 
-@pytest.mark.parametrize("tag,k", [("a", 64), ("b", 2000), ("b", 100), ("b", 512)])
+@pytest.mark.parametrize("tag,k", [("a", 64), ("b", 2000), ("b", 100), ("b", 512), ("c", 512)])
 def test_select_topk_exact(eng, tag, k):
     from icepy4d_amd._lib import stream_ptr
     o = oracle()
@@ -114,7 +114,7 @@ def test_sample_descriptors(eng):
 
 
 # ------------------------------------------------------------------------------------------- SuperPoint end to end
-@pytest.mark.parametrize("tag", ["a", "b"])
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
 def test_superpoint_end_to_end(eng, tag):
     """Pixels -> keypoints / scores / descriptors against the oracle: keypoints exact, or every difference explained by an
     oracle decision margin below the float error of the score map (tests/margins.py; observed: no difference at all);
@@ -142,7 +142,7 @@ def ordered_equal_or_tied(kp, sc, ref_kp, ref_sc, eps=1e-6):
     assert np.abs(np.sort(sc) - np.sort(ref_sc)).max() < 1e-5
 
 
-@pytest.mark.parametrize("tag,max_k", [("a", 50), ("b", -1)])
+@pytest.mark.parametrize("tag,max_k", [("a", 50), ("b", -1), ("c", 300)])
 def test_superpoint_superglue_flavour_golden(tag, max_k):
     """MagicLeap-flavour SuperPoint as icepy4d's SuperGlueMatcher configures it (nms 3, threshold 0.001, border 4,
     `SuperGlue/models/superpoint.py:151-220`) against the reference's own outputs `sg_*` of the golden: keypoints exact

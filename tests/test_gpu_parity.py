@@ -67,7 +67,7 @@ def conv_form(request, monkeypatch):
     return request.param
 
 
-@pytest.mark.parametrize("name", ["g1_superpoint_a", "g1_superpoint_b"])
+@pytest.mark.parametrize("name", ["g1_superpoint_a", "g1_superpoint_b", "g1_superpoint_c"])
 def test_small_goldens_exact_or_explained(eng, name, conv_form):
     g = load_golden(name)
     rep = parity_report.run_case(eng, g["image"], g["image"], SP_SD, LG_SD, min(int(g["max_k"]), 512))

@@ -23,7 +23,7 @@ def close(a, b, tol=1e-6):
     np.testing.assert_allclose(a, np.asarray(b), rtol=0, atol=tol)
 
 
-@pytest.mark.parametrize("tag", ["a", "b"])
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
 def test_superpoint_stages(tag):
     g = load_golden(f"g1_superpoint_{tag}")
     x = o.frame_to_tensor(g["image"])
@@ -40,7 +40,7 @@ def test_superpoint_stages(tag):
         close(out["keypoint_scores"], g["keypoint_scores"], 0)
         close(out["descriptors"], g["descriptors"])
         assert np.array_equal(out["image_size"].numpy(), g["image_size"])
-        sg = o.superpoint_sg(x[None], SP_SD, 3, 0.001, -1 if tag == "b" else 50)
+        sg = o.superpoint_sg(x[None], SP_SD, 3, 0.001, {"a": 50, "b": -1, "c": 300}[tag])
         assert np.array_equal(sg["keypoints"].numpy(), g["sg_keypoints"])
         close(sg["scores"], g["sg_scores"], 0)
         close(sg["descriptors"], g["sg_descriptors"])

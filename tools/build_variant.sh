@@ -16,9 +16,11 @@ else
   flags=("$@")
 fi
 cd $out/src
+rm -f *.o
 for f in *.hip; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I$root/include -I$root/icepy4d_amd/csrc/../../include "${flags[@]}" -c $f -o ${f%.hip}.o &
 done
 wait
+for f in *.hip; do [ -f ${f%.hip}.o ] || { echo "compiling $f FAILED"; exit 1; }; done
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $out/libicematch.so *.o
 echo built $out/libicematch.so

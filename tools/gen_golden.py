@@ -334,7 +334,8 @@ def main():
     sp_sd = synthetic.superpoint_state_dict(0)
 
     # ---------------- G1: SuperPoint, stage by stage, both flavours ----------------
-    for tag, (h, w), k, seed in (("a", (96, 128), 64, 11), ("b", (136, 200), 2000, 12)):
+    # a, b: the sizes of rounds 1-3 (kept); c: the 240 x 320 image SURVEY 8c planned (several 4-wave conv block columns per row)
+    for tag, (h, w), k, seed in (("a", (96, 128), 64, 11), ("b", (136, 200), 2000, 12), ("c", (240, 320), 512, 13)):
         img = noise_image(seed, h, w)
         x = torch.tensor(img / 255.0, dtype=torch.float)[None, None]
         net = r_sp.SuperPoint(max_num_keypoints=k).eval()
@@ -360,7 +361,7 @@ def main():
             nms3 = r_sgsp.simple_nms(sc, 3)
             dense = torch.nn.functional.normalize(net.convDb(net.relu(net.convDa(feat))), p=2, dim=1)
             out = net.extract(x[0], resize=None)
-            sg_net = r_sgsp.SuperPoint({"nms_radius": 3, "keypoint_threshold": 0.001, "max_keypoints": -1 if tag == "b" else 50}).eval()
+            sg_net = r_sgsp.SuperPoint({"nms_radius": 3, "keypoint_threshold": 0.001, "max_keypoints": {"a": 50, "b": -1, "c": 300}[tag]}).eval()
             sg_net.load_state_dict(sp_sd)
             sg_out = sg_net({"image": x})
         save(f"g1_superpoint_{tag}", image=img, max_k=k,
