@@ -284,6 +284,164 @@ __global__ __launch_bounds__(SKF_T, 2) void sinkhorn_fused_kernel(const float* _
     if (tid == 0) pp[n] = make_float2(bM, bS);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Round 4 form of the single-read iteration (selected by default; IM_SINKHORN_FORM=1 keeps the kernel above for A/B): the same
+// one read of the couplings per iteration, written for FEWER vector instructions per element and more waves per SIMD - the
+// kernel above issues ~26 VALU slots per element (three exponentials at a quarter of the rate each), which at 16384^2 is more
+// time than the 1.07 GB take to arrive:
+//   * TWO rows per step: both rows' log-sum-exps are reduced behind ONE block barrier, and the column statistics take both rows
+//     in one online update - max3(cM, yA, yB), one rescale of the running sum per two elements instead of per element: 1.75
+//     exponentials per element instead of 3;
+//   * everything in the log2 domain (v, u, the running column maxima pre-multiplied by log2 e once): z enters through one fma,
+//     the exponentials are bare v_exp_f32;
+//   * the cross-wave merge of a row's (max, sum) is a lane-indexed read + wave shuffles instead of one exponential per wave and
+//     thread;
+//   * 1024 threads x 16 columns (4 float4) instead of 512 x 32: four rows in flight (two being reduced, two loading) fit in
+//     ~128 registers, so 16 waves per CU cover the load latency.
+// Same arithmetic as above up to the order of the fp32 additions (parity tests: <= 1e-4 against the oracle at 16385^2).
+static constexpr float SK_L2E = 1.4426950408889634f, SK_LN2 = 0.6931471805599453f;
+
+// keeps the instruction scheduler from interleaving the unrolled column groups of a pass (it would hold the temporaries of all of
+// them at once: 290 registers wanted, 80 spilled); a group's dozen instructions are enough to cover the LDS read they start with
+#define IM_SK_FENCE() __builtin_amdgcn_sched_barrier(0)
+template <int SK2_T, int SK2_Q>     // SK2_T x SK2_Q float4 = 16384 columns
+__global__ __launch_bounds__(SK2_T, 1) void sinkhorn_fused2_kernel(const float* __restrict__ sim, int ld, const int* __restrict__ m_ptr,
+                                                                   const int* __restrict__ n_ptr, float alpha, const float* __restrict__ v,
+                                                                   float* __restrict__ u, float2* __restrict__ part, int pstride) {
+    static_assert(SK2_T * SK2_Q * 4 == SKF_MAXN, "columns");
+    constexpr int SK2_W = SK2_T / 64;
+    extern __shared__ __attribute__((aligned(16))) float sk_lds[];     // v * log2(e) of this iteration [SKF_MAXN] (64 KB), then red[2][waves] float4
+    float4* sv = reinterpret_cast<float4*>(sk_lds);
+    float4* red = reinterpret_cast<float4*>(sk_lds + SKF_MAXN);
+    const int m = *m_ptr, n = *n_ptr;
+    if (m <= 0 || n <= 0 || (int)blockIdx.x > m) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int G = gridDim.x;
+    float cM[4 * SK2_Q], cS[4 * SK2_Q];
+#pragma unroll
+    for (int q = 0; q < SK2_Q; ++q) {
+        const int j = q * (SK2_T * 4) + tid * 4;
+        // masked columns carry v = -3e38: z + v stays hugely negative, its exponential is 0
+        sv[q * SK2_T + tid] = make_float4(j < n ? v[j] * SK_L2E : SKF_NEG, j + 1 < n ? v[j + 1] * SK_L2E : SKF_NEG,
+                                          j + 2 < n ? v[j + 2] * SK_L2E : SKF_NEG, j + 3 < n ? v[j + 3] * SK_L2E : SKF_NEG);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { cM[4 * q + e] = SKF_NEG; cS[4 * q + e] = 0.f; }
+    }
+    const float bin2 = (alpha + v[n]) * SK_L2E;      // dustbin column of a row, log2 domain
+    float bM = SKF_NEG, bS = 0.f;                    // its column statistics (thread 0): alpha + u_i over this block's rows
+    const float norm = sg_norm(m, n);
+    float4 ra[SK2_Q], rb[SK2_Q], rc[SK2_Q], rd[SK2_Q];
+    // (each thread reads back only the v entries it wrote: no barrier needed for sv)
+
+    // A row through a buffer descriptor that covers exactly its n live floats: lanes past the row end read zero (per-dword range
+    // check), the lane offset is fixed for the whole kernel, the part of a row a float4 group starts at is a scalar offset - no
+    // address arithmetic or masks on the VALU, one address register in all
+    const unsigned voff = (unsigned)tid * 16u;
+    auto load_row = [&](int row, float4 (&buf)[SK2_Q]) {
+        if (row >= m) {                                                // the dustbin row is a row of alpha
+#pragma unroll
+            for (int q = 0; q < SK2_Q; ++q) buf[q] = make_float4(alpha, alpha, alpha, alpha);
+            return;
+        }
+        const __amdgpu_buffer_rsrc_t rs = gmake_rsrc(sim + (long)row * ld, (unsigned)n * 4u);
+#pragma unroll
+        for (int q = 0; q < SK2_Q; ++q) buf[q] = gbuf_load4(rs, voff, (unsigned)q * (SK2_T * 16u));
+    };
+    // rows iA and iB = iA + G (iB > m: absent) from A and B
+    auto step = [&](int iA, const float4 (&A)[SK2_Q], const float4 (&B)[SK2_Q], int parity) {
+        const int iB = iA + G;
+        const bool hasB = iB <= m;
+        // ---- row maxima of (z + v) log2(e), lane-local
+        float mA = SKF_NEG, mB = SKF_NEG;
+#pragma unroll
+        for (int q = 0; q < SK2_Q; ++q) {
+            const float4 w = sv[q * SK2_T + tid];
+            mA = fmaxf(fmaxf(mA, fmaxf(fmaf(A[q].x, SK_L2E, w.x), fmaf(A[q].y, SK_L2E, w.y))), fmaxf(fmaf(A[q].z, SK_L2E, w.z), fmaf(A[q].w, SK_L2E, w.w)));
+            mB = fmaxf(fmaxf(mB, fmaxf(fmaf(B[q].x, SK_L2E, w.x), fmaf(B[q].y, SK_L2E, w.y))), fmaxf(fmaf(B[q].z, SK_L2E, w.z), fmaf(B[q].w, SK_L2E, w.w)));
+            IM_SK_FENCE();
+        }
+        if (tid == 0) { mA = fmaxf(mA, bin2); mB = fmaxf(mB, bin2); }
+        float sA = 0.f, sB = 0.f;
+#pragma unroll
+        for (int q = 0; q < SK2_Q; ++q) {
+            const float4 w = sv[q * SK2_T + tid];
+            const float4 wa = make_float4(w.x - mA, w.y - mA, w.z - mA, w.w - mA), wb = make_float4(w.x - mB, w.y - mB, w.z - mB, w.w - mB);
+            sA += (__builtin_amdgcn_exp2f(fmaf(A[q].x, SK_L2E, wa.x)) + __builtin_amdgcn_exp2f(fmaf(A[q].y, SK_L2E, wa.y))) +
+                  (__builtin_amdgcn_exp2f(fmaf(A[q].z, SK_L2E, wa.z)) + __builtin_amdgcn_exp2f(fmaf(A[q].w, SK_L2E, wa.w)));
+            sB += (__builtin_amdgcn_exp2f(fmaf(B[q].x, SK_L2E, wb.x)) + __builtin_amdgcn_exp2f(fmaf(B[q].y, SK_L2E, wb.y))) +
+                  (__builtin_amdgcn_exp2f(fmaf(B[q].z, SK_L2E, wb.z)) + __builtin_amdgcn_exp2f(fmaf(B[q].w, SK_L2E, wb.w)));
+            IM_SK_FENCE();
+        }
+        if (tid == 0) { sA += __builtin_amdgcn_exp2f(bin2 - mA); sB += __builtin_amdgcn_exp2f(bin2 - mB); }
+        // ---- wave, then block: one barrier for both rows; the 16 per-wave (max, sum) pairs are merged by lane-indexed reads + shuffles
+        const float wMA = wave_max(mA), wMB = wave_max(mB);
+        const float wSA = wave_sum(sA * __builtin_amdgcn_exp2f(mA - wMA)), wSB = wave_sum(sB * __builtin_amdgcn_exp2f(mB - wMB));
+        if (lane == 0) red[parity * SK2_W + wave] = make_float4(wMA, wSA, wMB, wSB);
+        __syncthreads();
+        const float4 r = red[parity * SK2_W + (lane & (SK2_W - 1))];
+        float MA = r.x, MB = r.z;
+#pragma unroll
+        for (int o = SK2_W / 2; o > 0; o >>= 1) { MA = fmaxf(MA, __shfl_xor(MA, o)); MB = fmaxf(MB, __shfl_xor(MB, o)); }
+        float SA = r.y * __builtin_amdgcn_exp2f(r.x - MA), SB = r.w * __builtin_amdgcn_exp2f(r.z - MB);
+#pragma unroll
+        for (int o = SK2_W / 2; o > 0; o >>= 1) { SA += __shfl_xor(SA, o); SB += __shfl_xor(SB, o); }
+        // u_i = log_mu - logsumexp_j(z + v), natural domain for the output, log2 domain for the column pass
+        const float uA = ((iA == m) ? logf((float)n) + norm : norm) - (__builtin_amdgcn_logf(SA) + MA) * SK_LN2;
+        const float uB = ((iB == m) ? logf((float)n) + norm : norm) - (__builtin_amdgcn_logf(SB) + MB) * SK_LN2;
+        if (tid == 0) {
+            u[iA] = uA;
+            if (hasB) u[iB] = uB;
+        }
+        // ---- column statistics with the fresh u of both rows (the dustbin ROW is added by the combine kernel; an absent row
+        // contributes nothing): y = (z + u) log2(e), running (max, sum of 2^(y - max)) per column
+        const bool useA = iA < m, useB = iB < m;
+        const float uA2 = uA * SK_L2E, uB2 = uB * SK_L2E;
+#pragma unroll
+        for (int q = 0; q < SK2_Q; ++q) {
+            const float za[4] = {A[q].x, A[q].y, A[q].z, A[q].w}, zb[4] = {B[q].x, B[q].y, B[q].z, B[q].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float ya = useA ? fmaf(za[e], SK_L2E, uA2) : SKF_NEG, yb = useB ? fmaf(zb[e], SK_L2E, uB2) : SKF_NEG;
+                const float nm = fmaxf(fmaxf(cM[4 * q + e], ya), yb);
+                cS[4 * q + e] = fmaf(cS[4 * q + e], __builtin_amdgcn_exp2f(cM[4 * q + e] - nm), __builtin_amdgcn_exp2f(ya - nm) + __builtin_amdgcn_exp2f(yb - nm));
+                cM[4 * q + e] = nm;
+            }
+            IM_SK_FENCE();
+        }
+        if (tid == 0) {
+            const float ya = useA ? (alpha + uA) * SK_L2E : SKF_NEG, yb = useB ? (alpha + uB) * SK_L2E : SKF_NEG;
+            const float nm = fmaxf(fmaxf(bM, ya), yb);
+            bS = fmaf(bS, __builtin_amdgcn_exp2f(bM - nm), __builtin_amdgcn_exp2f(ya - nm) + __builtin_amdgcn_exp2f(yb - nm));
+            bM = nm;
+        }
+    };
+
+    int i = blockIdx.x;
+    load_row(i, ra);
+    load_row(min(i + G, m), rb);                     // an absent second row re-reads a valid one; `step` ignores it
+    for (;;) {
+        const bool more = i + 2 * G <= m;
+        if (more) { load_row(i + 2 * G, rc); load_row(min(i + 3 * G, m), rd); }
+        step(i, ra, rb, 0);
+        i += 2 * G;
+        if (!more) break;
+        const bool more2 = i + 2 * G <= m;
+        if (more2) { load_row(i + 2 * G, ra); load_row(min(i + 3 * G, m), rb); }
+        step(i, rc, rd, 1);
+        i += 2 * G;
+        if (!more2) break;
+    }
+    float2* pp = part + (long)blockIdx.x * pstride;   // natural-log domain, as sinkhorn_fused_combine_kernel expects
+#pragma unroll
+    for (int q = 0; q < SK2_Q; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int j = q * (SK2_T * 4) + tid * 4 + e;
+            if (j < n) pp[j] = make_float2(cM[4 * q + e] * SK_LN2, cS[4 * q + e]);
+        }
+    if (tid == 0) pp[n] = make_float2(bM * SK_LN2, bS);
+}
+
 // v from the per-block column partials of sinkhorn_fused_kernel: 32 columns x 8 partial groups per block
 __global__ __launch_bounds__(256) void sinkhorn_fused_combine_kernel(const float2* __restrict__ part, int pstride, int n_parts,
                                                                       const int* __restrict__ m_ptr, const int* __restrict__ n_ptr,
@@ -354,12 +512,20 @@ static int sinkhorn(im_ctx* ctx, hipStream_t s, const float* sim, int ld, const 
     static const bool two_sweep = getenv("IM_SINKHORN_TWO_SWEEP") && getenv("IM_SINKHORN_TWO_SWEEP")[0] == '1';   // A/B switch
     const int max_parts = (ctx->max_kpts + 15) / 16;
     if (!two_sweep && n_max <= SKF_MAXN && (ld % 4) == 0 && (reinterpret_cast<uintptr_t>(sim) % 16) == 0 && max_parts >= 1 && iters > 0) {
-        const int G = std::min(std::min(256, max_parts), m_max + 1);
-        const size_t skf_lds = (SKF_MAXN + 2 * 2 * (SKF_T / 64)) * sizeof(float);
-        static size_t lds_optin[IM_MAX_DEVICES] = {0};
-        IM_HIP(ctx, ensure_dyn_lds(reinterpret_cast<const void*>(&sinkhorn_fused_kernel), skf_lds, lds_optin));
+        // IM_SINKHORN_FORM=1: the round-2 kernel (one row per step, 512 threads); default: two rows per step, 1024 threads
+        static const bool form1 = getenv("IM_SINKHORN_FORM") && getenv("IM_SINKHORN_FORM")[0] == '1';
+        static const bool wide = getenv("IM_SINKHORN_FORM") && getenv("IM_SINKHORN_FORM")[0] == '3';   // 1024 threads x 16 columns
+        static const int blocks_env = getenv("IM_SINKHORN_BLOCKS") ? atoi(getenv("IM_SINKHORN_BLOCKS")) : 0;   // tuning knob
+        const int G = std::min(std::min(blocks_env > 0 ? blocks_env : 256, max_parts), m_max + 1);
+        const size_t skf_lds = form1 ? (SKF_MAXN + 2 * 2 * (SKF_T / 64)) * sizeof(float) : (SKF_MAXN + 2 * 16 * 4) * sizeof(float);
+        static size_t lds_optin[IM_MAX_DEVICES] = {0}, lds_optin2[IM_MAX_DEVICES] = {0}, lds_optin3[IM_MAX_DEVICES] = {0};
+        if (form1) IM_HIP(ctx, ensure_dyn_lds(reinterpret_cast<const void*>(&sinkhorn_fused_kernel), skf_lds, lds_optin));
+        else if (wide) IM_HIP(ctx, ensure_dyn_lds(reinterpret_cast<const void*>(&sinkhorn_fused2_kernel<1024, 4>), skf_lds, lds_optin3));
+        else IM_HIP(ctx, ensure_dyn_lds(reinterpret_cast<const void*>(&sinkhorn_fused2_kernel<512, 8>), skf_lds, lds_optin2));
         for (int it = 0; it < iters; ++it) {
-            hipLaunchKernelGGL(sinkhorn_fused_kernel, dim3(G), dim3(SKF_T), skf_lds, s, sim, ld, m_ptr, n_ptr, alpha, v, u, ws->part, pstride);
+            if (form1) hipLaunchKernelGGL(sinkhorn_fused_kernel, dim3(G), dim3(SKF_T), skf_lds, s, sim, ld, m_ptr, n_ptr, alpha, v, u, ws->part, pstride);
+            else if (wide) hipLaunchKernelGGL((sinkhorn_fused2_kernel<1024, 4>), dim3(G), dim3(1024), skf_lds, s, sim, ld, m_ptr, n_ptr, alpha, v, u, ws->part, pstride);
+            else hipLaunchKernelGGL((sinkhorn_fused2_kernel<512, 8>), dim3(G), dim3(512), skf_lds, s, sim, ld, m_ptr, n_ptr, alpha, v, u, ws->part, pstride);
             hipLaunchKernelGGL(sinkhorn_fused_combine_kernel, dim3((n_max + 1 + 31) / 32), dim3(256), 0, s, ws->part, pstride, G, m_ptr, n_ptr,
                                alpha, u, v, norm_out);
         }

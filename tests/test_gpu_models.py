@@ -303,6 +303,65 @@ def test_log_optimal_transport(lg_eng, ci):
     assert err < 1e-4, err
 
 
+@pytest.mark.parametrize("form", ["1", "3", "two_sweep"])
+def test_log_optimal_transport_other_kernel_forms(form):
+    """The Sinkhorn kernels kept behind A/B switches (IM_SINKHORN_FORM=1: one row per step, the round-2 kernel; 3: two rows per
+    step on 1024 threads; IM_SINKHORN_TWO_SWEEP=1: the round-1 row / column sweeps) against the reference's `ot_out`
+    (`superglue.py:152-186`, 20 and 100 iterations) and on ragged sizes against the oracle - the switches are read once per process,
+    so each form runs in a child process."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import numpy as np, torch, sys\n"
+        "sys.path.insert(0, 'tests')\n"
+        "from conftest import load_golden\n"
+        "from icepy4d_amd._lib import ptr\n"
+        "from icepy4d_amd.engine import Engine\n"
+        "from oracle import ref_cpu as o\n"
+        "e = Engine(0); e.reserve(64, 64, 2, 1200)\n"
+        "worst = 0.0\n"
+        "cases = [(torch.from_numpy(load_golden(f'g3_superglue_{ci}')['ot_in']), int(load_golden(f'g3_superglue_{ci}')['iters']), "
+        "torch.from_numpy(load_golden(f'g3_superglue_{ci}')['ot_out'])) for ci in range(3)]\n"
+        "g = torch.Generator().manual_seed(3)\n"
+        "for m, n in ((1, 1), (1, 700), (1100, 3), (517, 1031), (1200, 1199)):\n"
+        "    z = torch.randn(m, n, generator=g) * 3\n"
+        "    cases.append((z, 20, o.log_optimal_transport(z[None], torch.tensor(0.7), 20)[0]))\n"
+        "for i, (z, iters, want) in enumerate(cases):\n"
+        "    m, n = z.shape\n"
+        "    zin = z.cuda().contiguous(); out = torch.full((m + 1, n + 1), float('nan'), device='cuda')\n"
+        "    e.ctx.call('im_log_optimal_transport', ptr(zin), m, n, n, 1.0 if i < 3 else 0.7, iters, ptr(out), e.stream_ptr())\n"
+        "    torch.cuda.synchronize()\n"
+        "    worst = max(worst, float((out.cpu() - want).abs().max()))\n"
+        "print('WORST', worst)\n"
+        "assert worst < 1e-4, worst\n")
+    env = dict(os.environ, PYTHONPATH=root)
+    env.update({"IM_SINKHORN_TWO_SWEEP": "1"} if form == "two_sweep" else {"IM_SINKHORN_FORM": form})
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0 and "WORST" in r.stdout, r.stdout[-1500:] + r.stderr[-2500:]
+
+
+def test_log_optimal_transport_ragged_sizes():
+    """The default Sinkhorn kernel (two rows per step) on sizes that leave rows / column groups partly or wholly empty, incl. an odd
+    number of rows per block and one-row / one-column problems, against the oracle (`superglue.py:152-186`)."""
+    from icepy4d_amd.engine import Engine
+    o = oracle()
+    e = Engine(0)
+    e.reserve(64, 64, 2, 1200)
+    g = torch.Generator().manual_seed(3)
+    for m, n in ((1, 1), (1, 700), (1100, 3), (517, 1031), (1200, 1199), (2, 5)):
+        z = torch.randn(m, n, generator=g) * 3
+        want = o.log_optimal_transport(z[None], torch.tensor(0.7), 20)[0]
+        zin = z.cuda().contiguous()
+        out = torch.full((m + 1, n + 1), float("nan"), device="cuda")
+        e.ctx.call("im_log_optimal_transport", *ptrs(zin), m, n, n, 0.7, 20, *ptrs(out), e.stream_ptr())
+        torch.cuda.synchronize()
+        err = float((out.cpu() - want).abs().max())
+        assert err < 1e-4, (m, n, err)
+    e.close()
+
+
 def test_superglue_empty_input(lg_eng):
     """`superglue.py:255-262`: no keypoints in one image -> all matches -1, scores 0."""
     e = lg_eng
