@@ -35,9 +35,13 @@
 // issued as asm (no forced wait in front of the step's LDS reads) 1.49; instruction-count work found with tools/isa_census.py -
 // accumulators started from a literal-zero C operand instead of 256 v_mov per wave 1.445; epilogue in vectors over neighbouring
 // accumulator registers (no moves), packed subtracts (v_pk_fma_f32 by an opaque -1), uniform output addressing and max3 for
-// ReLU + pool, about 500 -> 170 vector instructions per wave, 1.42 ms (fused first layer 1.49 -> 1.43).
+// ReLU + pool, about 500 -> 170 vector instructions per wave, 1.42 ms (fused first layer 1.49 -> 1.43). Round 4 measured three more
+// ideas and adopted none (tools/experiments/conv_wino_round4_experiments.patch): the fused layer's U transfer as asm
+// with its conv1a weights moved to the kernel-argument segment (keeps the scalar loads): +-0; conv1a itself on the matrix pipe
+// (v_mfma_f32_4x4x1, bit-identical): +2..5 % SLOWER; an L2 prefetch of the later cache lines of every patch pixel: +5 % slower. The
+// slab loop is bound by instruction issue (32 MFMAs + 20 LDS reads + ~45 vector + 10 transfer instructions per wave and step: the
+// same loop without reads and transform reaches 0.95 of the matrix peak, tools/dma_rate.hip).
 #include <cstdlib>
-#include <cstring>
 #include <type_traits>
 
 #include "common.h"
@@ -118,37 +122,20 @@ __device__ __forceinline__ wu32x4 wmake_rsrc4(const void* base, unsigned bytes) 
     r.w = 0x00020000u;
     return r;
 }
-// M0 is named in the clobber lists so that a compiler-generated M0 user (builtin LDS-DMA, readlane / movrel, sendmsg) placed in the
+// M0 is named in the clobber list so that a compiler-generated M0 user (builtin LDS-DMA, readlane / movrel, sendmsg) placed in the
 // same kernel never relies on a value from before the statement; clang notes that M0 is a reserved register (-Winline-asm), which is
-// the point: silenced for these two functions only.
+// the point: silenced for this function only.
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
 __device__ __forceinline__ void dma16(wu32x4 rsrc, unsigned lds_byte_addr, unsigned voff, unsigned soff) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                  :: "s"(lds_byte_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory", "m0");
 }
-#define IM_DMA_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-// 4 bytes per lane to LDS: used only to pull a cache line into L2 ahead of the transfers that need it (the data is discarded)
-__device__ __forceinline__ void dma4(wu32x4 rsrc, unsigned lds_byte_addr, unsigned voff, unsigned soff) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
-                 :: "s"(lds_byte_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory", "m0");
-}
 #pragma clang diagnostic pop
-
-// conv1a's weights [9][64] and bias [64] as a KERNEL ARGUMENT of the fused first layer (2.5 KB of the 4 KB kernarg segment): loads
-// from the kernarg segment are scalar loads whatever else the kernel contains, whereas the same loads through a global pointer turn
-// into 20 vector loads per stage as soon as an `asm volatile` with a memory clobber (the LDS-DMA below) is in the kernel (round 3,
-// finding 4) - which is what had kept the fused layer on the builtin form of the transfer and its forced waits.
-struct Conv1aK { float w[9 * 64]; float b[64]; };
-struct NoConv1aK {};
+#define IM_DMA_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
 template <bool POOL, bool FUSE1A>
-__global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a, std::conditional_t<FUSE1A, Conv1aK, NoConv1aK> k1) {
-#ifdef IM_EXP_FUSE_ASM
-    constexpr bool ASM_U = true;        // U transfer issued as asm in every instantiation
-#else
-    constexpr bool ASM_U = !FUSE1A;
-#endif
+__global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sP = smem;                   // [2][S_SP]
     float* sU = smem + 2 * S_SP;        // [2][16][64][8]
@@ -212,16 +199,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a, std::c
     const unsigned u_slab_bytes = 16u * a.Cout * WCC * 4u, u_k_bytes = 2u * a.Cout * WCC * 4u;
 
     auto fused_quad = [&](int ch) -> float4 {      // conv1a(img / 255) of this thread's pixel, channels ch .. ch + 3 (uniform)
-        const float* w1_ = a.w1;
-        const float* b1_ = a.b1;
-#ifdef IM_EXP_FUSE_ASM
-        if constexpr (FUSE1A) { w1_ = k1.w; b1_ = k1.b; }
-#endif
-        const float4 bq = *reinterpret_cast<const float4*>(b1_ + ch);
+        const float4 bq = *reinterpret_cast<const float4*>(a.b1 + ch);
         f32x2 lo = {bq.x, bq.y}, hi = {bq.z, bq.w};
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            const float4 wv = *reinterpret_cast<const float4*>(w1_ + t * 64 + ch);
+            const float4 wv = *reinterpret_cast<const float4*>(a.w1 + t * 64 + ch);
             const f32x2 tt = {tap[t], tap[t]};
             lo = __builtin_elementwise_fma(tt, f32x2{wv.x, wv.y}, lo);
             hi = __builtin_elementwise_fma(tt, f32x2{wv.z, wv.w}, hi);
@@ -236,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a, std::c
         const unsigned ub = lds_sU + (((slab) & 1) * W_SU + wave * 256) * 4u;                           \
         const unsigned so_ = (slab) * u_slab_bytes;                                                     \
         _Pragma("unroll") for (int k_ = 0; k_ < 8; ++k_) {                                              \
-            if constexpr (!ASM_U) __builtin_amdgcn_raw_ptr_buffer_load_lds(ruw_b, (lds_ptr_t)(sU + ((slab) & 1) * W_SU + wave * 256 + k_ * 1024), 16, uv, so_ + k_ * u_k_bytes, 0, 0); \
+            if constexpr (FUSE1A) __builtin_amdgcn_raw_ptr_buffer_load_lds(ruw_b, (lds_ptr_t)(sU + ((slab) & 1) * W_SU + wave * 256 + k_ * 1024), 16, uv, so_ + k_ * u_k_bytes, 0, 0); \
             else dma16(ruw, ub + k_ * 4096u, uv, so_ + k_ * u_k_bytes);                                 \
         }                                                                                               \
         float* pb = sP + ((slab) & 1) * S_SP;                                                           \
@@ -290,18 +272,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a, std::c
 
     const int nslab = a.Cin / WCC;
     const f32x2 m1 = minus_one();
-#ifdef IM_EXP_L2PF
-    if constexpr (!FUSE1A) {
-        // a pixel's Cin floats span Cin / 32 lines of 128 bytes; slab 0's transfer brings in the first one, the others would be
-        // fetched from HBM by the slabs that first touch them (slab 4 at Cin = 64) with one slab of lead: request them all now
-        if (tid < S_QUAD) {
-            const unsigned scratch = lds_sP + (S_LDS_FLOATS + wave * 64) * 4u;
-            for (unsigned off = 128u; off < (unsigned)a.Cin * 4u; off += 128u) dma4(rin, scratch, pv, off);
-        }
-    }
-#endif
     IM_SSTAGE(0)
-    if constexpr (ASM_U) IM_DMA_WAIT();
+    if constexpr (!FUSE1A) IM_DMA_WAIT();
     __syncthreads();
     // one step: stage (slab + 1) & 1 was last read in step slab - 1 and its transfers stay in flight under this step's MFMAs;
     // the MFMAs stay in FRONT of the wait and the barrier; the wait covers this wave's transfers, the barrier the others'
@@ -310,7 +282,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a, std::c
     {                                                                                                   \
         if ((slab) + 1 < nslab) IM_SSTAGE((slab) + 1)                                                   \
         IM_SMMA(slab, FIRST)                                                                            \
-        if constexpr (ASM_U) {                                                                          \
+        if constexpr (!FUSE1A) {                                                                        \
             __builtin_amdgcn_sched_barrier(0);                                                          \
             IM_DMA_WAIT();                                                                              \
         }                                                                                               \
@@ -417,22 +389,10 @@ template <bool POOL, bool FUSE>
 static hipError_t launch_wino(const ConvArgs& a, hipStream_t s) {
     const int ntile = ((a.W + S_TW - 1) / S_TW) * ((a.H + S_TH - 1) / S_TH) * a.B;
     dim3 grid(((ntile + 7) / 8) * 8 * (a.Cout / 64)), block(256);
-#ifdef IM_EXP_L2PF
-    const size_t lds = (S_LDS_FLOATS + (FUSE ? S_FUSE : 256)) * sizeof(float);
-#else
     const size_t lds = (S_LDS_FLOATS + (FUSE ? S_FUSE : 0)) * sizeof(float);
-#endif
     static size_t lds_optin[IM_MAX_DEVICES] = {0};   // per device: a process may hold contexts on several GPUs
     if (hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(&conv3x3_wino_kernel<POOL, FUSE>), lds, lds_optin); e != hipSuccess) return e;
-    if constexpr (FUSE) {
-        Conv1aK k1;
-        if (!a.w1_host || !a.b1_host) return hipErrorInvalidValue;
-        memcpy(k1.w, a.w1_host, sizeof(k1.w));
-        memcpy(k1.b, a.b1_host, sizeof(k1.b));
-        hipLaunchKernelGGL((conv3x3_wino_kernel<POOL, FUSE>), grid, block, lds, s, a, k1);
-    } else {
-        hipLaunchKernelGGL((conv3x3_wino_kernel<POOL, FUSE>), grid, block, lds, s, a, NoConv1aK{});
-    }
+    hipLaunchKernelGGL((conv3x3_wino_kernel<POOL, FUSE>), grid, block, lds, s, a);
     return hipGetLastError();
 }
 

@@ -26,7 +26,6 @@ std::vector<float> pack_conv3x3_wino(const float* w, int cout, int cin);  // -> 
 struct SuperPointW {
     bool ready = false;
     float* c1a_w = nullptr; float* c1a_b = nullptr;          // [9][64], [64]
-    std::vector<float> c1a_w_host, c1a_b_host;               // host copies (kernel argument of the fused first Winograd layer)
     float* cw[10] = {nullptr}; float* cb[10] = {nullptr};     // conv1b..conv4b, convPa, convDa (packed slabs)
     float* cww[10] = {nullptr};                               // the same layers, Winograd-transformed weights
     float* pb_w = nullptr; float* pb_b = nullptr;             // convPb [65][256], [65]

@@ -99,7 +99,6 @@ struct ConvArgs {
     int gray_mode = 0;            // 3 channels: 0 = float-image weights (LightGlue flavour), 1 = OpenCV uint8 fixed point (SuperGlue)
     const float* w1 = nullptr;    // conv1a weights [9][64]
     const float* b1 = nullptr;    // conv1a bias [64]
-    const float* w1_host = nullptr; const float* b1_host = nullptr;   // the same two arrays in HOST memory (the Winograd form passes them as a kernel argument)
 };
 hipError_t launch_conv3x3(const ConvArgs& a, hipStream_t s);
 // Winograd F(2x2, 3x3) variant (conv_wino.hip); a.w = weights packed by pack_conv3x3_wino: [Cin / 8][16][Cout][8]

@@ -43,8 +43,6 @@ static int finalize_superpoint(im_ctx* ctx) {
             for (int t = 0; t < 9; ++t) p[t * 64 + co] = (*cw)[co * 9 + t];
         w.c1a_w = ctx->upload(p);
         w.c1a_b = ctx->upload(*cb);
-        w.c1a_w_host = p;
-        w.c1a_b_host = *cb;
     }
     for (int i = 0; SP_CONV3[i]; ++i) {
         const std::string nm = SP_CONV3[i];
@@ -397,7 +395,7 @@ int im_superpoint_forward(im_ctx* ctx, const uint8_t* d_img, int n_images, int h
         ConvArgs a;
         a.in = src; a.bias = W.cb[i]; a.out = dst; a.B = B; a.H = ch; a.W = cw_;
         a.Cin = SP_CIN[i]; a.Cout = SP_COUT[i]; a.pool = pool_after[i]; a.relu = 1;
-        if (i == 0) { a.img = d_img; a.img_channels = channels; a.gray_mode = flavour == 1 ? 1 : 0; a.w1 = W.c1a_w; a.b1 = W.c1a_b; a.w1_host = W.c1a_w_host.data(); a.b1_host = W.c1a_b_host.data(); }
+        if (i == 0) { a.img = d_img; a.img_channels = channels; a.gray_mode = flavour == 1 ? 1 : 0; a.w1 = W.c1a_w; a.b1 = W.c1a_b; }
         IM_LAUNCH(ctx, SP_CONV3[i], s, conv(a, i));
         if (pool_after[i]) { ch /= 2; cw_ /= 2; }
         src = dst;
