@@ -589,10 +589,7 @@ class ImageMatcherBase(ImageMatcherABC):
             eng.n[slot:slot + 1].copy_(c["n"])
 
     def _features_from_engine(self):
-        eng = self.engine
-        k0, d0, s0 = eng.features_to_host(0, channels_first=True)
-        k1, d1, s1 = eng.features_to_host(1, channels_first=True)
-        out = eng.matches_to_host(len(k0), len(k1))
+        (k0, d0, s0), (k1, d1, s1), out = self.engine.pair_to_host(0, channels_first=True, pageable=bool(self._opt.get("pageable_results", False)))
         f0 = FeaturesBase(keypoints=k0, descriptors=d0, scores=s0)
         f1 = FeaturesBase(keypoints=k1, descriptors=d1, scores=s1)
         return f0, f1, out
@@ -672,10 +669,7 @@ class SuperGlueMatcher(ImageMatcherBase):
             cap = max(n_cand)
             logger.info(f"SuperPoint found {cap} candidates: growing the keypoint workspace from {eng.max_kpts}")
         eng.superglue(g0.shape[:2], g1.shape[:2], sg["sinkhorn_iterations"], sg["match_threshold"])
-        self.engine.synchronize()
-        k0, d0, s0 = eng.features_to_host(0, channels_first=True)
-        k1, d1, s1 = eng.features_to_host(1, channels_first=True)
-        out = eng.matches_to_host(len(k0), len(k1))
+        (k0, d0, s0), (k1, d1, s1), out = eng.pair_to_host(0, channels_first=True, pageable=bool(self._opt.get("pageable_results", False)))    # one round of async copies, one synchronisation
         features0 = FeaturesBase(keypoints=k0, descriptors=d0, scores=s0)
         features1 = FeaturesBase(keypoints=k1, descriptors=d1, scores=s1)
         matches0 = out["matches0"]
@@ -768,16 +762,20 @@ class LightGlueMatcher(ImageMatcherBase):
                     del eng.graphs[next(iter(eng.graphs))]   # oldest first: a long run over many image shapes stays bounded
                 sm._capture()
                 eng.graphs[key] = sm
-            sm._inp.copy_(torch.from_numpy(np.stack([g0, g1])), non_blocking=True)
+            # page-locked staging owned by the captured entry: two host copies of one image each instead of np.stack + a
+            # pageable upload; the previous call has synchronised, so the buffer is free
+            if getattr(sm, "_stage_in", None) is None:
+                sm._stage_in = torch.empty(sm._inp.shape, dtype=torch.uint8, pin_memory=True)
+            st_np = sm._stage_in.numpy()
+            np.copyto(st_np[0], g0)
+            np.copyto(st_np[1], g1)
+            sm._inp.copy_(sm._stage_in, non_blocking=True)
             sm._graph.replay()
         else:
             for slot, up in enumerate(self._upload_pair(g0, g1)):   # one batched launch, or one per image if the sizes differ
                 eng.superpoint(up, 4, 0.0005, 4, int(max_keypoints), flavour=0, slot=slot)
             eng.lightglue((g0.shape[1], g0.shape[0]), (g1.shape[1], g1.shape[0]), **self._lg_conf)
-        self.engine.synchronize()
-        k0, d0, s0 = eng.features_to_host(0, channels_first=True)
-        k1, d1, s1 = eng.features_to_host(1, channels_first=True)
-        out = eng.matches_to_host(len(k0), len(k1))
+        (k0, d0, s0), (k1, d1, s1), out = eng.pair_to_host(0, channels_first=True, pageable=bool(self._opt.get("pageable_results", False)))    # one round of async copies, one synchronisation
         features0 = FeaturesBase(keypoints=k0, descriptors=d0, scores=s0)
         features1 = FeaturesBase(keypoints=k1, descriptors=d1, scores=s1)
         matches0 = out["matches0"]
