@@ -1,8 +1,8 @@
 #!/bin/bash
 # Runs the measurement passes behind profiles/ on the GPU box (one gpurun call):
-#   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh r03'
+#   /usr/local/graft/bin/gpurun --timeout 3000 -- 'bash tools/collect_profiles.sh r04'
 # rocprofv3 wants cwd=/tmp and TMPDIR=/tmp on this pool; PMC passes are separate runs with --kernel-trace only.
-tag=${1:-r03}
+tag=${1:-r04}
 root=${GRAFT_REPO_ROOT:-/root/repo}
 out=$root/gpurun_out/$tag
 mkdir -p $out
@@ -19,6 +19,10 @@ python3 $root/bench.py --config 3 --no-cpu-baseline > $out/bench_config3.json 2>
 python3 $root/bench.py --config 4 --steps 256 --no-cpu-baseline --no-side-measurements > $out/bench_config4_1gpu_256epochs.json 2> $out/bench_config4.err
 IM_BENCH_FORCE_DIST=1 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 $root/bench.py --gpus 1 --config 4 --steps 64 --no-cpu-baseline --no-side-measurements > $out/bench_config4_nccl_world1.json 2> $out/bench_config4_nccl.err
 IM_BENCH_ONE_DEVICE=1 python3 $root/bench.py --gpus 2 --steps 40 --warmup 10 --no-cpu-baseline --no-side-measurements > $out/bench_2ranks_one_device_gloo.json 2> $out/bench_2ranks.err
+# the shape of the first 8-GPU lease on the one device of this box: eight ranks, gloo, 32 pairs each of configs[3]
+IM_BENCH_ONE_DEVICE=1 python3 $root/bench.py --gpus 8 --config 4 --steps 32 --warmup 4 --no-cpu-baseline --no-side-measurements > $out/bench_config4_8ranks_one_device_gloo.json 2> $out/bench_8ranks.err
+python3 $root/tools/profile_match_call.py > $out/match_call_phases.txt 2>&1
+python3 $root/tools/bench_sinkhorn.py > $out/sinkhorn_forms.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_config5 -- python3 $root/bench.py --config 5 --steps 3 --warmup 1 > $out/bench_config5_under_rocprof.json 2> /dev/null
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_lg_$c -- python3 $root/tools/run_pair_once.py lightglue 2 > /dev/null 2>&1
