@@ -38,7 +38,8 @@
 // ReLU + pool, about 500 -> 170 vector instructions per wave, 1.42 ms (fused first layer 1.49 -> 1.43). Round 4 measured three more
 // ideas and adopted none (tools/experiments/conv_wino_round4_experiments.patch): the fused layer's U transfer as asm
 // with its conv1a weights moved to the kernel-argument segment (keeps the scalar loads): +-0; conv1a itself on the matrix pipe
-// (v_mfma_f32_4x4x1, bit-identical): +2..5 % SLOWER; an L2 prefetch of the later cache lines of every patch pixel: +5 % slower. The
+// (v_mfma_f32_4x4x1, bit-identical): +2..5 % SLOWER; an L2 prefetch of the later cache lines of every patch pixel: +5 % slower; persistent
+// blocks that request the next region's first stage during the last slab (no prologue): -1 % on the large layers, +3..9 % on the small. The
 // slab loop is bound by instruction issue (32 MFMAs + 20 LDS reads + ~45 vector + 10 transfer instructions per wave and step: the
 // same loop without reads and transform reaches 0.95 of the matrix peak, tools/dma_rate.hip).
 #include <cstdlib>
@@ -139,24 +140,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sP = smem;                   // [2][S_SP]
     float* sU = smem + 2 * S_SP;        // [2][16][64][8]
-#ifdef IM_EXP_PERSIST
-    constexpr bool PERSIST = !FUSE1A;   // a block walks items bid, bid + gridDim.x, ...; the next region's first stage is requested during the last slab
-#else
-    constexpr bool PERSIST = false;
-#endif
-    float* sX = PERSIST ? sU + W_SU : smem;   // epilogue exchange [2][8][128] float4: aliases the stages (persistent form: U stage 1 only, stage 0 is being filled)
+    float* sX = smem;                   // epilogue exchange [2][8][128] float4, aliases the above
     float* sImg = smem + S_LDS_FLOATS;  // FUSE1A only
 
     const int nslices = a.Cout / 64;
     const int tx = (a.W + S_TW - 1) / S_TW, ty = (a.H + S_TH - 1) / S_TH;
     const int ntile = tx * ty * a.B;
     const int bid = blockIdx.x;
-    int rtile = (bid & 7) + 8 * ((bid >> 3) / nslices);   // XCD-aware: slices of one region share bid % 8
-    const int co0 = ((bid >> 3) % nslices) * 64;          // (persistent form: gridDim.x is a multiple of 8 nslices, so the slice of a block never changes)
+    const int rtile = (bid & 7) + 8 * ((bid >> 3) / nslices);   // XCD-aware: slices of one region share bid % 8
+    const int co0 = ((bid >> 3) % nslices) * 64;
     if (rtile >= ntile) return;
-    int b = rtile / (tx * ty);
-    int trem = rtile - b * tx * ty;
-    int x0 = (trem % tx) * S_TW, y0 = (trem / tx) * S_TH;
+    const int b = rtile / (tx * ty);
+    const int trem = rtile - b * tx * ty;
+    const int x0 = (trem % tx) * S_TW, y0 = (trem / tx) * S_TH;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 31, hh = lane >> 5;
@@ -165,10 +161,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
     // ---- staging plan of this thread, fixed for the whole kernel: pixel slot tid of the patch image
     const int p_row = tid / S_ROW, p_rem = tid - p_row * S_ROW;
     const int p_par = p_rem >= S_PAR ? 1 : 0, p_s = p_rem - p_par * S_PAR;
-    const int p_px = 2 * p_s + p_par;
-    int p_gy = y0 + p_row - 1, p_gx = x0 + p_px - 1;
+    const int p_px = 2 * p_s + p_par, p_gy = y0 + p_row - 1, p_gx = x0 + p_px - 1;
     const bool p_slot = tid < S_QUAD && p_s < S_PW / 2;
-    bool p_in = p_slot && p_gy >= 0 && p_gy < a.H && p_gx >= 0 && p_gx < a.W;
+    const bool p_in = p_slot && p_gy >= 0 && p_gy < a.H && p_gx >= 0 && p_gx < a.W;
 
     float tap[9];
     if constexpr (FUSE1A) {
@@ -188,15 +183,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
             for (int dx = 0; dx < 3; ++dx) tap[dy * 3 + dx] = sImg[(iy + dy) * S_IW + ix + dx];
     }
 
-    wu32x4 rin = wmake_rsrc4(FUSE1A ? (const void*)a.w : (const void*)(a.in + (long)b * a.H * a.W * a.Cin),
-                             FUSE1A ? 0u : (unsigned)a.H * a.W * a.Cin * 4u);
+    const wu32x4 rin = wmake_rsrc4(FUSE1A ? (const void*)a.w : (const void*)(a.in + (long)b * a.H * a.W * a.Cin),
+                                   FUSE1A ? 0u : (unsigned)a.H * a.W * a.Cin * 4u);
     const wu32x4 ruw = wmake_rsrc4(a.w, (unsigned)(a.Cin / WCC) * 16u * a.Cout * WCC * 4u);
     const unsigned lds_sP = (unsigned)(unsigned long)(lds_ptr_t)sP, lds_sU = (unsigned)(unsigned long)(lds_ptr_t)sU;   // LDS byte addresses
     // The fused first layer keeps the builtin form of the U transfer (compiler-managed waits): its stage is dominated by the conv1a
     // arithmetic and the ds_writes of the patch, and with the asm form it measured 10 % SLOWER (1.67 vs 1.52 ms at 1080p); the
     // plain layers gain 3-5 % from the asm form.
     const __amdgpu_buffer_rsrc_t ruw_b = wmake_rsrc(a.w, (unsigned)(a.Cin / WCC) * 16u * a.Cout * WCC * 4u);
-    unsigned pv = p_in ? (unsigned)(((unsigned)p_gy * a.W + p_gx) * a.Cin) * 4u : 0xFFFFF000u;
+    const unsigned pv = p_in ? (unsigned)(((unsigned)p_gy * a.W + p_gx) * a.Cin) * 4u : 0xFFFFF000u;
     // U image in LDS: [pos][channel quad][64 output channels] float4, so that the 16 lanes of a ds_read_b128 lane
     // group read 16 consecutive slots (with the quad innermost the even / odd slots of one quad gave a 2-way bank
     // conflict on every B-operand read). DMA slot tid + 256 k, k < 8: pos = (tid >> 7) + 2 k, quad = (tid >> 6) & 1,
@@ -219,8 +214,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
         return v;
     };
     // fill stage (slab & 1) with slab's U block and patch
-#define IM_SSTAGE(slab) IM_SSTAGE_FROM(slab, rin, pv)
-#define IM_SSTAGE_FROM(slab, RIN, PV)                                                                   \
+#define IM_SSTAGE(slab)                                                                                 \
     {                                                                                                   \
         const unsigned ub = lds_sU + (((slab) & 1) * W_SU + wave * 256) * 4u;                           \
         const unsigned so_ = (slab) * u_slab_bytes;                                                     \
@@ -235,8 +229,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
                 reinterpret_cast<float4*>(pb)[S_QUAD + tid] = fused_quad((slab) * WCC + 4);             \
             } else {                                                                                    \
                 const unsigned pb_ = lds_sP + (((slab) & 1) * S_SP + wave * 256) * 4u;                  \
-                dma16(RIN, pb_, PV, (slab) * (WCC * 4u));                                               \
-                dma16(RIN, pb_ + S_QUAD * 16u, PV, (slab) * (WCC * 4u) + 16u);                          \
+                dma16(rin, pb_, pv, (slab) * (WCC * 4u));                                               \
+                dma16(rin, pb_ + S_QUAD * 16u, pv, (slab) * (WCC * 4u) + 16u);                          \
             }                                                                                           \
         }                                                                                               \
     }
@@ -298,38 +292,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
     // slab 0 is peeled so that its first MFMAs start the accumulators from a literal zero: zeroing 128 registers ahead of the
     // loop was 256 v_mov per wave (the compiler emitted the zeroing twice), a fifth of the kernel's non-MFMA vector instructions,
     // and fp32 MFMA and VALU never co-execute on this part
-    for (;;) {   // the regions of this block: one, unless PERSIST
-    // ---- (persistent form) the next region of this block: item + gridDim.x, i.e. region + gridDim.x / nslices, same slice and same XCD
-    int n_rtile = 0, n_b = 0, n_x0 = 0, n_y0 = 0;
-    unsigned n_pv = 0xFFFFF000u;
-    wu32x4 n_rin = rin;
-    bool has_next = false;
-    if constexpr (PERSIST) {
-        n_rtile = rtile + (int)gridDim.x / nslices;
-        has_next = n_rtile < ntile;
-        if (has_next) {
-            n_b = n_rtile / (tx * ty);
-            const int n_trem = n_rtile - n_b * tx * ty;
-            n_x0 = (n_trem % tx) * S_TW; n_y0 = (n_trem / tx) * S_TH;
-            const int gy = n_y0 + p_row - 1, gx = n_x0 + p_px - 1;
-            const bool in = p_slot && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-            n_pv = in ? (unsigned)(((unsigned)gy * a.W + gx) * a.Cin) * 4u : 0xFFFFF000u;
-            n_rin = wmake_rsrc4(a.in + (long)n_b * a.H * a.W * a.Cin, (unsigned)a.H * a.W * a.Cin * 4u);
-        }
-    }
     IM_SSTEP(0, true)
-    if constexpr (PERSIST) {
-        for (int slab = 1; slab < nslab - 1; ++slab) IM_SSTEP(slab, false)
-        // last slab (stage 1; nslab is even): stage 0 is free since the barrier of step nslab - 2 and takes slab 0 of the NEXT region,
-        // whose transfers run under this step's MFMAs and the epilogue - the next region starts without a prologue
-        if (has_next) IM_SSTAGE_FROM(0, n_rin, n_pv)
-        IM_SMMA(nslab - 1, false)
-        __builtin_amdgcn_sched_barrier(0);
-        IM_DMA_WAIT();
-        __syncthreads();
-    } else {
-        for (int slab = 1; slab < nslab; ++slab) IM_SSTEP(slab, false)
-    }
+    for (int slab = 1; slab < nslab; ++slab) IM_SSTEP(slab, false)
+#undef IM_SSTEP
+#undef IM_SSTAGE
+#undef IM_SD
+#undef IM_SMMA
 
     // ---- inverse transform Y = A^T M A. Row pass (over j) in registers: s[il][b]; the column pass needs both V-row halves:
     //   Y[0][b] = s[0][b] + s[1][b] + s[2][b],   Y[1][b] = s[1][b] - s[2][b] - s[3][b]
@@ -414,18 +382,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
     };
     if (ph == 0) finish(std::integral_constant<int, 0>{}, t0, t1, sb0, sb1);
     else finish(std::integral_constant<int, 1>{}, sa0, sa1, t0, t1);
-    if constexpr (!PERSIST) break;
-    else {
-        if (!has_next) break;
-        __syncthreads();      // the exchange buffer (U stage 1) has been read: the next region's step 0 may fill it with slab 1
-        rtile = n_rtile; b = n_b; x0 = n_x0; y0 = n_y0; pv = n_pv; rin = n_rin;
-    }
-    }   // regions
-#undef IM_SSTEP
-#undef IM_SSTAGE
-#undef IM_SSTAGE_FROM
-#undef IM_SD
-#undef IM_SMMA
 }
 
 
@@ -434,10 +390,6 @@ template <bool POOL, bool FUSE>
 static hipError_t launch_wino(const ConvArgs& a, hipStream_t s) {
     const int ntile = ((a.W + S_TW - 1) / S_TW) * ((a.H + S_TH - 1) / S_TH) * a.B;
     dim3 grid(((ntile + 7) / 8) * 8 * (a.Cout / 64)), block(256);
-#ifdef IM_EXP_PERSIST
-    // persistent form (plain layers): two resident blocks per CU walk the items; 512 is a multiple of 8 x nslices for 1, 2, 4 slices
-    if (!FUSE && (a.Cin / WCC) % 2 == 0 && grid.x > IM_EXP_PERSIST) grid.x = IM_EXP_PERSIST;
-#endif
     const size_t lds = (S_LDS_FLOATS + (FUSE ? S_FUSE : 0)) * sizeof(float);
     static size_t lds_optin[IM_MAX_DEVICES] = {0};   // per device: a process may hold contexts on several GPUs
     if (hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(&conv3x3_wino_kernel<POOL, FUSE>), lds, lds_optin); e != hipSuccess) return e;
