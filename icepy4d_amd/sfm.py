@@ -2,8 +2,8 @@
 linear triangulation (`src/icepy4d/sfm/geometry.py:31-76`, `sfm/two_view_geometry.py:38-110`,
 `sfm/triangulation.py:153-186`). The reference uses OpenCV (`findEssentialMat`, `recoverPose`), which is absent here, so
 parity of `estimate_pose` is unpinned (same interface, same conventions, checked on synthetic geometry); the linear
-triangulation is pure numpy in the reference and is reproduced to rounding (tests compare against a restatement of its
-formulation). Small host-side linear algebra on S <= 1e4 matched points: not a device workload; the RANSAC inside
+triangulation is pure numpy in the reference and its HOST path here reproduces it to rounding (tests compare against a restatement of
+its formulation; the device path solves through A^T A, see `triangulate_points_linear`). Small host-side linear algebra on S <= 1e4 matched points: not a device workload; the RANSAC inside
 `estimate_pose(engine=...)` generates and scores essential-matrix hypotheses on the device (`im_ransac_essential`, csrc/geometry.hip)
 and `triangulate_points_linear(engine=...)` triangulates on the device (`im_triangulate_linear`); the cheirality test and the 5-7
 match case (five-point solver on every 5-subset) stay host numpy: one 3 x 3 matrix."""
@@ -34,7 +34,10 @@ def triangulate_nviews(P, ip) -> np.ndarray:
 def triangulate_points_linear(P1, P2, x1, x2, engine=None) -> np.ndarray:
     """Two-view triangulation of n points (`triangulation.py:153-163`); x1, x2 are [n, 3] homogeneous image points.
     Vectorised DLT: one batched 4x4 SVD instead of the reference's Python loop over an (6 x 6) system per point. With
-    `engine=` the points are triangulated on the device (`im_triangulate_linear`: one thread per point, fp64 Jacobi on A^T A)."""
+    `engine=` the points are triangulated on the device (`im_triangulate_linear`: one thread per point, fp64 Jacobi on A^T A).
+    The host path solves the same 4 x 4 system by SVD of A, as the reference does; the device path takes the smallest eigenvector of
+    A^T A, which squares the condition number: in fp64 the two agree to ~1e-7 on ordinary geometry (tested), but for near-degenerate
+    rays (parallax below ~1e-6 rad) the device result is NOT to-rounding equal to the SVD - use the host path there."""
     x1, x2 = np.asarray(x1, np.float64), np.asarray(x2, np.float64)
     if len(x1) != len(x2):
         raise ValueError("Number of points don't match.")

@@ -403,6 +403,18 @@ def test_lightglue_matcher_api():
     # medium quality goes through the pyramid and rescales keypoints
     m.match(g["image0"], g["image1"], quality=Quality.MEDIUM, tile_selection=TileSelection.NONE, **cfg)
     assert m.mkpts0[:, 0].max() > g["image0"].shape[1] / 2
+    # results arrive through page-locked buffers owned by the returned arrays (one round of asynchronous copies); with
+    # opt["pageable_results"] they are copied out: same values, and a second call does not disturb the arrays of the first
+    m1 = LightGlueMatcher({"state_dicts": sds})
+    m2 = LightGlueMatcher({"state_dicts": sds, "pageable_results": True})
+    m1.match(g["image0"], g["image1"], quality=Quality.HIGH, tile_selection=TileSelection.NONE, **cfg)
+    kept = (m1.mkpts0, m1.descriptors0, m1.scores0, m1.mconf)
+    copies = tuple(np.array(x) for x in kept)
+    m2.match(g["image0"], g["image1"], quality=Quality.HIGH, tile_selection=TileSelection.NONE, **cfg)
+    m1.match(g["image1"], g["image0"], quality=Quality.HIGH, tile_selection=TileSelection.NONE, **cfg)     # other images, same matcher
+    for a_, b_, c_ in zip(kept, copies, (m2.mkpts0, m2.descriptors0, m2.scores0, m2.mconf)):
+        assert np.array_equal(a_, b_) and np.array_equal(a_, c_)
+    assert m2.descriptors0.shape == g["lg_none_desc0"].shape and not np.array_equal(m1.mkpts0, kept[0])
 
 
 def test_superglue_matcher_api():
