@@ -11,20 +11,26 @@
 // On gfx950 every VALU / LDS instruction a wave issues costs matrix-pipe time (tools/mfma_peak.hip: a v_fma next to a
 // v_mfma_f32_32x32x2_f32 stream costs its full 4 cycles, with one or two waves per SIMD alike), so the kernel is built
 // for instruction count per MFMA, not for overlap:
-//   * 256 threads = 4 waves (cb, ph), output region 8 x 16 pixels = 32 Winograd tiles x 64 output channels; a wave owns
-//     the 32 tiles x 32 output channels x the 8 Winograd positions of V rows 2 ph, 2 ph + 1 (128 accumulator registers);
+//   * 256 threads = 4 waves = the 4 ROWS of V, output region 8 x 16 pixels = 32 Winograd tiles x 64 output channels; wave ph
+//     owns the 32 tiles x 64 output channels (two MFMA column tiles that share every A operand) x the 4 positions of V row ph
+//     (128 accumulator registers). Round 4: until then a wave owned two V rows x 32 channels, so the two channel halves each
+//     computed every V value of the block and each read three patch rows: 32 packed adds + 20 LDS reads per 32 MFMAs; now every V
+//     value is computed once per block from the TWO patch rows its V row needs: 16 packed adds + 16 reads per 32 MFMAs (the loop is
+//     bound by instruction issue, see below), bit-identical, -2..-5 % per layer;
 //     TWO blocks share a CU and drift apart, so one block's prologue, barrier waits, epilogue and store drain run under
 //     the other block's MFMAs;
 //   * the input transform happens in REGISTERS, there is no V image: the halo patch lives in LDS as
-//     [channel quad][row][column parity][column / 2] float4 (row stride 20 slots, 2 x 9 used), so the 12 input pixels a
-//     lane needs for its tile and its two V rows are 12 conflict-free ds_read_b128 with compile-time offsets; the two
-//     1-D passes of B^T d B are 32 packed-fp32 adds for 4 channels, and the results ARE the MFMA A operands;
+//     [channel quad][row][column parity][column / 2] float4 (row stride 20 slots, 2 x 9 used), so the 8 input pixels a
+//     lane needs for its tile and its V row are 8 conflict-free ds_read_b128 (two wave-uniform row bases, compile-time column
+//     offsets); the row pass is one packed fma per pixel pair (dA + sgn dB with a wave-uniform sign), the column pass the usual
+//     four combinations, and the results ARE the MFMA A operands;
 //   * per 8-channel slab the U block [16][64][8] and the patch are double-buffered and filled by LDS-DMA
 //     (`buffer_load_dwordx4 ... lds`): lane-linear destinations, no staging registers, no ds_write, lane offsets fixed
 //     for the whole kernel, the slab a scalar offset; out-of-image pixels and padding slots read zero through the
 //     descriptor's range check. One barrier per slab;
-//   * epilogue: row pass of A^T M A in registers, the two V-row halves swap half of their partials through LDS (8
-//     float4 per lane each way) and each finishes 16 of the 32 tiles: bias, ReLU, optional 2x2 max-pool (= one tile);
+//   * epilogue: the pass of A^T M A over a V row's four positions in registers, then the four waves exchange through LDS (12
+//     float4 per lane each way, one barrier) and wave w finishes tile row w for all 64 channels: bias, ReLU, optional 2x2
+//     max-pool (= one tile), in the associations of the two-row form (same bits);
 //   * FUSE1A: the patch is conv1a(img / 255) computed on the fly: thread t keeps the 3 x 3 image neighbourhood of its
 //     patch pixel in registers for the whole kernel, and per slab the conv1a weights of a channel quad are wave-uniform
 //     (scalar loads), so a patch value costs 9 fused multiply-adds per channel and no LDS read.
@@ -35,8 +41,9 @@
 // issued as asm (no forced wait in front of the step's LDS reads) 1.49; instruction-count work found with tools/isa_census.py -
 // accumulators started from a literal-zero C operand instead of 256 v_mov per wave 1.445; epilogue in vectors over neighbouring
 // accumulator registers (no moves), packed subtracts (v_pk_fma_f32 by an opaque -1), uniform output addressing and max3 for
-// ReLU + pool, about 500 -> 170 vector instructions per wave, 1.42 ms (fused first layer 1.49 -> 1.43). Round 4 measured three more
-// ideas and adopted none (tools/experiments/conv_wino_round4_experiments.patch): the fused layer's U transfer as asm
+// ReLU + pool, about 500 -> 170 vector instructions per wave, 1.42 ms (fused first layer 1.49 -> 1.43). Round 4: one V row x 64
+// channels per wave instead of two V rows x 32 (above): conv 64 -> 64 + pool at 540p 0.332 -> 0.319 ms, fused first layer 1.437 ->
+// 1.398. Round 4 also measured four more ideas and adopted none (tools/experiments/conv_wino_round4_experiments.patch): the fused layer's U transfer as asm
 // with its conv1a weights moved to the kernel-argument segment (keeps the scalar loads): +-0; conv1a itself on the matrix pipe
 // (v_mfma_f32_4x4x1, bit-identical): +2..5 % SLOWER; an L2 prefetch of the later cache lines of every patch pixel: +5 % slower; persistent
 // blocks that request the next region's first stage during the last slab (no prologue): -1 % on the large layers, +3..9 % on the small. The
@@ -140,7 +147,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sP = smem;                   // [2][S_SP]
     float* sU = smem + 2 * S_SP;        // [2][16][64][8]
-    float* sX = smem;                   // epilogue exchange [2][8][128] float4, aliases the above
     float* sImg = smem + S_LDS_FLOATS;  // FUSE1A only
 
     const int nslices = a.Cout / 64;
@@ -156,7 +162,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 31, hh = lane >> 5;
-    const int cb = wave & 1, ph = wave >> 1;
+    const int ph = wave;                  // this wave's V row (0..3): 32 tiles x 64 output channels x the 4 positions of that row
 
     // ---- staging plan of this thread, fixed for the whole kernel: pixel slot tid of the patch image
     const int p_row = tid / S_ROW, p_rem = tid - p_row * S_ROW;
@@ -237,38 +243,37 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
 
     f32x16 acc[8];   // position (2 ph + (p >> 2), p & 3); first written by the MFMAs of slab 0, which take a literal zero as C
 
-    // lane (c, hh): tile c of the 4 x 8 tile grid, channel quad hh; B operand: output channel cb * 32 + c
+    // lane (c, hh): tile c of the 4 x 8 tile grid, channel quad hh; B operands: output channels c and 32 + c.
+    // V row ph of B^T d B needs TWO patch rows (0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3): 8 operand reads and 16 packed adds per
+    // slab, and every V value of the block is computed exactly once (the two-row form computes each one in both channel halves).
     const int t_ty = c >> 3, t_tx = c & 7;
-    const int a_slot = hh * S_QUAD + (2 * t_ty + ph) * S_ROW + t_tx;         // patch row 2 ty + ph, parity 0, quad hh
-    const int b_slot = ((ph * 8) * 2 + hh) * 64 + cb * 32 + c;               // position 8 ph, quad hh, this lane's channel
-#define IM_SD(i, j) pa[a_slot + (i) * S_ROW + ((j) & 1) * S_PAR + ((j) >> 1)]
+    const int rowA = ph == 0 ? 0 : (ph == 2 ? 2 : 1), rowB = ph == 0 ? 2 : (ph == 3 ? 3 : (ph == 2 ? 1 : 2));   // wave-uniform
+    const int a_slotA = hh * S_QUAD + (2 * t_ty + rowA) * S_ROW + t_tx, a_slotB = hh * S_QUAD + (2 * t_ty + rowB) * S_ROW + t_tx;
+    const int b_slot = ((ph * 4) * 2 + hh) * 64 + c;                         // position 4 ph, quad hh, this lane's channel
+    f32x2 rsgn;                                                               // +1 for V row 1 (d1 + d2), -1 otherwise: dA + rsgn dB
+    {
+        float sg = __uint_as_float(__builtin_amdgcn_readfirstlane(ph == 1 ? 0x3F800000u : 0xBF800000u));
+        asm("" : "+s"(sg));
+        rsgn = f32x2{sg, sg};
+    }
+#define IM_SDA(j) pa[a_slotA + ((j) & 1) * S_PAR + ((j) >> 1)]
+#define IM_SDB(j) pa[a_slotB + ((j) & 1) * S_PAR + ((j) >> 1)]
 #define IM_SMMA(slab, FIRST)                                                                            \
     {                                                                                                   \
         const float4* pa = reinterpret_cast<const float4*>(sP + ((slab) & 1) * S_SP);                   \
         const float4* ua = reinterpret_cast<const float4*>(sU + ((slab) & 1) * W_SU) + b_slot;          \
-        float4 v[8];                                                                                    \
+        float4 v[4];                                                                                    \
         {                                                                                               \
-            float4 t0[4], t1[4];                                                                        \
-            if (ph == 0) {              /* V rows 0, 1 from patch rows 0, 1, 2 */                       \
-                _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                      \
-                    const float4 d0 = IM_SD(0, j_), d1 = IM_SD(1, j_), d2 = IM_SD(2, j_);               \
-                    t0[j_] = sub4(d0, d2, m1); t1[j_] = add4(d1, d2);                                   \
-                }                                                                                       \
-            } else {                    /* V rows 2, 3 from patch rows 1, 2, 3 (= rows 0, 1, 2 relative to ph) */ \
-                _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                      \
-                    const float4 d1 = IM_SD(0, j_), d2 = IM_SD(1, j_), d3 = IM_SD(2, j_);               \
-                    t0[j_] = sub4(d2, d1, m1); t1[j_] = sub4(d1, d3, m1);                               \
-                }                                                                                       \
-            }                                                                                           \
-            v[0] = sub4(t0[0], t0[2], m1); v[1] = add4(t0[1], t0[2]); v[2] = sub4(t0[2], t0[1], m1); v[3] = sub4(t0[1], t0[3], m1); \
-            v[4] = sub4(t1[0], t1[2], m1); v[5] = add4(t1[1], t1[2]); v[6] = sub4(t1[2], t1[1], m1); v[7] = sub4(t1[1], t1[3], m1); \
+            float4 t[4];                                                                                \
+            _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) t[j_] = sub4(IM_SDA(j_), IM_SDB(j_), rsgn); \
+            v[0] = sub4(t[0], t[2], m1); v[1] = add4(t[1], t[2]); v[2] = sub4(t[2], t[1], m1); v[3] = sub4(t[1], t[3], m1); \
         }                                                                                               \
         float4 u[8];                                                                                    \
-        _Pragma("unroll") for (int p_ = 0; p_ < 8; ++p_) u[p_] = ua[p_ * 128];                          \
-        _Pragma("unroll") for (int p_ = 0; p_ < 8; ++p_) acc[p_] = mfma32(v[p_].x, u[p_].x, (FIRST) ? f32x16{} : acc[p_]); \
-        _Pragma("unroll") for (int p_ = 0; p_ < 8; ++p_) acc[p_] = mfma32(v[p_].y, u[p_].y, acc[p_]);   \
-        _Pragma("unroll") for (int p_ = 0; p_ < 8; ++p_) acc[p_] = mfma32(v[p_].z, u[p_].z, acc[p_]);   \
-        _Pragma("unroll") for (int p_ = 0; p_ < 8; ++p_) acc[p_] = mfma32(v[p_].w, u[p_].w, acc[p_]);   \
+        _Pragma("unroll") for (int p_ = 0; p_ < 8; ++p_) u[p_] = ua[(p_ >> 1) * 128 + (p_ & 1) * 32];   \
+        _Pragma("unroll") for (int p_ = 0; p_ < 8; ++p_) acc[p_] = mfma32(v[p_ >> 1].x, u[p_].x, (FIRST) ? f32x16{} : acc[p_]); \
+        _Pragma("unroll") for (int p_ = 0; p_ < 8; ++p_) acc[p_] = mfma32(v[p_ >> 1].y, u[p_].y, acc[p_]); \
+        _Pragma("unroll") for (int p_ = 0; p_ < 8; ++p_) acc[p_] = mfma32(v[p_ >> 1].z, u[p_].z, acc[p_]); \
+        _Pragma("unroll") for (int p_ = 0; p_ < 8; ++p_) acc[p_] = mfma32(v[p_ >> 1].w, u[p_].w, acc[p_]); \
     }
 
     const int nslab = a.Cin / WCC;
@@ -296,92 +301,88 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
     for (int slab = 1; slab < nslab; ++slab) IM_SSTEP(slab, false)
 #undef IM_SSTEP
 #undef IM_SSTAGE
-#undef IM_SD
+#undef IM_SDA
+#undef IM_SDB
 #undef IM_SMMA
 
-    // ---- inverse transform Y = A^T M A. Row pass (over j) in registers: s[il][b]; the column pass needs both V-row halves:
-    //   Y[0][b] = s[0][b] + s[1][b] + s[2][b],   Y[1][b] = s[1][b] - s[2][b] - s[3][b]
-    // ph 0 holds {s0 + s1, s1}, ph 1 holds {s2, s2 + s3}; ph 0 keeps accumulator registers 0..7, ph 1 registers 8..15, and each
-    // sends the other its partials of the registers it gives away ([sender][slot][thread] float4). All of it in two-element
-    // vectors over neighbouring accumulator registers (= neighbouring tiles of one row), which are register pairs already, so the
-    // packed instructions need no moves; output addresses are a uniform base per register plus one per-lane offset.
-    const f32x16 sa0 = (acc[0] + acc[1]) + acc[2], sa1 = sub16(sub16(acc[1], acc[2], m1), acc[3], m1);
-    const f32x16 sb0 = (acc[4] + acc[5]) + acc[6], sb1 = sub16(sub16(acc[5], acc[6], m1), acc[7], m1);
-    const f32x16 t0 = sa0 + sb0, t1 = sa1 + sb1;
-    const int co = co0 + cb * 32 + c;
-    const float bv = a.bias[co];
-    const f32x2 bv2 = {bv, bv};
+    // ---- inverse transform Y = A^T M A. acc[2 j + n]: position (ph, j), output channels n * 32 + c. Pass over j in registers:
+    //   s_ph[0] = (M0 + M1) + M2,  s_ph[1] = (M1 - M2) - M3;   then over the four V rows = the four waves:
+    //   Y[0][b] = (s0[b] + s1[b]) + s2[b],   Y[1][b] = s1[b] - (s2[b] + s3[b])       (the associations of the two-row form: same bits)
+    // Wave w finishes tile row w (accumulator registers 4 w .. 4 w + 3 of every s): each wave hands the other three the four registers
+    // they own of its four s vectors ([source][owner][b][n][lane] float4: 12 writes, 12 reads per lane, one barrier).
+    f32x16 sv[2][2];     // [b][n]
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        sv[0][n] = (acc[0 + n] + acc[2 + n]) + acc[4 + n];
+        sv[1][n] = sub16(sub16(acc[2 + n], acc[4 + n], m1), acc[6 + n], m1);
+    }
+    float4* const xw = reinterpret_cast<float4*>(smem);      // both stages are free now: 4 x 4 x 4 x 64 float4 = 64 KB of the 77
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        if (w != ph) {                                       // wave-uniform
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    xw[(((ph * 4 + w) * 2 + bb) * 2 + n) * 64 + lane] =
+                        make_float4(sv[bb][n][4 * w], sv[bb][n][4 * w + 1], sv[bb][n][4 * w + 2], sv[bb][n][4 * w + 3]);
+        }
+    }
+    __syncthreads();
     const float floor_ = a.relu ? 0.f : -__builtin_inff();
-    const f32x2 fl2 = {floor_, floor_};
-    auto finish = [&](auto PH, const f32x16& e00, const f32x16& e01, const f32x16& e10, const f32x16& e11) {
-        constexpr int P = decltype(PH)::value;
-        constexpr int G = P == 0 ? 8 : 0;     // first register given away
-        constexpr int K = P == 0 ? 0 : 8;     // first register kept
-        float4* xs = reinterpret_cast<float4*>(sX) + (P * 8) * 128 + (tid & 127);
-#define IM_SX(e, k) make_float4(e[G + 4 * (k)], e[G + 1 + 4 * (k)], e[G + 2 + 4 * (k)], e[G + 3 + 4 * (k)])
-        xs[0 * 128] = IM_SX(e00, 0); xs[1 * 128] = IM_SX(e00, 1);
-        xs[2 * 128] = IM_SX(e01, 0); xs[3 * 128] = IM_SX(e01, 1);
-        xs[4 * 128] = IM_SX(e10, 0); xs[5 * 128] = IM_SX(e10, 1);
-        xs[6 * 128] = IM_SX(e11, 0); xs[7 * 128] = IM_SX(e11, 1);
-#undef IM_SX
-        __syncthreads();
-        const float4* xr = reinterpret_cast<const float4*>(sX) + ((P ^ 1) * 8) * 128 + (tid & 127);
-        // register r of the accumulator is tile (r >> 2, (r & 3) + 4 hh) of the block's 4 x 8 tile grid (acc_row)
-        const int Ho = POOL ? a.H >> 1 : a.H, Wo = POOL ? a.W >> 1 : a.W;         // output grid
-        constexpr int ST = POOL ? 1 : 2;                                          // output pixels per tile and axis
-        const int oy0 = POOL ? y0 >> 1 : y0, ox0 = POOL ? x0 >> 1 : x0;
-        float* const ubase = a.out + (((long)b * Ho + oy0) * Wo + ox0) * a.Cout;  // uniform
-        const unsigned lane_off = (unsigned)(ST * 4 * hh) * a.Cout + co;
-        const int rows_left = Ho - oy0, cols_left = Wo - ox0 - ST * 4 * hh;
+    const int Ho = POOL ? a.H >> 1 : a.H, Wo = POOL ? a.W >> 1 : a.W;         // output grid
+    constexpr int ST = POOL ? 1 : 2;                                          // output pixels per tile and axis
+    const int oy0 = POOL ? y0 >> 1 : y0, ox0 = POOL ? x0 >> 1 : x0;
+    float* const ubase = a.out + (((long)b * Ho + oy0) * Wo + ox0) * a.Cout;  // uniform
+    const int rows_left = Ho - oy0, cols_left = Wo - ox0 - ST * 4 * hh;
+    auto finish_row = [&](auto W_) {
+        constexpr int w = decltype(W_)::value;                                 // this wave's tile row: registers 4 w .. 4 w + 3
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const float4 x00 = xr[(0 + k) * 128], x01 = xr[(2 + k) * 128], x10 = xr[(4 + k) * 128], x11 = xr[(6 + k) * 128];
+        for (int n = 0; n < 2; ++n) {
+            const int co = co0 + n * 32 + c;
+            const float bv = a.bias[co];
+            const unsigned lane_off = (unsigned)(ST * 4 * hh) * a.Cout + co;
+            float4 y[2][2];                                                     // [a][b], four tile columns each
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int r = K + 4 * k + 2 * h;                                  // registers r, r + 1
-                const f32x2 a00 = h ? f32x2{x00.z, x00.w} : f32x2{x00.x, x00.y}, a01 = h ? f32x2{x01.z, x01.w} : f32x2{x01.x, x01.y};
-                const f32x2 a10 = h ? f32x2{x10.z, x10.w} : f32x2{x10.x, x10.y}, a11 = h ? f32x2{x11.z, x11.w} : f32x2{x11.x, x11.y};
-                f32x2 y00 = (f32x2{e00[r], e00[r + 1]} + a00) + bv2, y01 = (f32x2{e01[r], e01[r + 1]} + a01) + bv2;
-                f32x2 y10, y11;
-                if constexpr (P == 0) {        // own s1 minus the other's s2 + s3
-                    y10 = __builtin_elementwise_fma(a10, m1, f32x2{e10[r], e10[r + 1]}) + bv2;
-                    y11 = __builtin_elementwise_fma(a11, m1, f32x2{e11[r], e11[r + 1]}) + bv2;
-                } else {                       // the other's s1 minus own s2 + s3
-                    y10 = __builtin_elementwise_fma(f32x2{e10[r], e10[r + 1]}, m1, a10) + bv2;
-                    y11 = __builtin_elementwise_fma(f32x2{e11[r], e11[r + 1]}, m1, a11) + bv2;
-                }
-                if constexpr (!POOL) {
-                    y00 = __builtin_elementwise_max(y00, fl2); y01 = __builtin_elementwise_max(y01, fl2);
-                    y10 = __builtin_elementwise_max(y10, fl2); y11 = __builtin_elementwise_max(y11, fl2);
-                }
-                const int trow = (K + 4 * k) >> 2 & 3;                            // r >> 2
+            for (int bb = 0; bb < 2; ++bb) {
+                float4 sr[4];
 #pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const int tcol = 2 * h + e;                                   // (r + e) & 3
-                    const float v00 = e ? y00.y : y00.x, v01 = e ? y01.y : y01.x, v10 = e ? y10.y : y10.x, v11 = e ? y11.y : y11.x;
-                    if constexpr (POOL) {      // relu(max) = max(relu)
-                        float* const up = ubase + ((long)trow * Wo + tcol) * a.Cout;
-                        const float m = __builtin_fmaxf(__builtin_fmaxf(v00, v01), v10);
-                        if (trow < rows_left && tcol < cols_left) up[lane_off] = __builtin_fmaxf(__builtin_fmaxf(m, v11), floor_);
-                    } else {
-                        float* const up = ubase + ((long)(2 * trow) * Wo + 2 * tcol) * a.Cout;
-                        float* const dn = up + (long)Wo * a.Cout;
-                        const bool c0 = 2 * tcol < cols_left, c1 = 2 * tcol + 1 < cols_left;
-                        if (2 * trow < rows_left) {
-                            if (c0) up[lane_off] = v00;
-                            if (c1) up[lane_off + a.Cout] = v01;
-                        }
-                        if (2 * trow + 1 < rows_left) {
-                            if (c0) dn[lane_off] = v10;
-                            if (c1) dn[lane_off + a.Cout] = v11;
-                        }
+                for (int r = 0; r < 4; ++r)
+                    sr[r] = r == w ? make_float4(sv[bb][n][4 * w], sv[bb][n][4 * w + 1], sv[bb][n][4 * w + 2], sv[bb][n][4 * w + 3])
+                                   : xw[(((r * 4 + w) * 2 + bb) * 2 + n) * 64 + lane];
+                const float4 bq = make_float4(bv, bv, bv, bv);
+                y[0][bb] = add4(add4(add4(sr[0], sr[1]), sr[2]), bq);
+                y[1][bb] = add4(sub4(sr[1], add4(sr[2], sr[3]), m1), bq);
+            }
+            const float* y00 = reinterpret_cast<const float*>(&y[0][0]), *y01 = reinterpret_cast<const float*>(&y[0][1]);
+            const float* y10 = reinterpret_cast<const float*>(&y[1][0]), *y11 = reinterpret_cast<const float*>(&y[1][1]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {                                       // tile column q (+ 4 hh through lane_off)
+                const float v00 = y00[q], v01 = y01[q], v10 = y10[q], v11 = y11[q];
+                if constexpr (POOL) {      // relu(max) = max(relu)
+                    float* const up = ubase + ((long)w * Wo + q) * a.Cout;
+                    const float m = __builtin_fmaxf(__builtin_fmaxf(v00, v01), v10);
+                    if (w < rows_left && q < cols_left) up[lane_off] = __builtin_fmaxf(__builtin_fmaxf(m, v11), floor_);
+                } else {
+                    float* const up = ubase + ((long)(2 * w) * Wo + 2 * q) * a.Cout;
+                    float* const dn = up + (long)Wo * a.Cout;
+                    const bool c0 = 2 * q < cols_left, c1 = 2 * q + 1 < cols_left;
+                    if (2 * w < rows_left) {
+                        if (c0) up[lane_off] = __builtin_fmaxf(v00, floor_);
+                        if (c1) up[lane_off + a.Cout] = __builtin_fmaxf(v01, floor_);
+                    }
+                    if (2 * w + 1 < rows_left) {
+                        if (c0) dn[lane_off] = __builtin_fmaxf(v10, floor_);
+                        if (c1) dn[lane_off + a.Cout] = __builtin_fmaxf(v11, floor_);
                     }
                 }
             }
         }
     };
-    if (ph == 0) finish(std::integral_constant<int, 0>{}, t0, t1, sb0, sb1);
-    else finish(std::integral_constant<int, 1>{}, sa0, sa1, t0, t1);
+    if (ph == 0) finish_row(std::integral_constant<int, 0>{});
+    else if (ph == 1) finish_row(std::integral_constant<int, 1>{});
+    else if (ph == 2) finish_row(std::integral_constant<int, 2>{});
+    else finish_row(std::integral_constant<int, 3>{});
 }
 
 
