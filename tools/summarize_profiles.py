@@ -11,8 +11,15 @@ def short(name):
     return name.split("(")[0][:70]
 
 
+def newest(fns):
+    """gpurun MERGES a call's outputs into gpurun_out/: a second collection of the same tag leaves two traces side by side. Only the
+    newest file of a directory is the current build's."""
+    fns = sorted(fns, key=os.path.getmtime)
+    return fns[-1:]
+
+
 def durations(sub):
-    fns = glob.glob(f"{src}/{sub}/**/*kernel_trace.csv", recursive=True)
+    fns = newest(glob.glob(f"{src}/{sub}/**/*kernel_trace.csv", recursive=True))
     d = collections.defaultdict(list)
     for fn in fns:
         for r in csv.DictReader(open(fn)):
@@ -37,7 +44,7 @@ for sub, outname in (("stats1", f"{tag}_kernel_stats_streams1_batch1.csv"), ("st
 
 def counters(sub):
     agg = collections.defaultdict(list)
-    for fn in glob.glob(f"{src}/{sub}/**/*counter_collection.csv", recursive=True):
+    for fn in newest(glob.glob(f"{src}/{sub}/**/*counter_collection.csv", recursive=True)):
         for r in csv.DictReader(open(fn)):
             agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
     return agg
@@ -59,7 +66,7 @@ for mode, suffix in (("lg", ""), ("sg", "@16384")):
                                "traffic_bytes": int((2 * fk + wk) * 1024)}
 json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
 sq = counters("pmc_attn_sq")
-for fn in glob.glob(f"{src}/pmc_attn_sq/**/*counter_collection.csv", recursive=True):
+for fn in newest(glob.glob(f"{src}/pmc_attn_sq/**/*counter_collection.csv", recursive=True)):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(fn)):
         if "flash_attn" in r["Kernel_Name"]:
@@ -70,7 +77,7 @@ for fn in glob.glob(f"{src}/pmc_attn_sq/**/*counter_collection.csv", recursive=T
             fh.write(f"{k},{sum(v)/len(v):.1f},{len(v)}\n")
 # matrix-pipe busy share of every kernel of one pair: SQ_VALU_MFMA_BUSY_CYCLES (summed over the 1024 SIMDs) over SQ_BUSY_CYCLES
 # (32 instances per launch, one per shader engine: / 32 = busy cycles of the launch)
-for fn in glob.glob(f"{src}/pmc_sq_all/**/*counter_collection.csv", recursive=True):
+for fn in newest(glob.glob(f"{src}/pmc_sq_all/**/*counter_collection.csv", recursive=True)):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(fn)):
         agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
