@@ -444,8 +444,8 @@ def main():
             groups = {"im::flash_attn_f32_kernel": ["flash_attn_self", "flash_attn_cross"]}
         else:
             groups = {"im::flash_attn_f32_kernel": ["flash_attn_self", "flash_attn_cross"],
-                      "im::conv3x3_wino_kernel<true, *>": ["conv1b", "conv2b", "conv3b"],
-                      "im::conv3x3_wino_kernel<false, false>": ["conv2a", "conv3a", "conv4a", "conv4b", "convPa", "convDa"]}
+                      "im::conv3x3_wino_kernel<POOL, FUSE1A, UREG> (all instantiations)": ["conv1b", "conv2a", "conv2b", "conv3a", "conv3b", "conv4a",
+                                                                                             "conv4b", "convPa", "convDa"]}
         gstat = {}
         for sym, names in groups.items():
             ms = sum(prof[k]["total_ms"] for k in names if k in prof)

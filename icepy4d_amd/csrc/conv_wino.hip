@@ -142,7 +142,7 @@ __device__ __forceinline__ void dma16(wu32x4 rsrc, unsigned lds_byte_addr, unsig
 #pragma clang diagnostic pop
 #define IM_DMA_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
-template <bool POOL, bool FUSE1A>
+template <bool POOL, bool FUSE1A, bool UREG>
 __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sP = smem;                   // [2][S_SP]
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
     {                                                                                                   \
         const unsigned ub = lds_sU + (((slab) & 1) * W_SU + wave * 256) * 4u;                           \
         const unsigned so_ = (slab) * u_slab_bytes;                                                     \
-        _Pragma("unroll") for (int k_ = 0; k_ < 8; ++k_) {                                              \
+        _Pragma("unroll") for (int k_ = 0; k_ < (UREG ? 0 : 8); ++k_) {                                 \
             if constexpr (FUSE1A) __builtin_amdgcn_raw_ptr_buffer_load_lds(ruw_b, (lds_ptr_t)(sU + ((slab) & 1) * W_SU + wave * 256 + k_ * 1024), 16, uv, so_ + k_ * u_k_bytes, 0, 0); \
             else dma16(ruw, ub + k_ * 4096u, uv, so_ + k_ * u_k_bytes);                                 \
         }                                                                                               \
@@ -256,9 +256,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
         asm("" : "+s"(sg));
         rsgn = f32x2{sg, sg};
     }
+    // UREG (the 64 -> 64 layers): U straight from L2 into registers. Wave ph reads only the four positions of its V row and nobody
+    // else reads them, so the U block need not pass through LDS at all: per slab 8 coalesced 16-byte loads per lane (32 output
+    // channels x 32 bytes = 1 KB per load and half wave), requested one slab ahead into the other of two register sets, instead of
+    // 8 LDS-DMA pieces + 8 ds_read_b128. Measured -2..-3 % at 64 output channels and +1..+3 % at 128 / 256 (several slices per
+    // region fetch from L2 at once), hence a template parameter chosen per layer.
+    const __amdgpu_buffer_rsrc_t ruq = wmake_rsrc(a.w, (unsigned)(a.Cin / WCC) * 16u * a.Cout * WCC * 4u);
+    const unsigned uq_voff = (unsigned)((((ph * 4) * a.Cout + co0 + c) * WCC) + hh * 4) * 4u;
+    const unsigned uq_j = (unsigned)a.Cout * WCC * 4u;
+    float4 uA[8], uB[8];
+#define IM_ULOAD(dst, slab) _Pragma("unroll") for (int p_ = 0; p_ < 8; ++p_) dst[p_] = gbuf_load4(ruq, uq_voff + (p_ & 1) * 1024u, (unsigned)(slab) * u_slab_bytes + (p_ >> 1) * uq_j);
 #define IM_SDA(j) pa[a_slotA + ((j) & 1) * S_PAR + ((j) >> 1)]
 #define IM_SDB(j) pa[a_slotB + ((j) & 1) * S_PAR + ((j) >> 1)]
-#define IM_SMMA(slab, FIRST)                                                                            \
+#define IM_SMMA(slab, FIRST) IM_SMMA_U(slab, FIRST, ul_)
+#define IM_SMMA_U(slab, FIRST, u)                                                                       \
     {                                                                                                   \
         const float4* pa = reinterpret_cast<const float4*>(sP + ((slab) & 1) * S_SP);                   \
         const float4* ua = reinterpret_cast<const float4*>(sU + ((slab) & 1) * W_SU) + b_slot;          \
@@ -268,8 +279,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
             _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) t[j_] = sub4(IM_SDA(j_), IM_SDB(j_), rsgn); \
             v[0] = sub4(t[0], t[2], m1); v[1] = add4(t[1], t[2]); v[2] = sub4(t[2], t[1], m1); v[3] = sub4(t[1], t[3], m1); \
         }                                                                                               \
-        float4 u[8];                                                                                    \
-        _Pragma("unroll") for (int p_ = 0; p_ < 8; ++p_) u[p_] = ua[(p_ >> 1) * 128 + (p_ & 1) * 32];   \
+        float4 ul_[8];                                                                                  \
+        if constexpr (!UREG) { _Pragma("unroll") for (int p_ = 0; p_ < 8; ++p_) ul_[p_] = ua[(p_ >> 1) * 128 + (p_ & 1) * 32]; } \
         _Pragma("unroll") for (int p_ = 0; p_ < 8; ++p_) acc[p_] = mfma32(v[p_ >> 1].x, u[p_].x, (FIRST) ? f32x16{} : acc[p_]); \
         _Pragma("unroll") for (int p_ = 0; p_ < 8; ++p_) acc[p_] = mfma32(v[p_ >> 1].y, u[p_].y, acc[p_]); \
         _Pragma("unroll") for (int p_ = 0; p_ < 8; ++p_) acc[p_] = mfma32(v[p_ >> 1].z, u[p_].z, acc[p_]); \
@@ -278,6 +289,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
 
     const int nslab = a.Cin / WCC;
     const f32x2 m1 = minus_one();
+    if constexpr (UREG) { IM_ULOAD(uA, 0) }
     IM_SSTAGE(0)
     if constexpr (!FUSE1A) IM_DMA_WAIT();
     __syncthreads();
@@ -297,8 +309,28 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
     // slab 0 is peeled so that its first MFMAs start the accumulators from a literal zero: zeroing 128 registers ahead of the
     // loop was 256 v_mov per wave (the compiler emitted the zeroing twice), a fifth of the kernel's non-MFMA vector instructions,
     // and fp32 MFMA and VALU never co-execute on this part
-    IM_SSTEP(0, true)
-    for (int slab = 1; slab < nslab; ++slab) IM_SSTEP(slab, false)
+#define IM_USTEP(slab, FIRST, ucur, unext)                                                              \
+    {                                                                                                   \
+        if ((slab) + 1 < nslab) { IM_SSTAGE((slab) + 1) IM_ULOAD(unext, (slab) + 1) }                   \
+        IM_SMMA_U(slab, FIRST, ucur)                                                                    \
+        if constexpr (!FUSE1A) {                                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                          \
+            IM_DMA_WAIT();                                                                              \
+        }                                                                                               \
+        __syncthreads();                                                                                \
+    }
+    if constexpr (UREG) {      // two register sets of U alternate: steps in pairs (nslab is even)
+        IM_USTEP(0, true, uA, uB)
+        for (int slab = 1; slab + 1 < nslab; slab += 2) {
+            IM_USTEP(slab, false, uB, uA)
+            IM_USTEP(slab + 1, false, uA, uB)
+        }
+        IM_USTEP(nslab - 1, false, uB, uA)
+    } else {
+        IM_SSTEP(0, true)
+        for (int slab = 1; slab < nslab; ++slab) IM_SSTEP(slab, false)
+    }
+#undef IM_USTEP
 #undef IM_SSTEP
 #undef IM_SSTAGE
 #undef IM_SDA
@@ -387,24 +419,29 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
 
 
 // a.w must be the Winograd-packed weights [Cin/8][16][Cout][8] (pack_conv3x3_wino)
-template <bool POOL, bool FUSE>
+template <bool POOL, bool FUSE, bool UREG>
 static hipError_t launch_wino(const ConvArgs& a, hipStream_t s) {
     const int ntile = ((a.W + S_TW - 1) / S_TW) * ((a.H + S_TH - 1) / S_TH) * a.B;
     dim3 grid(((ntile + 7) / 8) * 8 * (a.Cout / 64)), block(256);
     const size_t lds = (S_LDS_FLOATS + (FUSE ? S_FUSE : 0)) * sizeof(float);
     static size_t lds_optin[IM_MAX_DEVICES] = {0};   // per device: a process may hold contexts on several GPUs
-    if (hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(&conv3x3_wino_kernel<POOL, FUSE>), lds, lds_optin); e != hipSuccess) return e;
-    hipLaunchKernelGGL((conv3x3_wino_kernel<POOL, FUSE>), grid, block, lds, s, a);
+    if (hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(&conv3x3_wino_kernel<POOL, FUSE, UREG>), lds, lds_optin); e != hipSuccess) return e;
+    hipLaunchKernelGGL((conv3x3_wino_kernel<POOL, FUSE, UREG>), grid, block, lds, s, a);
     return hipGetLastError();
 }
 
 hipError_t launch_conv3x3_wino(const ConvArgs& a, hipStream_t s) {
     if (a.Cin < WCC || a.Cin % WCC != 0 || a.Cout % 64 != 0) return hipErrorInvalidValue;
+    // U through registers where one slice covers all output channels (the 64 -> 64 layers), through LDS otherwise; the register form
+    // walks the slabs in pairs
+    const bool ureg = a.Cout == 64 && (a.Cin / WCC) % 2 == 0;
     if (a.img) {
         if (a.Cin != 64 || !a.w1 || !a.b1) return hipErrorInvalidValue;
-        return a.pool ? launch_wino<true, true>(a, s) : launch_wino<false, true>(a, s);
+        if (ureg && a.pool) return launch_wino<true, true, true>(a, s);     // (the unpooled fused form would spill with U in registers: LDS form)
+        return a.pool ? launch_wino<true, true, false>(a, s) : launch_wino<false, true, false>(a, s);
     }
-    return a.pool ? launch_wino<true, false>(a, s) : launch_wino<false, false>(a, s);
+    if (ureg) return a.pool ? launch_wino<true, false, true>(a, s) : launch_wino<false, false, true>(a, s);
+    return a.pool ? launch_wino<true, false, false>(a, s) : launch_wino<false, false, false>(a, s);
 }
 
 }  // namespace im

@@ -707,3 +707,16 @@ def test_kernels_keep_their_register_budget(tmp_path):
     assert lse and best
     assert all(v <= 128 for v, _ in lse), lse
     assert all(v <= 168 for v, _ in best), best
+    # the Winograd convolution: every instantiation at two waves per SIMD (<= 256 registers) without scratch
+    out2 = tmp_path / "conv_wino.s"
+    r = subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only", "-I" + os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "icepy4d_amd", "csrc", "conv_wino.hip"), "-o", str(out2)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    conv = {}
+    for blk in re.split(r"\n  - \.agpr_count:", out2.read_text())[1:]:
+        def field2(k):
+            m = re.search(r"\." + k + r":\s+(\S+)", blk)
+            return m.group(1) if m else "0"
+        conv[field2("name")] = (int(field2("vgpr_count")), int(field2("vgpr_spill_count")), int(field2("private_segment_fixed_size")))
+    assert len(conv) == 7, sorted(conv)     # pool / plain x fused / plain x U through registers / LDS, minus the unpooled fused register form
+    assert all(v <= 256 and sp == 0 and scratch == 0 for v, sp, scratch in conv.values()), conv
