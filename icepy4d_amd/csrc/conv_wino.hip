@@ -147,7 +147,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sP = smem;                   // [2][S_SP]
     float* sU = smem + 2 * S_SP;        // [2][16][64][8]
-    float* sImg = smem + S_LDS_FLOATS;  // FUSE1A only
+    // RESIDENT (the fused first layer with U in registers): conv1a of the whole halo patch and all 64 channels is computed ONCE, on
+    // the matrix pipe, into a resident LDS image [16 quads][S_QUAD] float4 (51 KB); the slab loop then has no producer, no transfer
+    // and NO BARRIER - patch read-only, U per wave in registers. The exchange buffer of the epilogue (64 KB) aliases the patch.
+    constexpr bool RESIDENT = FUSE1A && UREG;
+    float* sImg = smem + (RESIDENT ? 16384 : S_LDS_FLOATS);  // FUSE1A only
 
     const int nslices = a.Cout / 64;
     const int tx = (a.W + S_TW - 1) / S_TW, ty = (a.H + S_TH - 1) / S_TH;
@@ -182,11 +186,58 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
             sImg[idx] = v;
         }
         __syncthreads();
-        const int iy = min(p_row, S_PH - 1), ix = min(p_px, S_PW - 1);
+        if constexpr (RESIDENT) {
+            // conv1a as D[channel][pixel] = sum_k W[channel][k] X[k][pixel], k = 0: bias x in-image mask, k = 1 + t: tap t - the fma chain of
+            // the vector form in the same order (same bits). A = weights (lane: channel c of the row tile, k = 2 s + hh), B = the patch
+            // slot's image taps; a lane ends with its slot's channels (r & 3) + 8 (r >> 2) + 4 hh = one channel quad per register group,
+            // i.e. the float4 the patch image holds. Seven column tiles of 32 slots cover the 200 slots; wave w takes tiles w, w + 4.
+            const __amdgpu_buffer_rsrc_t rwq = wmake_rsrc(a.w1q, 64u * 2u * 8u * 4u);
+            float wA[2][5];
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
+            for (int m = 0; m < 2; ++m) {
+                const unsigned off = (unsigned)(((m * 32 + c) * 2 + hh) * 8) * 4u;
+                const float4 w4 = gbuf_load4(rwq, off, 0u), w5 = gbuf_load4(rwq, off + 16u, 0u);
+                wA[m][0] = w4.x; wA[m][1] = w4.y; wA[m][2] = w4.z; wA[m][3] = w4.w; wA[m][4] = w5.x;
+            }
+            float4* const sPq = reinterpret_cast<float4*>(smem);
+            for (int t = wave; t < 7; t += 4) {
+                const int slot = t * 32 + c;
+                const int r_ = slot / S_ROW, rem_ = slot - r_ * S_ROW;
+                const int par_ = rem_ >= S_PAR ? 1 : 0, s_ = rem_ - par_ * S_PAR, px_ = 2 * s_ + par_;
+                const int gy = y0 + r_ - 1, gx = x0 + px_ - 1;
+                const bool in = slot < S_QUAD && s_ < S_PW / 2 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+                const float* ip = sImg + min(r_, S_PH - 1) * S_IW + min(px_, S_PW - 1);
+                float bB[5];
 #pragma unroll
-            for (int dx = 0; dx < 3; ++dx) tap[dy * 3 + dx] = sImg[(iy + dy) * S_IW + ix + dx];
+                for (int k2 = 0; k2 < 5; ++k2) {
+                    // hh = 0: k = 2 k2 -> mask (k2 = 0) or tap 2 k2 - 1; hh = 1: k = 2 k2 + 1 -> tap 2 k2
+                    const int t0 = 2 * k2 - 1, t1 = 2 * k2;
+                    const int o0 = k2 == 0 ? 0 : (t0 / 3) * S_IW + t0 % 3, o1 = (t1 / 3) * S_IW + t1 % 3;
+                    float v = ip[hh ? o1 : o0];
+                    if (k2 == 0 && hh == 0) v = 1.f;
+                    bB[k2] = in ? v : 0.f;
+                }
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    f32x16 d = {};
+#pragma unroll
+                    for (int k2 = 0; k2 < 5; ++k2) d = mfma32(wA[m][k2], bB[k2], d);
+                    if (slot < S_QUAD) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            sPq[(m * 8 + 2 * g + hh) * S_QUAD + slot] = make_float4(fmaxf(d[4 * g], 0.f), fmaxf(d[4 * g + 1], 0.f),
+                                                                                   fmaxf(d[4 * g + 2], 0.f), fmaxf(d[4 * g + 3], 0.f));
+                    }
+                }
+            }
+            __syncthreads();
+        } else {
+            const int iy = min(p_row, S_PH - 1), ix = min(p_px, S_PW - 1);
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) tap[dy * 3 + dx] = sImg[(iy + dy) * S_IW + ix + dx];
+        }
     }
 
     const wu32x4 rin = wmake_rsrc4(FUSE1A ? (const void*)a.w : (const void*)(a.in + (long)b * a.H * a.W * a.Cin),
@@ -229,7 +280,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
             else dma16(ruw, ub + k_ * 4096u, uv, so_ + k_ * u_k_bytes);                                 \
         }                                                                                               \
         float* pb = sP + ((slab) & 1) * S_SP;                                                           \
-        if (tid < S_QUAD) {                                                                             \
+        if (!RESIDENT && tid < S_QUAD) {                                                                \
             if constexpr (FUSE1A) {                                                                     \
                 reinterpret_cast<float4*>(pb)[tid] = fused_quad((slab) * WCC);                          \
                 reinterpret_cast<float4*>(pb)[S_QUAD + tid] = fused_quad((slab) * WCC + 4);             \
@@ -271,7 +322,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
 #define IM_SMMA(slab, FIRST) IM_SMMA_U(slab, FIRST, ul_)
 #define IM_SMMA_U(slab, FIRST, u)                                                                       \
     {                                                                                                   \
-        const float4* pa = reinterpret_cast<const float4*>(sP + ((slab) & 1) * S_SP);                   \
+        const float4* pa = RESIDENT ? reinterpret_cast<const float4*>(smem) + (slab) * (2 * S_QUAD)    \
+                                    : reinterpret_cast<const float4*>(sP + ((slab) & 1) * S_SP);        \
         const float4* ua = reinterpret_cast<const float4*>(sU + ((slab) & 1) * W_SU) + b_slot;          \
         float4 v[4];                                                                                    \
         {                                                                                               \
@@ -290,9 +342,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
     const int nslab = a.Cin / WCC;
     const f32x2 m1 = minus_one();
     if constexpr (UREG) { IM_ULOAD(uA, 0) }
-    IM_SSTAGE(0)
-    if constexpr (!FUSE1A) IM_DMA_WAIT();
-    __syncthreads();
+    if constexpr (!RESIDENT) {
+        IM_SSTAGE(0)
+        if constexpr (!FUSE1A) IM_DMA_WAIT();
+        __syncthreads();
+    }
     // one step: stage (slab + 1) & 1 was last read in step slab - 1 and its transfers stay in flight under this step's MFMAs;
     // the MFMAs stay in FRONT of the wait and the barrier; the wait covers this wave's transfers, the barrier the others'
     // (FUSE1A: the compiler's own vmcnt(0) in front of the barrier covers the builtin transfers)
@@ -311,13 +365,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
     // and fp32 MFMA and VALU never co-execute on this part
 #define IM_USTEP(slab, FIRST, ucur, unext)                                                              \
     {                                                                                                   \
-        if ((slab) + 1 < nslab) { IM_SSTAGE((slab) + 1) IM_ULOAD(unext, (slab) + 1) }                   \
+        if ((slab) + 1 < nslab) {                                                                       \
+            if constexpr (!RESIDENT) IM_SSTAGE((slab) + 1)                                              \
+            IM_ULOAD(unext, (slab) + 1)                                                                 \
+        }                                                                                               \
         IM_SMMA_U(slab, FIRST, ucur)                                                                    \
         if constexpr (!FUSE1A) {                                                                        \
             __builtin_amdgcn_sched_barrier(0);                                                          \
             IM_DMA_WAIT();                                                                              \
         }                                                                                               \
-        __syncthreads();                                                                                \
+        if constexpr (!RESIDENT) __syncthreads();      /* resident patch + U in registers: nothing to wait for */ \
     }
     if constexpr (UREG) {      // two register sets of U alternate: steps in pairs (nslab is even)
         IM_USTEP(0, true, uA, uB)
@@ -348,6 +405,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
         sv[0][n] = (acc[0 + n] + acc[2 + n]) + acc[4 + n];
         sv[1][n] = sub16(sub16(acc[2 + n], acc[4 + n], m1), acc[6 + n], m1);
     }
+    if constexpr (RESIDENT) __syncthreads();                 // the exchange buffer aliases the resident patch: every wave must be past its last slab
     float4* const xw = reinterpret_cast<float4*>(smem);      // both stages are free now: 4 x 4 x 4 x 64 float4 = 64 KB of the 77
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
@@ -423,7 +481,7 @@ template <bool POOL, bool FUSE, bool UREG>
 static hipError_t launch_wino(const ConvArgs& a, hipStream_t s) {
     const int ntile = ((a.W + S_TW - 1) / S_TW) * ((a.H + S_TH - 1) / S_TH) * a.B;
     dim3 grid(((ntile + 7) / 8) * 8 * (a.Cout / 64)), block(256);
-    const size_t lds = (S_LDS_FLOATS + (FUSE ? S_FUSE : 0)) * sizeof(float);
+    const size_t lds = ((FUSE && UREG ? 16384 : S_LDS_FLOATS) + (FUSE ? S_FUSE : 0)) * sizeof(float);
     static size_t lds_optin[IM_MAX_DEVICES] = {0};   // per device: a process may hold contexts on several GPUs
     if (hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(&conv3x3_wino_kernel<POOL, FUSE, UREG>), lds, lds_optin); e != hipSuccess) return e;
     hipLaunchKernelGGL((conv3x3_wino_kernel<POOL, FUSE, UREG>), grid, block, lds, s, a);
@@ -436,7 +494,7 @@ hipError_t launch_conv3x3_wino(const ConvArgs& a, hipStream_t s) {
     // walks the slabs in pairs
     const bool ureg = a.Cout == 64 && (a.Cin / WCC) % 2 == 0;
     if (a.img) {
-        if (a.Cin != 64 || !a.w1 || !a.b1) return hipErrorInvalidValue;
+        if (a.Cin != 64 || !a.w1 || !a.b1 || !a.w1q) return hipErrorInvalidValue;
         if (ureg && a.pool) return launch_wino<true, true, true>(a, s);     // (the unpooled fused form would spill with U in registers: LDS form)
         return a.pool ? launch_wino<true, true, false>(a, s) : launch_wino<false, true, false>(a, s);
     }

@@ -26,6 +26,7 @@ std::vector<float> pack_conv3x3_wino(const float* w, int cout, int cin);  // -> 
 struct SuperPointW {
     bool ready = false;
     float* c1a_w = nullptr; float* c1a_b = nullptr;          // [9][64], [64]
+    float* c1a_wq = nullptr;                                 // [64][2][8]: conv1a weights + bias in the k order of the resident-patch form (conv_wino.hip)
     float* cw[10] = {nullptr}; float* cb[10] = {nullptr};     // conv1b..conv4b, convPa, convDa (packed slabs)
     float* cww[10] = {nullptr};                               // the same layers, Winograd-transformed weights
     float* pb_w = nullptr; float* pb_b = nullptr;             // convPb [65][256], [65]

@@ -99,6 +99,7 @@ struct ConvArgs {
     int gray_mode = 0;            // 3 channels: 0 = float-image weights (LightGlue flavour), 1 = OpenCV uint8 fixed point (SuperGlue)
     const float* w1 = nullptr;    // conv1a weights [9][64]
     const float* b1 = nullptr;    // conv1a bias [64]
+    const float* w1q = nullptr;   // conv1a as MFMA A operand: [64 channels][2 lane halves][8] = {bias, tap 1, 3, 5, 7, -, -, -} / {tap 0, 2, 4, 6, 8, -, -, -}
 };
 hipError_t launch_conv3x3(const ConvArgs& a, hipStream_t s);
 // Winograd F(2x2, 3x3) variant (conv_wino.hip); a.w = weights packed by pack_conv3x3_wino: [Cin / 8][16][Cout][8]

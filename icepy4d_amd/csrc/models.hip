@@ -43,6 +43,11 @@ static int finalize_superpoint(im_ctx* ctx) {
             for (int t = 0; t < 9; ++t) p[t * 64 + co] = (*cw)[co * 9 + t];
         w.c1a_w = ctx->upload(p);
         w.c1a_b = ctx->upload(*cb);
+        // contraction index k of the matrix form: 0 = bias (times the in-image mask), 1 + t = tap t; lane half hh supplies k = 2 s + hh
+        std::vector<float> pq(64 * 2 * 8, 0.f);
+        for (int co = 0; co < 64; ++co)
+            for (int k = 0; k < 10; ++k) pq[((size_t)co * 2 + (k & 1)) * 8 + (k >> 1)] = k == 0 ? (*cb)[co] : (*cw)[co * 9 + (k - 1)];
+        w.c1a_wq = ctx->upload(pq);
     }
     for (int i = 0; SP_CONV3[i]; ++i) {
         const std::string nm = SP_CONV3[i];
@@ -395,7 +400,7 @@ int im_superpoint_forward(im_ctx* ctx, const uint8_t* d_img, int n_images, int h
         ConvArgs a;
         a.in = src; a.bias = W.cb[i]; a.out = dst; a.B = B; a.H = ch; a.W = cw_;
         a.Cin = SP_CIN[i]; a.Cout = SP_COUT[i]; a.pool = pool_after[i]; a.relu = 1;
-        if (i == 0) { a.img = d_img; a.img_channels = channels; a.gray_mode = flavour == 1 ? 1 : 0; a.w1 = W.c1a_w; a.b1 = W.c1a_b; }
+        if (i == 0) { a.img = d_img; a.img_channels = channels; a.gray_mode = flavour == 1 ? 1 : 0; a.w1 = W.c1a_w; a.b1 = W.c1a_b; a.w1q = W.c1a_wq; }
         IM_LAUNCH(ctx, SP_CONV3[i], s, conv(a, i));
         if (pool_after[i]) { ch /= 2; cw_ /= 2; }
         src = dst;
