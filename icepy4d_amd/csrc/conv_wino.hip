@@ -370,7 +370,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
             IM_ULOAD(unext, (slab) + 1)                                                                 \
         }                                                                                               \
         IM_SMMA_U(slab, FIRST, ucur)                                                                    \
-        if constexpr (!FUSE1A) {                                                                        \
+        if constexpr (!FUSE1A && !RESIDENT) {                                                           \
             __builtin_amdgcn_sched_barrier(0);                                                          \
             IM_DMA_WAIT();                                                                              \
         }                                                                                               \
