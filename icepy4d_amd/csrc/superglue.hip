@@ -442,6 +442,185 @@ __global__ __launch_bounds__(SK2_T, 1) void sinkhorn_fused2_kernel(const float* 
     if (tid == 0) pp[n] = make_float2(bM * SK_LN2, bS);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// IM_SINKHORN_FORM=4 (round 4, experimental A/B form; the default stays the two-row kernel above): ONE exponential per element.
+// With u_i fresh from the row pass, exp(z_ij + u_i + v_j - norm) is the row-softmax value the row pass has just computed,
+//     p_ij = exp((z_ij + v_j) - M_i) / S_i,          e^(z_ij + u_i + v_j) = mu_i p_ij,
+// so the column update needs no exponential of its own:  logsumexp_i(z_ij + u_i) = -v_j + norm + log C_j,  C_j = sum_i w_i p_ij  (w = 1, n for the
+// dustbin row), hence     v_j <- v_j - log C_j   (+ log m for the dustbin column).   All terms are <= 1: no running maximum, no rescale.
+// The one thing the online-max form gives for free is lost: when every p_ij of a column underflows (all rows put less than 1e-38 there under the PREVIOUS v)
+// C_j is 0. Such columns are listed by the combine kernel (C_j < 1e-30) and recomputed exactly, by a strided column read, in a repair kernel that
+// exits at once when the list is empty (every launch; the list is double-buffered over iterations).
+template <int SK4_T, int SK4_Q>
+__global__ __launch_bounds__(SK4_T, 1) void sinkhorn_fused4_kernel(const float* __restrict__ sim, int ld, const int* __restrict__ m_ptr,
+                                                                   const int* __restrict__ n_ptr, float alpha, const float* __restrict__ v,
+                                                                   float* __restrict__ u, float* __restrict__ csum, int pstride) {
+    static_assert(SK4_T * SK4_Q * 4 == SKF_MAXN, "columns");
+    constexpr int SK4_W = SK4_T / 64;
+    extern __shared__ __attribute__((aligned(16))) float sk_lds[];     // v * log2(e) [SKF_MAXN], then red[2][waves] float4
+    float4* sv = reinterpret_cast<float4*>(sk_lds);
+    float4* red = reinterpret_cast<float4*>(sk_lds + SKF_MAXN);
+    const int m = *m_ptr, n = *n_ptr;
+    if (m <= 0 || n <= 0 || (int)blockIdx.x > m) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int G = gridDim.x;
+    float cS[4 * SK4_Q];
+#pragma unroll
+    for (int q = 0; q < SK4_Q; ++q) {
+        const int j = q * (SK4_T * 4) + tid * 4;
+        sv[q * SK4_T + tid] = make_float4(j < n ? v[j] * SK_L2E : SKF_NEG, j + 1 < n ? v[j + 1] * SK_L2E : SKF_NEG,
+                                          j + 2 < n ? v[j + 2] * SK_L2E : SKF_NEG, j + 3 < n ? v[j + 3] * SK_L2E : SKF_NEG);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cS[4 * q + e] = 0.f;
+    }
+    const float bin2 = (alpha + v[n]) * SK_L2E;
+    float bS = 0.f;                                   // dustbin column (thread 0)
+    const float norm = sg_norm(m, n);
+    float4 ra[SK4_Q], rb[SK4_Q], rc[SK4_Q], rd[SK4_Q];
+    const unsigned voff = (unsigned)tid * 16u;
+    auto load_row = [&](int row, float4 (&buf)[SK4_Q]) {
+        if (row >= m) {
+#pragma unroll
+            for (int q = 0; q < SK4_Q; ++q) buf[q] = make_float4(alpha, alpha, alpha, alpha);
+            return;
+        }
+        const __amdgpu_buffer_rsrc_t rs = gmake_rsrc(sim + (long)row * ld, (unsigned)n * 4u);
+#pragma unroll
+        for (int q = 0; q < SK4_Q; ++q) buf[q] = gbuf_load4(rs, voff, (unsigned)q * (SK4_T * 16u));
+    };
+    // rows iA and iB = iA + G (iB > m: absent); on return A and B hold the exponentials exp2(t - lane maximum)
+    auto step = [&](int iA, float4 (&A)[SK4_Q], float4 (&B)[SK4_Q], int parity) {
+        const int iB = iA + G;
+        const bool hasB = iB <= m;
+        float mA = SKF_NEG, mB = SKF_NEG;
+#pragma unroll
+        for (int q = 0; q < SK4_Q; ++q) {
+            const float4 w = sv[q * SK4_T + tid];
+            A[q] = make_float4(fmaf(A[q].x, SK_L2E, w.x), fmaf(A[q].y, SK_L2E, w.y), fmaf(A[q].z, SK_L2E, w.z), fmaf(A[q].w, SK_L2E, w.w));
+            B[q] = make_float4(fmaf(B[q].x, SK_L2E, w.x), fmaf(B[q].y, SK_L2E, w.y), fmaf(B[q].z, SK_L2E, w.z), fmaf(B[q].w, SK_L2E, w.w));
+            mA = fmaxf(fmaxf(mA, fmaxf(A[q].x, A[q].y)), fmaxf(A[q].z, A[q].w));
+            mB = fmaxf(fmaxf(mB, fmaxf(B[q].x, B[q].y)), fmaxf(B[q].z, B[q].w));
+            IM_SK_FENCE();
+        }
+        if (tid == 0) { mA = fmaxf(mA, bin2); mB = fmaxf(mB, bin2); }
+        float sA = 0.f, sB = 0.f;
+#pragma unroll
+        for (int q = 0; q < SK4_Q; ++q) {
+            A[q] = make_float4(__builtin_amdgcn_exp2f(A[q].x - mA), __builtin_amdgcn_exp2f(A[q].y - mA), __builtin_amdgcn_exp2f(A[q].z - mA),
+                               __builtin_amdgcn_exp2f(A[q].w - mA));
+            B[q] = make_float4(__builtin_amdgcn_exp2f(B[q].x - mB), __builtin_amdgcn_exp2f(B[q].y - mB), __builtin_amdgcn_exp2f(B[q].z - mB),
+                               __builtin_amdgcn_exp2f(B[q].w - mB));
+            sA += (A[q].x + A[q].y) + (A[q].z + A[q].w);
+            sB += (B[q].x + B[q].y) + (B[q].z + B[q].w);
+            IM_SK_FENCE();
+        }
+        float ebA = 0.f, ebB = 0.f;                   // dustbin column entries of the two rows (thread 0)
+        if (tid == 0) { ebA = __builtin_amdgcn_exp2f(bin2 - mA); ebB = __builtin_amdgcn_exp2f(bin2 - mB); sA += ebA; sB += ebB; }
+        const float wMA = wave_max(mA), wMB = wave_max(mB);
+        const float wSA = wave_sum(sA * __builtin_amdgcn_exp2f(mA - wMA)), wSB = wave_sum(sB * __builtin_amdgcn_exp2f(mB - wMB));
+        if (lane == 0) red[parity * SK4_W + wave] = make_float4(wMA, wSA, wMB, wSB);
+        __syncthreads();
+        const float4 r = red[parity * SK4_W + (lane & (SK4_W - 1))];
+        float MA = r.x, MB = r.z;
+#pragma unroll
+        for (int o = SK4_W / 2; o > 0; o >>= 1) { MA = fmaxf(MA, __shfl_xor(MA, o)); MB = fmaxf(MB, __shfl_xor(MB, o)); }
+        float SA = r.y * __builtin_amdgcn_exp2f(r.x - MA), SB = r.w * __builtin_amdgcn_exp2f(r.z - MB);
+#pragma unroll
+        for (int o = SK4_W / 2; o > 0; o >>= 1) { SA += __shfl_xor(SA, o); SB += __shfl_xor(SB, o); }
+        if (tid == 0) {
+            u[iA] = ((iA == m) ? logf((float)n) + norm : norm) - (__builtin_amdgcn_logf(SA) + MA) * SK_LN2;
+            if (hasB) u[iB] = ((iB == m) ? logf((float)n) + norm : norm) - (__builtin_amdgcn_logf(SB) + MB) * SK_LN2;
+        }
+        // column sums of the row-normalised matrix: p = e * 2^(lane max - row max) / S, weight n for the dustbin row, 0 for an absent row
+        const float fA = __builtin_amdgcn_exp2f(mA - MA) / SA * (iA == m ? (float)n : 1.f);
+        const float fB = hasB ? __builtin_amdgcn_exp2f(mB - MB) / SB * (iB == m ? (float)n : 1.f) : 0.f;
+#pragma unroll
+        for (int q = 0; q < SK4_Q; ++q) {
+            cS[4 * q + 0] = fmaf(B[q].x, fB, fmaf(A[q].x, fA, cS[4 * q + 0]));
+            cS[4 * q + 1] = fmaf(B[q].y, fB, fmaf(A[q].y, fA, cS[4 * q + 1]));
+            cS[4 * q + 2] = fmaf(B[q].z, fB, fmaf(A[q].z, fA, cS[4 * q + 2]));
+            cS[4 * q + 3] = fmaf(B[q].w, fB, fmaf(A[q].w, fA, cS[4 * q + 3]));
+        }
+        if (tid == 0) bS = fmaf(ebB, fB, fmaf(ebA, fA, bS));
+    };
+    int i = blockIdx.x;
+    load_row(i, ra);
+    load_row(min(i + G, m), rb);
+    for (;;) {
+        const bool more = i + 2 * G <= m;
+        if (more) { load_row(i + 2 * G, rc); load_row(min(i + 3 * G, m), rd); }
+        step(i, ra, rb, 0);
+        i += 2 * G;
+        if (!more) break;
+        const bool more2 = i + 2 * G <= m;
+        if (more2) { load_row(i + 2 * G, ra); load_row(min(i + 3 * G, m), rb); }
+        step(i, rc, rd, 1);
+        i += 2 * G;
+        if (!more2) break;
+    }
+    float* pp = csum + (long)blockIdx.x * pstride;
+#pragma unroll
+    for (int q = 0; q < SK4_Q; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int j = q * (SK4_T * 4) + tid * 4 + e;
+            if (j < n) pp[j] = cS[4 * q + e];
+        }
+    if (tid == 0) pp[n] = bS;
+}
+
+// v_j <- v_j - log C_j (+ log m for the dustbin column) from the per-block column sums; columns whose sum underflowed go on the repair list
+__global__ __launch_bounds__(256) void sinkhorn_fused4_combine_kernel(const float* __restrict__ csum, int pstride, int n_parts,
+                                                                       const int* __restrict__ m_ptr, const int* __restrict__ n_ptr, float* __restrict__ v,
+                                                                       float* __restrict__ norm_out, int* __restrict__ list, int* __restrict__ cnt_this,
+                                                                       int* __restrict__ cnt_next, float c_min) {
+    __shared__ float red[8][32];
+    const int m = *m_ptr, n = *n_ptr;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *cnt_next = 0;      // the other iteration's counter: nobody uses it during this one
+    if (m <= 0 || n <= 0 || (int)blockIdx.x * 32 > n) return;
+    const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int j = blockIdx.x * 32 + c;
+    const int ns = min(n_parts, m + 1);
+    float S = 0.f;
+    if (j <= n)
+        for (int s0 = g; s0 < ns; s0 += 8) S += csum[(long)s0 * pstride + j];
+    red[g][c] = S;
+    __syncthreads();
+    if (g == 0 && j <= n) {
+        float C = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) C += red[k][c];
+        if (C > c_min) v[j] = v[j] - logf(C) + (j == n ? logf((float)m) : 0.f);
+        else list[atomicAdd(cnt_this, 1)] = j;                  // order does not matter: the repair kernel recomputes each entry on its own
+        if (j == 0) *norm_out = sg_norm(m, n);
+    }
+}
+
+// exact v_j = log_nu_j - logsumexp_i(z_ij + u_i) for the listed columns (one block per entry, strided column read); nothing to do, normally
+__global__ __launch_bounds__(256) void sinkhorn_fused4_repair_kernel(const float* __restrict__ sim, int ld, const int* __restrict__ m_ptr,
+                                                                      const int* __restrict__ n_ptr, float alpha, const float* __restrict__ u,
+                                                                      float* __restrict__ v, const int* __restrict__ list, const int* __restrict__ cnt) {
+    __shared__ float2 red[4];
+    const int count = *cnt;
+    const int m = *m_ptr, n = *n_ptr;
+    for (int idx = blockIdx.x; idx < count; idx += gridDim.x) {
+        const int j = list[idx];
+        OnlineLSE t;
+        for (int i = threadIdx.x; i <= m; i += 256) t.add(((i < m && j < n) ? sim[(long)i * ld + j] : alpha) + u[i]);
+        const float wm = wave_max(t.m);
+        const float wsum = wave_sum(wm == -INFINITY ? 0.f : t.s * expf(t.m - wm));
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = make_float2(wm, wsum);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            OnlineLSE a;
+            for (int w = 0; w < 4; ++w) a.merge(red[w].x, red[w].y);
+            const float norm = sg_norm(m, n);
+            v[j] = ((j == n) ? logf((float)m) + norm : norm) - (logf(a.s) + a.m);
+        }
+    }
+}
+
 // v from the per-block column partials of sinkhorn_fused_kernel: 32 columns x 8 partial groups per block
 __global__ __launch_bounds__(256) void sinkhorn_fused_combine_kernel(const float2* __restrict__ part, int pstride, int n_parts,
                                                                       const int* __restrict__ m_ptr, const int* __restrict__ n_ptr,
@@ -516,6 +695,29 @@ static int sinkhorn(im_ctx* ctx, hipStream_t s, const float* sim, int ld, const 
         static const bool form1 = getenv("IM_SINKHORN_FORM") && getenv("IM_SINKHORN_FORM")[0] == '1';
         static const bool wide = getenv("IM_SINKHORN_FORM") && getenv("IM_SINKHORN_FORM")[0] == '3';   // 1024 threads x 16 columns
         static const int blocks_env = getenv("IM_SINKHORN_BLOCKS") ? atoi(getenv("IM_SINKHORN_BLOCKS")) : 0;   // tuning knob
+        static const int form4 = (getenv("IM_SINKHORN_FORM") && getenv("IM_SINKHORN_FORM")[0] == '4') ? (getenv("IM_SINKHORN_FORM")[1] == 'w' ? 2 : 1) : 0;
+        if (form4) {      // one exponential per element + repair list (see sinkhorn_fused4_kernel); "4w": 1024 threads x 16 columns
+            const int G4 = std::min(std::min(blocks_env > 0 ? blocks_env : 256, 2 * max_parts), m_max + 1);
+            const size_t lds4 = (SKF_MAXN + 2 * 16 * 4) * sizeof(float);
+            static size_t lo4[IM_MAX_DEVICES] = {0}, lo4w[IM_MAX_DEVICES] = {0};
+            if (form4 == 2) IM_HIP(ctx, ensure_dyn_lds(reinterpret_cast<const void*>(&sinkhorn_fused4_kernel<1024, 4>), lds4, lo4w));
+            else IM_HIP(ctx, ensure_dyn_lds(reinterpret_cast<const void*>(&sinkhorn_fused4_kernel<512, 8>), lds4, lo4));
+            float* csum = reinterpret_cast<float*>(ws->part);       // [G4][pstride] floats in the partials buffer (room for 2 x max_parts rows)
+            int* list = ws->ridx;                                   // free until the assignment stage: [0 .. n] column list, then the two counters
+            int* cnt = ws->ridx + (ctx->max_kpts + 1);
+            IM_HIP(ctx, launch_zero_words(cnt, 2, s));
+            // IM_SINKHORN_REPAIR_ALL=1 (tests): every column goes through the exact repair kernel
+            static const float c_min = (getenv("IM_SINKHORN_REPAIR_ALL") && getenv("IM_SINKHORN_REPAIR_ALL")[0] == '1') ? 3.0e38f : 1e-30f;
+            for (int it = 0; it < iters; ++it) {
+                if (form4 == 2) hipLaunchKernelGGL((sinkhorn_fused4_kernel<1024, 4>), dim3(G4), dim3(1024), lds4, s, sim, ld, m_ptr, n_ptr, alpha, v, u, csum, pstride);
+                else hipLaunchKernelGGL((sinkhorn_fused4_kernel<512, 8>), dim3(G4), dim3(512), lds4, s, sim, ld, m_ptr, n_ptr, alpha, v, u, csum, pstride);
+                hipLaunchKernelGGL(sinkhorn_fused4_combine_kernel, dim3((n_max + 1 + 31) / 32), dim3(256), 0, s, csum, pstride, G4, m_ptr, n_ptr, v, norm_out,
+                                   list, cnt + (it & 1), cnt + ((it + 1) & 1), c_min);
+                hipLaunchKernelGGL(sinkhorn_fused4_repair_kernel, dim3(64), dim3(256), 0, s, sim, ld, m_ptr, n_ptr, alpha, u, v, list, cnt + (it & 1));
+            }
+            IM_HIP(ctx, hipGetLastError());
+            return 0;
+        }
         const int G = std::min(std::min(blocks_env > 0 ? blocks_env : 256, max_parts), m_max + 1);
         const size_t skf_lds = form1 ? (SKF_MAXN + 2 * 2 * (SKF_T / 64)) * sizeof(float) : (SKF_MAXN + 2 * 16 * 4) * sizeof(float);
         static size_t lds_optin[IM_MAX_DEVICES] = {0}, lds_optin2[IM_MAX_DEVICES] = {0}, lds_optin3[IM_MAX_DEVICES] = {0};

@@ -303,12 +303,13 @@ def test_log_optimal_transport(lg_eng, ci):
     assert err < 1e-4, err
 
 
-@pytest.mark.parametrize("form", ["1", "3", "two_sweep"])
+@pytest.mark.parametrize("form", ["1", "3", "two_sweep", "4", "4w", "4_repair_all"])
 def test_log_optimal_transport_other_kernel_forms(form):
     """The Sinkhorn kernels kept behind A/B switches (IM_SINKHORN_FORM=1: one row per step, the round-2 kernel; 3: two rows per
     step on 1024 threads; IM_SINKHORN_TWO_SWEEP=1: the round-1 row / column sweeps) against the reference's `ot_out`
     (`superglue.py:152-186`, 20 and 100 iterations) and on ragged sizes against the oracle - the switches are read once per process,
-    so each form runs in a child process."""
+    so each form runs in a child process. Form 4 (experimental): one exponential per element, column sums of the row-normalised matrix,
+    with its repair list for underflowed columns; `4_repair_all` sends EVERY column through the exact repair kernel."""
     import os
     import subprocess
     import sys
@@ -337,7 +338,8 @@ def test_log_optimal_transport_other_kernel_forms(form):
         "print('WORST', worst)\n"
         "assert worst < 1e-4, worst\n")
     env = dict(os.environ, PYTHONPATH=root)
-    env.update({"IM_SINKHORN_TWO_SWEEP": "1"} if form == "two_sweep" else {"IM_SINKHORN_FORM": form})
+    env.update({"IM_SINKHORN_TWO_SWEEP": "1"} if form == "two_sweep" else
+               {"IM_SINKHORN_FORM": "4", "IM_SINKHORN_REPAIR_ALL": "1"} if form == "4_repair_all" else {"IM_SINKHORN_FORM": form})
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0 and "WORST" in r.stdout, r.stdout[-1500:] + r.stderr[-2500:]
 
