@@ -478,13 +478,13 @@ def main():
             sk = prof["sinkhorn"]
             alg = 2.0 * 20 * (n0 + 1) * (n1 + 1) * 4
             gbs = alg * sk["count"] / (sk["total_ms"] * 1e-3) / 1e9
-            result["roofline_sinkhorn"] = {"bound": "hbm", "kernel": "im::sinkhorn_fused2_kernel + sinkhorn_fused_combine_kernel (20 iterations)", "achieved": gbs, "peak": PEAK_HBM_GBS,
+            result["roofline_sinkhorn"] = {"bound": "hbm", "kernel": "im::sinkhorn_fused4_kernel + its combine / repair kernels (20 iterations)", "achieved": gbs, "peak": PEAK_HBM_GBS,
                                            "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
                                            "traffic": (20 * sum(v.get("traffic_bytes", 0) for k, v in traffic_db.items()
                                                                 if isinstance(v, dict) and "sinkhorn_fused" in k and k.endswith("@16384"))) or None,
                                            "avg_solve_ms": sk["total_ms"] / sk["count"], "algorithmic_bytes_per_solve": alg,
                                            "note": "algorithmic bytes per SURVEY 8d: two reads of the (M+1)(N+1) fp32 couplings per "
-                                                   "iteration (row sweep, column sweep). The kernel (sinkhorn_fused2_kernel) keeps each row in "
+                                                   "iteration (row sweep, column sweep). The kernel (sinkhorn_fused4_kernel) keeps each row in "
                                                    "registers for both uses and reads the matrix ONCE per iteration: the bytes it moves are "
                                                    "half of that (`traffic`), i.e. the HBM rate actually sustained is achieved / 2"}
         result["kernel_ms_per_pair"] = {k: round(v["total_ms"] / prof_steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}

@@ -285,7 +285,7 @@ __global__ __launch_bounds__(SKF_T, 2) void sinkhorn_fused_kernel(const float* _
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Round 4 form of the single-read iteration (selected by default; IM_SINKHORN_FORM=1 keeps the kernel above for A/B): the same
+// Round 4, first step (IM_SINKHORN_FORM=2; the default is sinkhorn_fused4_kernel below, IM_SINKHORN_FORM=1 keeps the kernel above): the same
 // one read of the couplings per iteration, written for FEWER vector instructions per element and more waves per SIMD - the
 // kernel above issues ~26 VALU slots per element (three exponentials at a quarter of the rate each), which at 16384^2 is more
 // time than the 1.07 GB take to arrive:
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(SK2_T, 1) void sinkhorn_fused2_kernel(const float* 
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// IM_SINKHORN_FORM=4 (round 4, experimental A/B form; the default stays the two-row kernel above): ONE exponential per element.
+// The default form since the end of round 4 (IM_SINKHORN_FORM=2 keeps the two-row online-maximum kernel above for A/B): ONE exponential per element.
 // With u_i fresh from the row pass, exp(z_ij + u_i + v_j - norm) is the row-softmax value the row pass has just computed,
 //     p_ij = exp((z_ij + v_j) - M_i) / S_i,          e^(z_ij + u_i + v_j) = mu_i p_ij,
 // so the column update needs no exponential of its own:  logsumexp_i(z_ij + u_i) = -v_j + norm + log C_j,  C_j = sum_i w_i p_ij  (w = 1, n for the
@@ -695,8 +695,11 @@ static int sinkhorn(im_ctx* ctx, hipStream_t s, const float* sim, int ld, const 
         static const bool form1 = getenv("IM_SINKHORN_FORM") && getenv("IM_SINKHORN_FORM")[0] == '1';
         static const bool wide = getenv("IM_SINKHORN_FORM") && getenv("IM_SINKHORN_FORM")[0] == '3';   // 1024 threads x 16 columns
         static const int blocks_env = getenv("IM_SINKHORN_BLOCKS") ? atoi(getenv("IM_SINKHORN_BLOCKS")) : 0;   // tuning knob
-        static const int form4 = (getenv("IM_SINKHORN_FORM") && getenv("IM_SINKHORN_FORM")[0] == '4') ? (getenv("IM_SINKHORN_FORM")[1] == 'w' ? 2 : 1) : 0;
-        if (form4) {      // one exponential per element + repair list (see sinkhorn_fused4_kernel); "4w": 1024 threads x 16 columns
+        // default: form 4 (one exponential per element + repair list, see sinkhorn_fused4_kernel). IM_SINKHORN_FORM = 4w: the same on 1024
+        // threads x 16 columns; 2: the two-row online-maximum kernel; 3: that on 1024 threads; 1: the round-2 one-row kernel
+        static const char* const form_env = getenv("IM_SINKHORN_FORM");
+        static const int form4 = (!form_env || !form_env[0] || form_env[0] == '4') ? ((form_env && form_env[0] == '4' && form_env[1] == 'w') ? 2 : 1) : 0;
+        if (form4) {
             const int G4 = std::min(std::min(blocks_env > 0 ? blocks_env : 256, 2 * max_parts), m_max + 1);
             const size_t lds4 = (SKF_MAXN + 2 * 16 * 4) * sizeof(float);
             static size_t lo4[IM_MAX_DEVICES] = {0}, lo4w[IM_MAX_DEVICES] = {0};

@@ -303,13 +303,14 @@ def test_log_optimal_transport(lg_eng, ci):
     assert err < 1e-4, err
 
 
-@pytest.mark.parametrize("form", ["1", "3", "two_sweep", "4", "4w", "4_repair_all"])
+@pytest.mark.parametrize("form", ["1", "2", "3", "two_sweep", "4w", "4_repair_all"])
 def test_log_optimal_transport_other_kernel_forms(form):
-    """The Sinkhorn kernels kept behind A/B switches (IM_SINKHORN_FORM=1: one row per step, the round-2 kernel; 3: two rows per
-    step on 1024 threads; IM_SINKHORN_TWO_SWEEP=1: the round-1 row / column sweeps) against the reference's `ot_out`
+    """The Sinkhorn kernels kept behind A/B switches (IM_SINKHORN_FORM=1: one row per step, the round-2 kernel; 2: two rows per step with
+    online column maxima; 3: that on 1024 threads; 4w: the default form on 1024 threads; IM_SINKHORN_TWO_SWEEP=1: the round-1 row / column
+    sweeps) against the reference's `ot_out`
     (`superglue.py:152-186`, 20 and 100 iterations) and on ragged sizes against the oracle - the switches are read once per process,
-    so each form runs in a child process. Form 4 (experimental): one exponential per element, column sums of the row-normalised matrix,
-    with its repair list for underflowed columns; `4_repair_all` sends EVERY column through the exact repair kernel."""
+    so each form runs in a child process. The default form (4: one exponential per element, column sums of the row-normalised matrix, a
+    repair list for underflowed columns) is what every other test runs; `4_repair_all` sends EVERY column through its exact repair kernel."""
     import os
     import subprocess
     import sys
@@ -345,7 +346,7 @@ def test_log_optimal_transport_other_kernel_forms(form):
 
 
 def test_log_optimal_transport_ragged_sizes():
-    """The default Sinkhorn kernel (two rows per step) on sizes that leave rows / column groups partly or wholly empty, incl. an odd
+    """The default Sinkhorn kernel (two rows per step, one exponential per element) on sizes that leave rows / column groups partly or wholly empty, incl. an odd
     number of rows per block and one-row / one-column problems, against the oracle (`superglue.py:152-186`)."""
     from icepy4d_amd.engine import Engine
     o = oracle()

@@ -15,12 +15,12 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SETTINGS = [("form 1 (round 2: one row per step, 512 threads), 256 blocks", {"IM_SINKHORN_FORM": "1"}),
             ("form 1, 512 blocks", {"IM_SINKHORN_FORM": "1", "IM_SINKHORN_BLOCKS": "512"}),
-            ("form 2 (two rows per step, 512 threads), 256 blocks", {}),
-            ("form 2, 512 blocks", {"IM_SINKHORN_BLOCKS": "512"}),
-            ("form 2, 128 blocks", {"IM_SINKHORN_BLOCKS": "128"}),
+            ("form 2 (two rows per step, online column maxima, 512 threads), 256 blocks", {"IM_SINKHORN_FORM": "2"}),
+            ("form 2, 512 blocks", {"IM_SINKHORN_FORM": "2", "IM_SINKHORN_BLOCKS": "512"}),
+            ("form 2, 128 blocks", {"IM_SINKHORN_FORM": "2", "IM_SINKHORN_BLOCKS": "128"}),
             ("form 3 (two rows per step, 1024 threads), 256 blocks", {"IM_SINKHORN_FORM": "3"}),
-            ("form 4 (one exponential per element + repair list, 512 threads), 256 blocks", {"IM_SINKHORN_FORM": "4"}),
-            ("form 4, 512 blocks", {"IM_SINKHORN_FORM": "4", "IM_SINKHORN_BLOCKS": "512"}),
+            ("form 4 = DEFAULT (one exponential per element + repair list, 512 threads), 256 blocks", {}),
+            ("form 4, 512 blocks", {"IM_SINKHORN_BLOCKS": "512"}),
             ("form 4w (1024 threads x 16 columns), 256 blocks", {"IM_SINKHORN_FORM": "4w"}),
             ("two sweeps (round 1)", {"IM_SINKHORN_TWO_SWEEP": "1"})]
 
