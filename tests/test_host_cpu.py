@@ -292,6 +292,13 @@ def test_committed_bench_line_has_the_contract_fields():
         assert k in c, k
     assert c["kind"] in ("reference", "port") and c["value"] > 0
     assert abs(d["value"] - 1e3 / d["ms_per_step"] * d["n_gpus"]) < 1e-6 * d["value"]
+    if latest >= os.path.join(ROOT, "profiles", "r04_bench.json"):
+        # since round 4 the default line witnesses the other configurations too: configs[2] over distinct epochs, configs[4] (attention
+        # fraction, Sinkhorn time and rate) and one match() call through the plugin API
+        sm = d["side_measurements"]
+        assert sm["config3_distinct_epochs"]["pairs"] >= 60 and sm["config3_distinct_epochs"]["epochs_distinct_and_in_order"] is True
+        assert sm["config5"]["mean_keypoints"] == 16384 and sm["config5"]["sinkhorn"]["solve_ms"] > 0 and sm["config5"]["attention"]["frac_of_fp32_mfma_peak"] < 1
+        assert sm["match_call_ms"]["keypoints"] == 4096 and sm["match_call_ms"]["median"] > 0
 
 
 def test_sfm_relative_orientation_and_triangulation():
