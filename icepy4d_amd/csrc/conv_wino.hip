@@ -31,9 +31,14 @@
 //   * epilogue: the pass of A^T M A over a V row's four positions in registers, then the four waves exchange through LDS (12
 //     float4 per lane each way, one barrier) and wave w finishes tile row w for all 64 channels: bias, ReLU, optional 2x2
 //     max-pool (= one tile), in the associations of the two-row form (same bits);
-//   * FUSE1A: the patch is conv1a(img / 255) computed on the fly: thread t keeps the 3 x 3 image neighbourhood of its
-//     patch pixel in registers for the whole kernel, and per slab the conv1a weights of a channel quad are wave-uniform
-//     (scalar loads), so a patch value costs 9 fused multiply-adds per channel and no LDS read.
+//   * UREG (the 64 -> 64 layers, round 4): wave ph reads only the four positions of its V row, so the U block goes from L2 straight
+//     into registers (8 coalesced 16-byte loads per lane and slab, two register sets alternate) and not through LDS at all;
+//   * FUSE1A: the patch is conv1a(img / 255). With UREG (the model's conv1b, RESIDENT form, round 4): computed ONCE per block for the
+//     whole halo patch and all 64 channels as a [64 x 10] . [10 x 200] product on the matrix pipe (k = 0: bias x in-image mask, k =
+//     1 + t: tap t - the fma chain of the vector form, same bits) into a resident 51 KB LDS image; the slab loop then has no producer,
+//     no transfer and no barrier. Without UREG (unpooled fused form, unused by the model): thread t keeps the 3 x 3 image neighbourhood
+//     of its patch pixel in registers and computes its pixel's 8 channels per slab (9 packed fmas per channel pair, weights as
+//     wave-uniform scalar loads).
 //
 // History (same tests, conv 64 -> 64 + pool at 1080p, non-fused): 8-wave kernel with a V image in LDS 2.08 ms; its
 // 4-wave form with a register-local inverse transform 2.08; register input transform, 8 waves, one block per CU 1.60
@@ -43,7 +48,8 @@
 // accumulator registers (no moves), packed subtracts (v_pk_fma_f32 by an opaque -1), uniform output addressing and max3 for
 // ReLU + pool, about 500 -> 170 vector instructions per wave, 1.42 ms (fused first layer 1.49 -> 1.43). Round 4: one V row x 64
 // channels per wave instead of two V rows x 32 (above): conv 64 -> 64 + pool at 540p 0.332 -> 0.319 ms, fused first layer 1.437 ->
-// 1.398. Round 4 also measured four more ideas and adopted none (tools/experiments/conv_wino_round4_experiments.patch): the fused layer's U transfer as asm
+// 1.398; U through registers 0.319 -> 0.310 / 1.398 -> 1.356; resident patch 1.356 -> 1.293. Round 4 also measured six more ideas and
+// adopted none (tools/experiments/conv_wino_round4_experiments.patch): the fused layer's U transfer as asm
 // with its conv1a weights moved to the kernel-argument segment (keeps the scalar loads): +-0; conv1a itself on the matrix pipe
 // (v_mfma_f32_4x4x1, bit-identical): +2..5 % SLOWER; an L2 prefetch of the later cache lines of every patch pixel: +5 % slower; persistent
 // blocks that request the next region's first stage during the last slab (no prologue): -1 % on the large layers, +3..9 % on the small. The
