@@ -431,6 +431,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
     const int oy0 = POOL ? y0 >> 1 : y0, ox0 = POOL ? x0 >> 1 : x0;
     float* const ubase = a.out + (((long)b * Ho + oy0) * Wo + ox0) * a.Cout;  // uniform
     const int rows_left = Ho - oy0, cols_left = Wo - ox0 - ST * 4 * hh;
+    const bool cols_all = Wo - ox0 >= ST * 8;                                 // wave-uniform: every tile column of the region is inside the image
+    const __amdgpu_buffer_rsrc_t rout = wmake_rsrc(a.out + (long)b * Ho * Wo * a.Cout, (unsigned)Ho * Wo * a.Cout * 4u);
     auto finish_row = [&](auto W_) {
         constexpr int w = decltype(W_)::value;                                 // this wave's tile row: registers 4 w .. 4 w + 3
 #pragma unroll
@@ -452,6 +454,38 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
             }
             const float* y00 = reinterpret_cast<const float*>(&y[0][0]), *y01 = reinterpret_cast<const float*>(&y[0][1]);
             const float* y10 = reinterpret_cast<const float*>(&y[1][0]), *y11 = reinterpret_cast<const float*>(&y[1][1]);
+            if constexpr (!POOL) {       // ReLU on the register pairs (on the scalars each maximum drags two canonicalising v_max along)
+                const f32x2 fl2 = {floor_, floor_};
+#pragma unroll
+                for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+                    for (int bb = 0; bb < 2; ++bb) {
+                        const f32x2 lo = __builtin_elementwise_max(f32x2{y[aa][bb].x, y[aa][bb].y}, fl2), hi = __builtin_elementwise_max(f32x2{y[aa][bb].z, y[aa][bb].w}, fl2);
+                        y[aa][bb] = make_float4(lo.x, lo.y, hi.x, hi.y);
+                    }
+            }
+            if (cols_all) {
+                // the region's columns all lie inside the image (always, unless the width is ragged): stores through a buffer descriptor of
+                // this image's output - one per-lane offset for the whole epilogue, the pixel as a SCALAR offset, rows past the image
+                // dropped by the range check: no 64-bit address arithmetic, no compare, no branch per store; ReLU as one v_med3
+                const unsigned lane_voff = ((unsigned)(oy0 * Wo + ox0 + ST * 4 * hh) * a.Cout + co) * 4u;
+                const unsigned row_b = (unsigned)Wo * a.Cout * 4u, px_b = (unsigned)a.Cout * 4u;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float v00 = y00[q], v01 = y01[q], v10 = y10[q], v11 = y11[q];
+                    if constexpr (POOL) {
+                        const float mx = __builtin_fmaxf(__builtin_fmaxf(v00, v01), v10);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaxf(__builtin_fmaxf(mx, v11), floor_)), rout, lane_voff, w * row_b + q * px_b, 0);
+                    } else {
+                        const unsigned so = (2 * w) * row_b + (2 * q) * px_b;
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v00), rout, lane_voff, so, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v01), rout, lane_voff, so + px_b, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v10), rout, lane_voff, so + row_b, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v11), rout, lane_voff, so + row_b + px_b, 0);
+                    }
+                }
+                continue;
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {                                       // tile column q (+ 4 hh through lane_off)
                 const float v00 = y00[q], v01 = y01[q], v10 = y10[q], v11 = y11[q];
@@ -464,12 +498,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
                     float* const dn = up + (long)Wo * a.Cout;
                     const bool c0 = 2 * q < cols_left, c1 = 2 * q + 1 < cols_left;
                     if (2 * w < rows_left) {
-                        if (c0) up[lane_off] = __builtin_fmaxf(v00, floor_);
-                        if (c1) up[lane_off + a.Cout] = __builtin_fmaxf(v01, floor_);
+                        if (c0) up[lane_off] = v00;
+                        if (c1) up[lane_off + a.Cout] = v01;
                     }
                     if (2 * w + 1 < rows_left) {
-                        if (c0) dn[lane_off] = __builtin_fmaxf(v10, floor_);
-                        if (c1) dn[lane_off + a.Cout] = __builtin_fmaxf(v11, floor_);
+                        if (c0) dn[lane_off] = v10;
+                        if (c1) dn[lane_off + a.Cout] = v11;
                     }
                 }
             }
