@@ -2,7 +2,10 @@
 # Runs the measurement passes behind profiles/ on the GPU box (one gpurun call):
 #   /usr/local/graft/bin/gpurun --timeout 3000 -- 'bash tools/collect_profiles.sh r04'
 # rocprofv3 wants cwd=/tmp and TMPDIR=/tmp on this pool; PMC passes are separate runs with --kernel-trace only.
+# A second argument "core" re-measures only what a kernel change moves (bench lines, traces, counters of the LightGlue pair, parity
+# report) and leaves the rehearsal / SuperGlue / per-phase files of the last full collection in place.
 tag=${1:-r04}
+mode=${2:-full}
 root=${GRAFT_REPO_ROOT:-/root/repo}
 out=$root/gpurun_out/$tag
 mkdir -p $out
@@ -13,6 +16,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats1 -- python3 $
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_default -- python3 $root/bench.py --no-cpu-baseline --no-side-measurements > $out/bench_default_under_rocprof.json 2> /dev/null
 python3 $root/bench.py --config 5 > $out/bench_config5.json 2> $out/bench_config5.err
 python3 $root/bench.py --config 3 --no-cpu-baseline > $out/bench_config3.json 2> $out/bench_config3.err
+if [ "$mode" = full ]; then
 # config 4 rehearsed on the one GPU of this box: (a) 256 of its 2048 epochs on one rank (98 KB records with keypoints);
 # (b) the same through torch.distributed.run with ONE rank and the nccl backend forced (RCCL init, all-gather, `ranks` object);
 # (c) two ranks sharing cuda:0 over gloo (IM_BENCH_ONE_DEVICE=1): the N > 1 code path end to end with real GPU work
@@ -24,13 +28,14 @@ IM_BENCH_ONE_DEVICE=1 python3 $root/bench.py --gpus 8 --config 4 --steps 32 --wa
 python3 $root/tools/profile_match_call.py > $out/match_call_phases.txt 2>&1
 python3 $root/tools/bench_sinkhorn.py > $out/sinkhorn_forms.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_config5 -- python3 $root/bench.py --config 5 --steps 3 --warmup 1 > $out/bench_config5_under_rocprof.json 2> /dev/null
+fi
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_lg_$c -- python3 $root/tools/run_pair_once.py lightglue 2 > /dev/null 2>&1
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_sg_$c -- python3 $root/tools/run_pair_once.py superglue 1 > /dev/null 2>&1
+  [ "$mode" = full ] && rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_sg_$c -- python3 $root/tools/run_pair_once.py superglue 1 > /dev/null 2>&1
 done
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $out/pmc_attn_sq -- python3 $root/tools/run_attn_once.py > /dev/null 2>&1
+[ "$mode" = full ] && rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $out/pmc_attn_sq -- python3 $root/tools/run_attn_once.py > /dev/null 2>&1
 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $out/pmc_sq_all -- python3 $root/tools/run_pair_once.py lightglue 2 > /dev/null 2>&1
 cd $root
 python3 tests/parity_report.py --epochs 30 --superglue --out $out/parity_winograd.json > $out/parity_winograd.log 2>&1
-IM_CONV_DIRECT=1 python3 tests/parity_report.py --out $out/parity_direct_conv.json > $out/parity_direct_conv.log 2>&1
+[ "$mode" = full ] && IM_CONV_DIRECT=1 python3 tests/parity_report.py --out $out/parity_direct_conv.json > $out/parity_direct_conv.log 2>&1
 python3 tools/summarize_profiles.py $tag
