@@ -289,7 +289,9 @@ int im_ctx_reserve(im_ctx* ctx, int max_h, int max_w, int max_images, int max_kp
     if (max_h < 8 || max_w < 8 || max_images < 1 || max_kpts < 1) return ctx->fail(-30, "im_ctx_reserve: bad sizes");
     // the kernels address one image / one score matrix through 32-bit buffer offsets (range-checked descriptors): fail loudly
     // instead of wrapping around. Larger inputs go through the tile modes of the matcher (`matchers.py:304-469`).
-    if ((long)(max_h / 2) * (max_w / 2) * 64 * 4 >= (1L << 32))
+    // (16 rows of margin: halo rows below the image and the rows of a last, partial region are addressed too - past the descriptor's
+    // range, where loads return zero and stores are dropped - and their offsets must not wrap either)
+    if ((long)(max_h / 2 + 16) * (max_w / 2) * 64 * 4 >= (1L << 32))
         return ctx->fail(-33, "im_ctx_reserve: %d x %d exceeds 67 MP per image (32-bit offsets into the half-resolution activations): use a tile mode", max_h, max_w);
     if (max_kpts >= 32768)
         return ctx->fail(-34, "im_ctx_reserve: %d keypoints per image: the K x K score matrix is addressed with 32-bit byte offsets (K < 32768)", max_kpts);
