@@ -70,9 +70,13 @@ def _center_descriptor_head(sd: Dict[str, torch.Tensor]) -> None:
 
 
 LG_LAYERS = 9
+# `prune_gradual`: a descriptor channel of a unit vector in 256 dimensions is ~N(0, 1/256); sigmoid(400 x + b) > 0.01 (the keep test of
+# `get_pruning_mask`, `lightglue.py:563-569`) fails for x < (-4.595 - b) / 400, the token is confident for 400 x + b > logit(~0.9)
+PRUNE_GRADUAL_MATCH_BIAS = -1.5       # unmatchable below x = -0.0077: ~45 %
+PRUNE_GRADUAL_TOKEN_BIAS = 12.0       # confident above x = -0.0245: ~65 %
 
 
-def lightglue_state_dict(seed: int = 0, variant: str = "default") -> Dict[str, torch.Tensor]:
+def lightglue_state_dict(seed: int = 0, variant: str = "default", channel_stats=None) -> Dict[str, torch.Tensor]:
     """Seeded LightGlue(features='superpoint') weights, official key names
     (`lightglue/lightglue.py:350-373`).
 
@@ -84,6 +88,17 @@ def lightglue_state_dict(seed: int = 0, variant: str = "default") -> Dict[str, t
       prune        passthrough + matchability weight 0 / bias -10 in layers 0..7 and
                    confident tokens from layer 1 on: points get pruned, then
                    depth stop is disabled by the caller (depth_confidence=-1)
+      prune_gradual   passthrough + matchability and token confidence that each read ONE descriptor channel (a different
+                   one per layer, weight 400): every layer finds ~65 % of the live points confident and ~45 % of them
+                   unmatchable, so with the reference's default options (`depth_confidence` 0.95, `width_confidence` 0.99,
+                   pruning evaluated after every layer on the CPU path, `lightglue.py:326-331, 495-510`) ~30 % of the live
+                   points go per layer - 4096 points walk through (2048, 4096], (1024, 2048] and <= 1024 - until the
+                   pruned points (which count as confident, `:571-579`) lift the ratio over 0.95 and the pair stops at
+                   layer 6-8 on its own; with depth_confidence=-1 (no tokens: `keep` is the matchability test alone)
+                   ~45 % go per layer through all nine layers. `channel_stats` = (mean [256], std [256]) of the descriptors
+                   the weights will see (e.g. of the keypoint descriptors of one image; default: random unit vectors,
+                   0 and 1 / 16) keeps those rates on descriptors extracted from pixels
+      earlystop_late  passthrough + token-confidence bias +6 from layer 6 on: full width, stop = 7
     """
     rng = np.random.default_rng(2000 + seed)
     sd: Dict[str, torch.Tensor] = {}
@@ -136,7 +151,20 @@ def lightglue_state_dict(seed: int = 0, variant: str = "default") -> Dict[str, t
             w[0, 0] = 400.0
             sd[f"log_assignment.{i}.matchability.weight"] = w
             sd[f"log_assignment.{i}.matchability.bias"] = torch.full((1,), -4.0)
-    if variant not in ("default", "passthrough", "earlystop", "prune"):
+    if variant == "earlystop_late":
+        for i in range(6, LG_LAYERS - 1):
+            sd[f"token_confidence.{i}.token.0.weight"] *= 0.01
+            sd[f"token_confidence.{i}.token.0.bias"] = torch.full((1,), 6.0)
+    if variant == "prune_gradual":
+        mean, std = channel_stats if channel_stats is not None else (torch.zeros(256), torch.full((256,), 1.0 / 16.0))
+        for i in range(LG_LAYERS - 1):
+            for key, ch, bias in ((f"log_assignment.{i}.matchability", 2 * i, PRUNE_GRADUAL_MATCH_BIAS),
+                                  (f"token_confidence.{i}.token.0", 2 * i + 1, PRUNE_GRADUAL_TOKEN_BIAS)):
+                w = torch.zeros(1, 256)
+                w[0, ch] = 25.0 / float(std[ch])        # 400 for random unit vectors
+                sd[f"{key}.weight"] = w
+                sd[f"{key}.bias"] = torch.full((1,), bias - float(w[0, ch]) * float(mean[ch]))
+    if variant not in ("default", "passthrough", "earlystop", "prune", "prune_gradual", "earlystop_late"):
         raise ValueError(f"unknown LightGlue weight variant {variant!r}")
     return sd
 

@@ -354,6 +354,8 @@ def lightglue(feats0: dict, feats1: dict, sd: SD, depth_confidence: float = 0.95
             t1 = torch.sigmoid(F.linear(d1, tw, tb)).squeeze(-1)
             conf = torch.cat([t0, t1], -1)
             ratio = 1.0 - (conf < thr[i]).float().sum() / (m + n)
+            if trace is not None:      # decision margins of this layer (tests/parity_report.py reports them): confidence tests, stop ratio
+                layers[-1].update(token_margin=float((conf - thr[i]).abs().min()), stop_margin=float(ratio - depth_confidence))
             if ratio > depth_confidence:
                 break
         if do_prune:
@@ -364,6 +366,8 @@ def lightglue(feats0: dict, feats1: dict, sd: SD, depth_confidence: float = 0.95
                 if not d.shape[-2] > pruning_min_kpts:
                     continue
                 keep = torch.sigmoid(F.linear(d, mw, mb)).squeeze(-1) > (1 - width_confidence)
+                if trace is not None:
+                    layers[-1][f"match_margin{side}"] = float((torch.sigmoid(F.linear(d, mw, mb)) - (1 - width_confidence)).abs().min())
                 if t is not None:
                     keep |= t <= thr[i]
                 idx = torch.where(keep)[1]

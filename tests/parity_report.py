@@ -143,6 +143,12 @@ def run_case(eng, img0, img1, sp_sd, lg_sd, max_k, lg_conf=None, radius=4, thr=0
         "unexplained": exm["unexplained"], "stop_device": out["stop"], "stop_oracle": int(same["stop"]),
         "prune0_equal": bool(np.array_equal(out["prune0"], same["prune0"].numpy())),
         "prune1_equal": bool(np.array_equal(out["prune1"], same["prune1"].numpy())),
+        # live points per layer (prune counter = 1 + the number of layers a point survived, `lightglue.py:481-482, 502, 510`)
+        "live_device": [[int((out["prune0"] > l).sum()), int((out["prune1"] > l).sum())] for l in range(out["stop"])]
+        if float(lg_conf.get("width_confidence", 0.99)) > 0 else [],
+        "live_oracle": [[len(l["ind0"]), len(l["ind1"])] for l in tr["layers"]],
+        "oracle_min_margins": {k: min((l[k] for l in tr["layers"] if k in l), default=None)
+                               for k in ("token_margin", "stop_margin", "match_margin0", "match_margin1")},
         "mscore_max_abs_err": float(np.abs(out["matching_scores0"][v] - same["matching_scores0"].numpy()[v]).max()) if v.any() else 0.0}
     ours = margins.match_pairs(k0, k1, out["matches0"])
     theirs = margins.match_pairs(feats_o[0]["keypoints"].numpy(), feats_o[1]["keypoints"].numpy(), e2e["matches0"].numpy())

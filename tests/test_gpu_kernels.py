@@ -219,3 +219,42 @@ def test_flash_attn_large_dynamic_range(ctx):
         assert err < max(4 * err32, 1e-4), (z, err, err32)
 
 
+
+
+@pytest.mark.parametrize("nq,nk", [(1500, 4096), (900, 4096), (2048, 2049), (1025, 3000), (4096, 700), (1024, 4096), (2049, 1024), (130, 3967)])
+def test_flash_attn_split_kv_regimes_at_4096(ctx, nq, nk):
+    """The device-side split-KV of the attention kernel (`attention.hip`: the keys of a 128-query block are cut into 1 / 2 / 4 ranges
+    of whole steps for nq > 2048 / nq in (1024, 2048] / nq <= 1024; the last block to arrive merges the parked partials in split order)
+    at the widths a 4096-keypoint pair walks through while LightGlue prunes it (`lightglue/lightglue.py:495-510`): image 0 holds nq
+    live rows, image 1 nk, self and cross, against an fp64 softmax. K / V rows beyond the live counts hold NaN (never read: buffer
+    range check), so do the query rows beyond them, and the output rows beyond the live counts stay untouched. Each shape runs twice
+    through the same scratch (the merge counters reset themselves)."""
+    from icepy4d_amd._lib import ptr, stream_ptr
+    nmax, heads = 4096, 4
+    g = torch.Generator().manual_seed(nq * 5 + nk)
+    q = torch.randn(2, heads, nmax, 64, generator=g)
+    k = torch.randn(2, heads, nmax, 64, generator=g)
+    v = torch.randn(2, heads, nmax, 64, generator=g)
+    ns = [nq, nk]
+    qp, kp, vp = q.clone(), k.clone(), v.clone()
+    for z in range(2):
+        qp[z, :, ns[z]:] = float("nan"); kp[z, :, ns[z]:] = float("nan"); vp[z, :, ns[z]:] = float("nan")
+    dn = torch.tensor(ns, dtype=torch.int32, device="cuda")
+    dq, dk, dv = dev(qp), dev(kp), dev(vp)
+    for cross in (0, 1):
+        outs = []
+        for rep in range(2):
+            dout = torch.full((2, nmax, heads * 64), float("nan"), device="cuda")
+            ctx.call("im_flash_attn", ptr(dq), ptr(dk), ptr(dv), ptr(dout), ptr(dn), nmax, 2, heads, cross, 0.125, stream_ptr())
+            torch.cuda.synchronize()
+            outs.append(dout.cpu())
+        out = outs[0]
+        assert torch.equal(outs[0].nan_to_num(7.0), outs[1].nan_to_num(7.0))         # deterministic merge order
+        for z in range(2):
+            y = z ^ 1 if cross else z
+            for hd in range(heads):
+                qq, kk, vv = q[z, hd, :ns[z]].double(), k[y, hd, :ns[y]].double(), v[y, hd, :ns[y]].double()
+                ref = torch.softmax(qq @ kk.t() * 0.125, -1) @ vv
+                err = (out[z, :ns[z], hd * 64:(hd + 1) * 64].double() - ref).abs().max().item()
+                assert err < 2e-5, (cross, z, hd, err)
+            assert torch.isnan(out[z, ns[z]:]).all()

@@ -75,6 +75,26 @@ def test_lightglue(ci):
         close(out[key], g[key])
 
 
+@pytest.mark.parametrize("ci", range(6))
+def test_lightglue_adaptive_large(ci):
+    """G9: the reference's LightGlue with pruning / early stop at work in every layer at 2048 / 1536, 4096 / 3000 and 2500 / 4096 points
+    (`lightglue/lightglue.py:477-510, 558-585`): stop layer, prune counters (= the live set of every layer) and matches identical."""
+    g = load_golden(f"g9_lightglue_adaptive_{ci}")
+    sd = synthetic.lightglue_state_dict(0, str(g["variant"]))
+    f = synthetic.synthetic_features(int(g["seed"]), int(g["m"]), int(g["n"]))
+    f0 = dict(keypoints=torch.from_numpy(f["kpts0"]), descriptors=torch.from_numpy(f["desc0"]), image_size=torch.from_numpy(f["size0"]))
+    f1 = dict(keypoints=torch.from_numpy(f["kpts1"]), descriptors=torch.from_numpy(f["desc1"]), image_size=torch.from_numpy(f["size1"]))
+    with torch.inference_mode():
+        tr = {}
+        out = o.lightglue(f0, f1, sd, depth_confidence=float(g["depth_confidence"]), width_confidence=float(g["width_confidence"]), trace=tr)
+    assert out["stop"] == int(g["stop"])
+    assert [[len(l["ind0"]), len(l["ind1"])] for l in tr["layers"]] == g["live"].tolist()
+    for key in ("matches0", "matches1", "matches", "prune0", "prune1"):
+        assert np.array_equal(out[key].numpy(), g[key]), key
+    for key in ("matching_scores0", "matching_scores1", "scores"):
+        close(out[key], g[key])
+
+
 @pytest.mark.parametrize("ci", range(3))
 def test_superglue(ci):
     g = load_golden(f"g3_superglue_{ci}")

@@ -195,6 +195,40 @@ def gen_prune_threshold():
          matching_scores1=out["matching_scores1"][0], stop=out["stop"], prune0=out["prune0"][0], prune1=out["prune1"][0])
 
 
+G9_CASES = (("prune_gradual", 2048, 1536, {}), ("prune_gradual", 2048, 1536, {"depth_confidence": -1}),
+            ("earlystop_late", 2048, 1536, {}), ("prune_gradual", 1536, 2048, {"width_confidence": 0.95}),
+            ("prune_gradual", 4096, 3000, {}), ("prune_gradual", 2500, 4096, {"depth_confidence": -1}))
+
+
+def gen_adaptive_large():
+    """g9_lightglue_adaptive_{0..5}: the reference's `LightGlue` (`lightglue/lightglue.py:436-556`) on synthetic features of 2048 / 1536
+    (and 4096 / 3000, 2500 / 4096) points with weights under which the adaptive machinery is at work in EVERY layer, the way it is with trained weights on the CPU
+    path (pruning evaluated after every layer, `:326-331, 495-510`): live widths walk through (1024, 2048] and far below on both
+    images, the pair stops on its own once the pruned points lift the confident ratio over 0.95 (`:571-579`) - or runs all nine
+    layers with depth_confidence=-1, where `get_pruning_mask` has no token confidences (`:563-569`) - and `earlystop_late` stops at
+    layer 7 at full width. Outputs only (matches, scores, stop, prune counters = the layer each point was dropped at)."""
+    from icepy4d.thirdparty.LightGlue.lightglue import lightglue as r_lg
+    for ci, (variant, m, n, conf) in enumerate(G9_CASES):
+        sd = synthetic.lightglue_state_dict(0, variant)
+        net = r_lg.LightGlue(features="superpoint", **conf).eval()
+        net.load_state_dict(sd)
+        f = synthetic.synthetic_features(90 + ci, m, n)
+        data = {"image0": {"keypoints": torch.from_numpy(f["kpts0"])[None], "descriptors": torch.from_numpy(f["desc0"])[None],
+                           "image_size": torch.from_numpy(f["size0"])[None]},
+                "image1": {"keypoints": torch.from_numpy(f["kpts1"])[None], "descriptors": torch.from_numpy(f["desc1"])[None],
+                           "image_size": torch.from_numpy(f["size1"])[None]}}
+        with torch.inference_mode():
+            out = net(data)
+        p0, p1 = out["prune0"][0], out["prune1"][0]
+        live = [[int((p0 > l).sum()), int((p1 > l).sum())] for l in range(int(out["stop"]))]
+        print(f"  LG adaptive case {ci} {variant} {m}x{n} {conf}: stop={out['stop']} matches={int((out['matches0'] > -1).sum())} live per layer {live}")
+        save(f"g9_lightglue_adaptive_{ci}", variant=variant, m=m, n=n, seed=90 + ci,
+             depth_confidence=conf.get("depth_confidence", 0.95), width_confidence=conf.get("width_confidence", 0.99),
+             matches0=out["matches0"][0], matches1=out["matches1"][0],
+             matching_scores0=out["matching_scores0"][0], matching_scores1=out["matching_scores1"][0],
+             stop=out["stop"], matches=out["matches"][0], scores=out["scores"][0], prune0=p0, prune1=p1, live=np.array(live))
+
+
 # G8's input: a pair whose HALF-resolution pyramid level is textured and related by a translation (each pixel of a half-size
 # translated pair blown up to a 2 x 2 block: with seeded weights the doubly smoothed full-size noise would leave only a few dozen
 # low-resolution matches). Parameters found by `python tools/gen_golden.py preselection_search`: with them some tile pair holds 4 or
@@ -321,6 +355,9 @@ def main():
         return
     if len(sys.argv) > 1 and sys.argv[1] == "prune_threshold":
         gen_prune_threshold()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "adaptive_large":
+        gen_adaptive_large()
         return
     if len(sys.argv) > 1 and sys.argv[1] == "preselection":
         gen_preselection(synthetic.superpoint_state_dict(0))
@@ -510,6 +547,7 @@ def main():
     gen_prune_threshold()
     gen_features_pickle()
     gen_preselection(sp_sd)
+    gen_adaptive_large()
     save("g5_assets", gray0=g0, gray1=g1, keypoints0=f0["keypoints"][0], keypoints1=f1["keypoints"][0],
          scores0=f0["keypoint_scores"][0], scores1=f1["keypoint_scores"][0],
          desc0_sha=sha(f0["descriptors"][0]), desc0_sample=f0["descriptors"][0][::16],
