@@ -143,6 +143,9 @@ def main():
                     help="pairs per launch (batch dimension over pairs inside the kernels); see DEFAULT_PAIRS_PER_LAUNCH for the measured sweep")
     ap.add_argument("--no-side-measurements", action="store_true", help="skip the short untimed-side runs (other launch mode, translated pairs)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: spawn / rendezvous / sharding / gather / JSON only")
+    ap.add_argument("--fail-epochs", default="", help="test hook for the failure isolation of the sharded driver: comma-separated epochs whose "
+                    "input pair is replaced by an array of the wrong shape; their records come out as n_matches = -1, the rank goes on, "
+                    "the all-gather happens and the line lists them in `failed_epochs`")
     args = ap.parse_args()
     if args.steps is None:
         args.steps = {2: 50, 3: 256, 4: max(1, 2048 // max(args.gpus, 1)), 5: 5}[args.config]
@@ -219,10 +222,14 @@ def main():
     force_dist = os.environ.get("IM_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ
     if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # a bounded collective timeout: a rank that died without reaching the all-gather must not hold the others for the default
+        # 10 (nccl) / 30 (gloo) minutes; torch.distributed.run additionally ends every rank as soon as one exits non-zero
+        import datetime
+        tmo = datetime.timedelta(seconds=int(os.environ.get("IM_BENCH_COLLECTIVE_TIMEOUT_S", "300")))
         if cpu_group:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=tmo)
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=tmo)
 
     from icepy4d_amd.sequence import all_gather_tables, new_table
     if args.dry_run:
@@ -250,6 +257,8 @@ def main():
                       pairs_per_launch=args.batch, with_keypoints=with_kp)
     eng = sm.slots[0][0]
     pool = [torch.from_numpy(p).cuda().contiguous() for p in host_pairs]
+    fail_epochs = {int(x) for x in args.fail_epochs.split(",") if x.strip()}
+    bad_pair = torch.zeros((2, 8, 8), dtype=torch.uint8, device=pool[0].device)      # --fail-epochs: a pair of the wrong shape
     table = new_table(args.steps, kpts, eng.device, with_kp)
     scratch = new_table(max(args.warmup, 2), kpts, eng.device, with_kp)   # >= 2 rows: the untimed gather below must load torch's sort kernels
 
@@ -292,7 +301,8 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        sm.match_pair(pool[(args.warmup + i) % len(pool)], epochs[args.warmup + i], table, i)
+        ep = epochs[args.warmup + i]
+        sm.match_pair(bad_pair if ep in fail_epochs else pool[(args.warmup + i) % len(pool)], ep, table, i)
     sm.flush()
     t_enq = time.perf_counter() - t0            # host time to enqueue every step (graph launches are asynchronous)
     sm.synchronize()
@@ -315,9 +325,12 @@ def main():
         ranks["device_names"] = sorted({torch.cuda.get_device_name(torch.cuda.current_device())})
     n_pairs = args.steps * world
     assert full.shape[0] == n_pairs, (full.shape, n_pairs)
-    nm = full[:, 3].float().mean().item()
-    n0 = full[:, 1].float().mean().item()
-    n1 = full[:, 2].float().mean().item()
+    # failure isolation: a pair that could not be matched carries n_matches = -1 in the gathered table, whichever rank owned it
+    ok_rows = full[full[:, 3] >= 0]
+    failed_epochs = sorted(int(e) for e in full[full[:, 3] < 0, 0].tolist())
+    nm = ok_rows[:, 3].float().mean().item() if len(ok_rows) else 0.0
+    n0 = ok_rows[:, 1].float().mean().item() if len(ok_rows) else 0.0
+    n1 = ok_rows[:, 2].float().mean().item() if len(ok_rows) else 0.0
 
     if cfg5:
         metric = "matched stereo image-pairs/sec (16384 kpts, 12 MP, SuperGlue)"
@@ -341,7 +354,11 @@ def main():
                    "mean_keypoints": n0, "mean_matches": nm},
         "host_enqueue_ms_per_step": 1e3 * t_enq / args.steps, "untimed_pairs_before_timing": warm_pairs,
         "all_gather_ms": 1e3 * t_gather,
+        "failed_epochs": failed_epochs,
     }
+    if failed_epochs:
+        result["failed_epochs_note"] = (f"{len(failed_epochs)} of the {n_pairs} timed pairs have a record with n_matches = -1 (this rank's own: "
+                                        f"{sm.failed}); they are counted in `value` as steps, not as matched pairs")
     if ranks is not None:
         result["ranks"] = ranks
 
@@ -682,12 +699,17 @@ def dry_run(args, rank, world, epochs, kpts, dist):
     rank 0 prints a JSON line with the contract's fields (value = records per second of this fake work: NOT a measurement)."""
     import torch
     from icepy4d_amd.sequence import all_gather_tables, new_table
+    from icepy4d_amd.sequence import mark_failed
     table = new_table(args.steps, kpts, "cpu", args.config == 4)
+    fail_epochs = {int(x) for x in args.fail_epochs.split(",") if x.strip()}
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         e = epochs[args.warmup + i]
+        if e in fail_epochs:
+            mark_failed(table, i, e, kpts)
+            continue
         table[i, 0] = e
         table[i, 1] = kpts
         table[i, 2] = kpts
@@ -706,18 +728,41 @@ def dry_run(args, rank, world, epochs, kpts, dist):
     n_pairs = args.steps * world
     assert full.shape[0] == n_pairs, (full.shape, n_pairs)
     want = sorted(e for r in range(world) for e in range(r, (args.warmup + args.steps) * world, world)[args.warmup:])
-    assert full[:, 0].tolist() == want and full[:, 3].tolist() == want
+    assert full[:, 0].tolist() == want and full[:, 3].tolist() == [(-1 if e in fail_epochs else e) for e in want]
     ranks = rank_report(dist, rank, world, args, t_own, t_gather, -1, "cpu", table, full, True) if world > 1 else None
     if rank == 0:
         emit(json.dumps({"ranks": ranks, "metric": "matched stereo image-pairs/sec (4096 kpts, 1080p)", "value": n_pairs / dt, "unit": "pairs/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                           "config": {"workload": "DRY RUN: fabricated records, no GPU work"}, "dry_run": True,
+                          "failed_epochs": sorted(int(e) for e in full[full[:, 3] < 0, 0].tolist()),
                           "roofline": None, "cpu_baseline": None}))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
+def abort_rank(exc) -> None:
+    """An error nothing could isolate (the device is gone, the library failed outside a pair): say so, try to leave the process group
+    for a bounded time so that the other ranks' collective fails fast instead of waiting for its timeout, and exit non-zero -
+    torch.distributed.run then ends the remaining ranks. Never re-executes: this process has touched the GPU."""
+    import threading
+    import traceback
+    traceback.print_exc()
+    sys.stderr.write(f"bench.py rank {os.environ.get('RANK', '0')}: unrecoverable error, leaving the process group and exiting 3\n")
+    sys.stderr.flush()
+    dist = sys.modules.get("torch.distributed")
+    if dist is not None and dist.is_available() and dist.is_initialized():
+        t = threading.Thread(target=dist.destroy_process_group, daemon=True)
+        t.start()
+        t.join(20.0)
+    os._exit(3)
+
+
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException as exc:      # noqa: BLE001
+        abort_rank(exc)

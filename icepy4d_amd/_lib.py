@@ -51,6 +51,7 @@ SIGNATURES = {
     "im_debug_read": [_P, C.c_char_p, _P, C.c_size_t, _P],
     "im_debug_guard_failures": [],
     "im_debug_guard_selftest": [_P, _P],
+    "im_debug_guards_check": [_P, _P],
     "im_pyr_down": [_P, _P, _P, _I, _I, _I, _I, _P],
     "im_pyr_up": [_P, _P, _P, _I, _I, _I, _I, _P],
     "im_gemm_nt": [_P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _P],

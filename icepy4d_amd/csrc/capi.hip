@@ -141,6 +141,8 @@ int im_flash_attn(im_ctx* ctx, const float* d_q, const float* d_k, const float* 
         int* c = ctx->dalloc<int>(ni, "stage_attn_cnt");
         if (!p || !c) return ctx->fail(-11, "im_flash_attn: out of device memory");
         IM_HIP(ctx, hipMemset(c, 0, ni * sizeof(int)));
+        ctx->dfree(ctx->stage_attn_part);        // the smaller scratch it replaces (the device is idle: synchronised above)
+        ctx->dfree(ctx->stage_attn_cnt);
         ctx->stage_attn_part = p; ctx->stage_attn_cnt = c; ctx->stage_attn_floats = nf; ctx->stage_attn_ints = ni;
     }
     a.part = ctx->stage_attn_part; a.counters = ctx->stage_attn_cnt;

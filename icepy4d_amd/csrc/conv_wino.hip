@@ -431,9 +431,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
     const int oy0 = POOL ? y0 >> 1 : y0, ox0 = POOL ? x0 >> 1 : x0;
     float* const ubase = a.out + (((long)b * Ho + oy0) * Wo + ox0) * a.Cout;  // uniform
     const int rows_left = Ho - oy0, cols_left = Wo - ox0 - ST * 4 * hh;
-    // wave-uniform: every tile column of the region is inside the image, and the byte offset of a row below it (dropped by the range check)
-    // does not wrap around 32 bits
-    const bool cols_all = Wo - ox0 >= ST * 8 && (unsigned long)(Ho + 8) * (unsigned long)Wo * (unsigned long)a.Cout * 4ul < (1ul << 32);
+    // wave-uniform: every tile column of the region is inside the image, the byte offset of a row below it (dropped by the range check)
+    // does not wrap around 32 bits, and the scalar offset ALONE (up to ST * 4 - 1 rows) stays below the record count: the raw-buffer
+    // check is `offset >= num_records - soffset`, whose right side must not wrap for a map lower than one region (small tiles)
+    const bool cols_all = Wo - ox0 >= ST * 8 && Ho >= ST * 4 && (unsigned long)(Ho + 8) * (unsigned long)Wo * (unsigned long)a.Cout * 4ul < (1ul << 32);
     const __amdgpu_buffer_rsrc_t rout = wmake_rsrc(a.out + (long)b * Ho * Wo * a.Cout, (unsigned)Ho * Wo * a.Cout * 4u);
     auto finish_row = [&](auto W_) {
         constexpr int w = decltype(W_)::value;                                 // this wave's tile row: registers 4 w .. 4 w + 3

@@ -116,8 +116,10 @@ struct im_ctx {
     unsigned** d_guard_blocks = nullptr;  // [2 * guards.size()] device pointers: lo, hi of every buffer
     int* d_guard_flag = nullptr;          // 0, or 1 + index of the first changed block seen
     size_t guard_table_cap = 0;
+    std::vector<unsigned**> retired_guard_tables;   // older tables stay valid until free_all: a check kernel still in flight may read them
     void* galloc(size_t bytes, const char* name, std::vector<void*>& owner);   // hipMalloc (+ guards); owner gets the base pointer
     void gfree(void* base);                                                    // hipFree (+ forget its guards)
+    void dfree(void* user_ptr);   // a buffer dalloc'ed outside a model (scratch that is being replaced by a larger one): out of `allocs`, gfree
     int guards_check(hipStream_t s, const char* where);                        // 0 ok / not enabled; < 0 with `err` set
 
     template <typename T>

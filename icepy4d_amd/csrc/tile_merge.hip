@@ -135,6 +135,8 @@ int im_merge_tile_matches(im_ctx* ctx, int n_pairs, int max_kpts, const int32_t*
     MergeScratch& ms = *ctx->merge;
     if (cap > ms.cap) {
         IM_HIP(ctx, hipDeviceSynchronize());
+        ctx->dfree(ms.key); ctx->dfree(ms.skey); ctx->dfree(ms.seq);     // the smaller scratch this replaces
+        ms.key = ms.skey = nullptr; ms.seq = nullptr; ms.cap = 0;
         ms.key = ctx->dalloc<unsigned long long>(cap, "merge.key");
         ms.skey = ctx->dalloc<unsigned long long>(cap, "merge.skey");
         ms.seq = ctx->dalloc<unsigned>(cap, "merge.seq");

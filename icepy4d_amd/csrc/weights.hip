@@ -1,5 +1,6 @@
 // Host-side weight handling: tensors arrive under their official state-dict key names (im_set_tensor),
 // im_finalize_weights re-packs them for the kernels and uploads.
+#include <atomic>
 #include "ctx.h"
 #include "workspace.h"
 
@@ -41,7 +42,7 @@ std::vector<float> pack_conv3x3_wino(const float* w, int cout, int cin) {
 // ------------------------------------------------------------------------------------------------ IM_DEBUG_GUARDS
 static constexpr unsigned GUARD_WORDS = 64;                  // 256 bytes on each side
 static constexpr unsigned GUARD_PATTERN = 0xA5C3F00Du;
-static int g_guard_failures = 0;                             // process-wide tally (im_debug_guard_failures)
+static std::atomic<int> g_guard_failures{0};                  // process-wide tally (im_debug_guard_failures): contexts on several threads
 
 __global__ void guard_fill_kernel(unsigned* lo, unsigned* hi) {
     lo[threadIdx.x] = GUARD_PATTERN ^ threadIdx.x;
@@ -70,6 +71,13 @@ void* im_ctx::galloc(size_t bytes, const char* name, std::vector<void*>& owner) 
     return static_cast<char*>(base) + 256;
 }
 
+void im_ctx::dfree(void* user_ptr) {
+    if (!user_ptr) return;
+    void* base = guards_on ? static_cast<char*>(user_ptr) - 256 : user_ptr;
+    for (size_t i = 0; i < allocs.size(); ++i)
+        if (allocs[i] == base) { allocs.erase(allocs.begin() + i); gfree(base); return; }
+}
+
 void im_ctx::gfree(void* base) {
     if (guards_on)
         for (size_t i = 0; i < guards.size(); ++i)
@@ -82,16 +90,19 @@ int im_ctx::guards_check(hipStream_t s, const char* where) {
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     hipStreamIsCapturing(s, &cap);
     const bool capturing = cap != hipStreamCaptureStatusNone;
+    // Inside a graph capture nothing is recorded: a captured check kernel would keep the table pointer and the block count of the capture
+    // for every later replay, while buffers may have come and gone since. The caller checks from the host after the replay
+    // (`im_debug_guards_check`; icepy4d_amd/sequence.py does under IM_DEBUG_GUARDS=1), and im_ctx_destroy checks in any case.
+    if (capturing) return 0;
     if (guards_dirty) {
-        if (capturing) return 0;                              // no allocation inside a capture: the next plain call checks
-        hipDeviceSynchronize();
+        // a FRESH table per change (a few hundred pointers; debugging mode only): no synchronisation with check kernels that may still read
+        // the previous one on another stream - it is retired, not freed, until the context goes
         std::vector<unsigned*> h;
         for (const Guard& g : guards) { h.push_back(g.lo); h.push_back(g.hi); }
-        if (h.size() > guard_table_cap) {
-            if (d_guard_blocks) hipFree(d_guard_blocks);
-            guard_table_cap = h.size() + 64;
-            if (hipMalloc((void**)&d_guard_blocks, guard_table_cap * sizeof(unsigned*)) != hipSuccess) return fail(-91, "IM_DEBUG_GUARDS: table allocation failed");
-        }
+        if (d_guard_blocks) retired_guard_tables.push_back(d_guard_blocks);
+        d_guard_blocks = nullptr;
+        guard_table_cap = h.size();
+        if (hipMalloc((void**)&d_guard_blocks, guard_table_cap * sizeof(unsigned*)) != hipSuccess) return fail(-91, "IM_DEBUG_GUARDS: table allocation failed");
         if (!d_guard_flag) {
             if (hipMalloc((void**)&d_guard_flag, sizeof(int)) != hipSuccess) return fail(-91, "IM_DEBUG_GUARDS: flag allocation failed");
             hipMemset(d_guard_flag, 0, sizeof(int));
@@ -100,7 +111,6 @@ int im_ctx::guards_check(hipStream_t s, const char* where) {
         guards_dirty = false;
     }
     guard_check_kernel<<<(unsigned)(2 * guards.size()), GUARD_WORDS, 0, s>>>(d_guard_blocks, d_guard_flag);
-    if (capturing) return 0;                                  // the check is part of the graph; its flag is read by a later plain call
     int flag = 0;
     if (hipStreamSynchronize(s) != hipSuccess || hipMemcpy(&flag, d_guard_flag, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
         return fail(-92, "IM_DEBUG_GUARDS: reading the flag failed after %s", where);
@@ -114,7 +124,13 @@ int im_ctx::guards_check(hipStream_t s, const char* where) {
                 g.name.c_str(), where);
 }
 
-extern "C" int im_debug_guard_failures(void) { return g_guard_failures; }
+extern "C" int im_debug_guard_failures(void) { return g_guard_failures.load(); }
+
+extern "C" int im_debug_guards_check(im_ctx* ctx, void* stream) {
+    if (!ctx) return -1;
+    if (hipSetDevice(ctx->device) != hipSuccess) return ctx->fail(-3, "hipSetDevice failed");
+    return ctx->guards_check((hipStream_t)stream, "im_debug_guards_check (after a graph replay)");
+}
 
 __global__ void guard_poke_kernel(unsigned* word, unsigned value) { *word = value; }
 
@@ -154,6 +170,8 @@ void im_ctx::free_all() {
         ws = nullptr;
     }
     if (d_guard_blocks) hipFree(d_guard_blocks);
+    for (unsigned** t : retired_guard_tables) hipFree(t);
+    retired_guard_tables.clear();
     if (d_guard_flag) hipFree(d_guard_flag);
     d_guard_blocks = nullptr; d_guard_flag = nullptr; guard_table_cap = 0;
     delete merge;

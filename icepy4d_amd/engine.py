@@ -210,27 +210,36 @@ class Engine:
                     prune0=p[0, :n0], prune1=p[1, :n1], stop=int(info[0]))
 
     def pair_to_host(self, pair: int = 0, channels_first: bool = True, pageable: bool = False):
-        """Everything a matcher call returns for one pair, in ONE round of asynchronous device-to-host copies into page-locked
-        buffers and one synchronisation (the separate `features_to_host` / `matches_to_host` calls make about fourteen blocking
-        copies into pageable memory: ~1 ms of a 10.6 ms `match()` at 1080p / 4096 keypoints). The page-locked buffers come from
-        torch's caching host allocator (no allocation after the first call of a size) and are owned by the returned arrays - no
-        aliasing with later calls. Returns ((kpts0, desc0, scores0), (kpts1, desc1, scores1), matches dict); descriptors as
-        [256, n] when channels_first: a transposed VIEW of the [n, 256] rows, which is also what the reference hands out
-        (`feats['descriptors'].T`, `matchers.py:1281-1288`). pageable=True copies the results out of the page-locked buffers (for callers
-        that archive thousands of result sets: an array that stays alive keeps its page-locked block)."""
+        """Everything a matcher call returns for one pair: the two live counts first (8 bytes, one synchronisation), then ONE round of
+        asynchronous device-to-host copies of the LIVE rows only into page-locked buffers and a second synchronisation (the separate
+        `features_to_host` / `matches_to_host` calls make about fourteen blocking copies into pageable memory: ~1 ms of a 10.6 ms
+        `match()` at 1080p / 4096 keypoints; copying all K reserved rows instead of the live ones moved 21 MB per call at K = 10240, 33 MB
+        once a shared engine had grown to 16384, whatever n was). The page-locked buffers come from torch's caching host allocator (sizes in
+        power-of-two buckets: no allocation after the first call of a bucket) and are owned by the returned arrays - no aliasing with
+        later calls. Returns ((kpts0, desc0, scores0), (kpts1, desc1, scores1), matches dict); descriptors as [256, n] when
+        channels_first: a transposed VIEW of the [n, 256] rows, which is also what the reference hands out (`feats['descriptors'].T`,
+        `matchers.py:1281-1288`). pageable=True copies the results out of the page-locked buffers (for callers that archive thousands
+        of result sets: an array that stays alive keeps its page-locked block)."""
         a = 2 * pair
         host = {}
         with torch.cuda.device(self.device):
-            for name, t in (("n", self.n[a:a + 2]), ("info", self.info[pair]), ("kpts", self.kpts[a:a + 2]), ("scores", self.scores[a:a + 2]),
-                            ("desc", self.desc[a:a + 2]), ("matches", self.matches[a:a + 2]), ("mscores", self.mscores[a:a + 2]),
-                            ("prune", self.prune[a:a + 2])):
-                h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
-                h.copy_(t, non_blocking=True)
+            stream = torch.cuda.current_stream(self.device)
+            hn = torch.empty(2, dtype=torch.int32, pin_memory=True)
+            hn.copy_(self.n[a:a + 2], non_blocking=True)
+            stream.synchronize()
+            n0, n1 = (int(v) for v in hn.tolist())
+            rows = max(n0, n1, 1)
+            host["info"] = torch.empty(self.info[pair].shape, dtype=self.info.dtype, pin_memory=True)
+            host["info"].copy_(self.info[pair], non_blocking=True)
+            for name, t in (("kpts", self.kpts), ("scores", self.scores), ("desc", self.desc), ("matches", self.matches),
+                            ("mscores", self.mscores), ("prune", self.prune)):
+                live = t[a:a + 2, :rows]
+                h = torch.empty(live.shape, dtype=t.dtype, pin_memory=True)
+                h.copy_(live, non_blocking=True)
                 host[name] = h
-            torch.cuda.current_stream(self.device).synchronize()
+            stream.synchronize()
         if pageable:
             host = {k: torch.from_numpy(v.numpy().copy()) for k, v in host.items()}
-        n0, n1 = (int(v) for v in host["n"].tolist())
         feats = []
         for i, n in ((0, n0), (1, n1)):
             d = host["desc"][i, :n].numpy()

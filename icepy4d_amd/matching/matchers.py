@@ -738,8 +738,13 @@ class LightGlueMatcher(ImageMatcherBase):
                 return self._match_images_resized(image0, image1, int(config["resize"]), int(max_keypoints))
             try:
                 return self._match_images_resized(image0, image1, int(config["resize"]), int(max_keypoints))
-            except Exception as e:   # q7 (`matchers.py:1262-1267`): any failure of the resize path silently extracts without it
-                logger.debug(f"extract(resize={config['resize']!r}) failed ({e}): retrying without resize, as the reference does")
+            except RuntimeError:     # a library / device error (`Context.check`: out of memory, guard failure, HIP error) is not the
+                raise                # resize option's failure: hiding it behind a second forward would lose the message
+            except Exception as e:   # q7 (`matchers.py:1262-1267`): the reference's bare `except` calls `extract(image)` WITHOUT the option,
+                # i.e. with the preprocessor's default resize = 1024 (`lightglue/superpoint.py:106-110, 217-227`) - not "no resize"
+                logger.warning(f"extract(resize={config['resize']!r}) failed ({type(e).__name__}: {e}): retrying with the extractor's "
+                               "default resize=1024, as the reference does")
+                return self._match_images_resized(image0, image1, 1024, int(max_keypoints))
         g0, g1 = _as_device_image(image0), _as_device_image(image1)
         eng = self.engine
         eng.reserve(max(g0.shape[0], g1.shape[0]), max(g0.shape[1], g1.shape[1]), 2, int(max_keypoints))

@@ -23,6 +23,7 @@ import numpy as np
 import torch
 
 HEADER = 8
+_DEBUG_GUARDS = __import__("os").environ.get("IM_DEBUG_GUARDS") == "1"
 _FORCE_COLLECTIVE = __import__("os").environ.get("IM_BENCH_FORCE_DIST") == "1"   # rehearsal: run the all-gather at world size 1 too
 
 
@@ -40,6 +41,19 @@ def new_table(n_rows: int, max_kpts: int, device, with_keypoints: bool = False) 
     t = torch.full((n_rows, record_words(max_kpts, with_keypoints)), -1, dtype=torch.int32, device=device)
     t[:, HEADER + max_kpts:] = 0
     return t
+
+
+def mark_failed(table: torch.Tensor, row: int, epoch: int, max_kpts: int) -> None:
+    """The record of a pair that could not be matched: epoch, n0 = n1 = 0, n_matches = -1, no matches (`pending_epochs` hands such
+    epochs to a resumed run). The reference logs the error and goes on with the next epoch (`matchers.py:199-207`,
+    `main_dev.py:270-274, 295-301`); in a sharded run the rank must in addition reach the table all-gather, or every other rank
+    waits in it. Fill kernels only: enqueued on the current stream like the record of a pair that worked."""
+    r = table[row]
+    r[0:1].fill_(int(epoch))
+    r[1:HEADER].zero_()
+    r[3:4].fill_(-1)
+    r[HEADER:HEADER + max_kpts].fill_(-1)
+    r[HEADER + max_kpts:].zero_()
 
 
 def write_records(table: torch.Tensor, row: int, first_epoch: int, n_pairs: int, engine) -> None:
@@ -179,6 +193,7 @@ class SequenceMatcher:
         self._inp = torch.zeros(shape, dtype=torch.uint8, device=engine.device)
         self._rec = new_table(self.P, engine.max_kpts, engine.device, with_keypoints)
         self._pending = []           # (epoch, table, row) of the pairs waiting in self._inp
+        self.failed = []             # (epoch, message) of the pairs whose record says n_matches = -1
         self._pinned = None          # host feeder: ring of page-locked staging buffers (match_host_pair)
         self._pin_i = 0
 
@@ -212,24 +227,51 @@ class SequenceMatcher:
                 self._record(self._rec, 0, 0, self.P)
         self._graph = g
 
+    def _fail(self, epoch: int, table: torch.Tensor, row: int, exc: BaseException) -> None:
+        """Failure isolation (the reference logs and continues, `matchers.py:199-207`, `main_dev.py:270-274`): the pair gets
+        the record `mark_failed` writes and the sequence goes on. If even that cannot be enqueued the device is gone: the error
+        propagates to the caller, who owns the process group (bench.py: abort, exit non-zero)."""
+        import logging
+        logging.getLogger("icepy4d_amd").error("epoch %d failed: %s: %s", epoch, type(exc).__name__, exc)
+        self.failed.append((int(epoch), f"{type(exc).__name__}: {exc}"))
+        mark_failed(table, row, epoch, self.e.max_kpts)
+
     def _run_group(self) -> None:
         pend, self._pending = self._pending, []
         if not pend:
             return
-        if not self.use_graph or len(pend) < self.P:
-            # direct launches; also for a partially filled group (the tail of a sequence whose length is not a multiple of the
-            # pairs per launch): only the parked pairs are computed, the captured graph always runs all P
-            self._enqueue(self._inp[:2 * len(pend)] if self.P > 1 else self._inp)
-            self._record(self._rec, 0, 0, len(pend))
-        else:
-            if self._graph is None:
-                self._capture()
-            self._graph.replay()
-        for j, (epoch, table, row) in enumerate(pend):
+        for epoch, table, row in pend:     # a caller's programming error, not a pair's failure: raised, before anything runs
             if table.shape[1] != self._rec.shape[1]:
                 raise ValueError(f"match table rows are {table.shape[1]} words wide, this matcher writes records of {self._rec.shape[1]} "
                                  f"(with_keypoints={self._rec.shape[1] == record_words(self.e.max_kpts, True)}): build the table with "
                                  "new_table(..., with_keypoints=) to match the matcher's")
+        try:
+            if not self.use_graph or len(pend) < self.P:
+                # direct launches; also for a partially filled group (the tail of a sequence whose length is not a multiple of the
+                # pairs per launch): only the parked pairs are computed, the captured graph always runs all P
+                self._enqueue(self._inp[:2 * len(pend)] if self.P > 1 else self._inp)
+                self._record(self._rec, 0, 0, len(pend))
+            else:
+                if self._graph is None:
+                    self._capture()
+                self._graph.replay()
+                if _DEBUG_GUARDS:       # forwards inside a graph carry no guard check of their own (csrc/weights.hip): from the host
+                    self.e.ctx.call("im_debug_guards_check", self.e.stream_ptr())
+        except Exception as group_exc:      # noqa: BLE001 - any error of a launch group is isolated to the pairs that cause it
+            # the group as a whole could not be enqueued: its pairs one by one with direct launches (their inputs are still parked in
+            # self._inp), so that only the pairs that fail by themselves are marked
+            for j, (epoch, table, row) in enumerate(pend):
+                try:
+                    if len(pend) == 1:
+                        raise group_exc
+                    self._enqueue(self._inp[2 * j:2 * j + 2])
+                    self._record(self._rec, 0, 0, 1)
+                    table[row].copy_(self._rec[0], non_blocking=True)
+                    table[row, 0:1].fill_(epoch)
+                except Exception as exc:    # noqa: BLE001
+                    self._fail(epoch, table, row, exc)
+            return
+        for j, (epoch, table, row) in enumerate(pend):
             table[row].copy_(self._rec[j], non_blocking=True)
             table[row, 0:1].fill_(epoch)
 
@@ -237,13 +279,20 @@ class SequenceMatcher:
         """pair_u8: device uint8 [2, H, W]. Enqueues the pair (or, with pairs_per_launch > 1, parks it until its group is
         full) and its record; never synchronises."""
         if self.P == 1 and not self.use_graph:
-            self._enqueue(pair_u8)
-            self._record(table, row, epoch, 1)
+            try:
+                self._enqueue(pair_u8)
+                self._record(table, row, epoch, 1)
+            except Exception as exc:        # noqa: BLE001
+                self._fail(epoch, table, row, exc)
             return
         if self.use_graph and self._graph is None:
             self._capture()
         j = len(self._pending)
-        self._inp[2 * j:2 * j + 2].copy_(pair_u8, non_blocking=True)
+        try:
+            self._inp[2 * j:2 * j + 2].copy_(pair_u8, non_blocking=True)
+        except Exception as exc:            # noqa: BLE001 - e.g. an image of another shape or type than the sequence's: this pair only
+            self._fail(epoch, table, row, exc)
+            return
         self._pending.append((epoch, table, row))
         if len(self._pending) == self.P:
             self._run_group()
@@ -263,7 +312,11 @@ class SequenceMatcher:
         self._pin_i = (self._pin_i + 1) % len(self._pinned)
         if slot[1] is not None:
             slot[1].synchronize()
-        np.copyto(slot[0].numpy(), pair_u8)
+        try:
+            np.copyto(slot[0].numpy(), pair_u8)       # an unreadable / wrongly shaped image fails here: this pair only
+        except Exception as exc:            # noqa: BLE001
+            self._fail(epoch, table, row, exc)
+            return
         if self.use_graph and self._graph is None:
             self._capture()
         j = len(self._pending) if (self.P > 1 or self.use_graph) else 0
@@ -271,8 +324,11 @@ class SequenceMatcher:
         slot[1] = torch.cuda.Event()
         slot[1].record(torch.cuda.current_stream(self.e.device))
         if self.P == 1 and not self.use_graph:
-            self._enqueue(self._inp)
-            self._record(table, row, epoch, 1)
+            try:
+                self._enqueue(self._inp)
+                self._record(table, row, epoch, 1)
+            except Exception as exc:        # noqa: BLE001
+                self._fail(epoch, table, row, exc)
             return
         self._pending.append((epoch, table, row))
         if len(self._pending) == self.P:
@@ -332,6 +388,11 @@ class PairPipeline:
             sm.match_host_pair(pair_u8, epoch, table, row)
         if not sm._pending:
             self._next = (self._next + 1) % len(self.slots)
+
+    @property
+    def failed(self):
+        """(epoch, message) of every pair that got a `mark_failed` record, over all slots."""
+        return sorted(f for _, _, sm in self.slots for f in sm.failed)
 
     def flush(self) -> None:
         """Enqueue whatever is still waiting for a full launch group (nothing with one pair per launch)."""

@@ -135,6 +135,10 @@ int im_debug_guard_failures(void);
 /* Self-test of that mode: issues one stray 4-byte store right behind the newest library buffer, expects the check to fail with
  * -90, restores the word. Returns 0 when the stray store was caught, -93 when the mode is off, -94 when it went unnoticed. */
 int im_debug_guard_selftest(im_ctx* ctx, void* stream);
+/* Compares the guard words now, from the host (0 when the mode is off or every word is intact, -90 otherwise). Forwards recorded into
+ * a HIP graph carry no check of their own (a captured check would keep the buffer table of the capture): callers that replay graphs
+ * call this after a replay. */
+int im_debug_guards_check(im_ctx* ctx, void* stream);
 
 /* ---- stage entry points (what the stage-isolated parity tests call; also usable on their own) ----------- */
 /* C[m][n] = alpha * (sum_k A[m][k] W[n][k] + bias[n]); fp32 MFMA GEMM. bias may be NULL. big_tile: 128x128 tiles. */

@@ -111,7 +111,11 @@ def test_conv3x3(ctx, cin, cout, h, w, pool, relu):
 @pytest.mark.parametrize("cin,cout,h,w,pool", [(16, 64, 8, 32, 0), (64, 64, 37, 70, 0), (64, 128, 40, 64, 1), (128, 256, 17, 33, 0), (64, 64, 31, 47, 1),
                                                    # whole regions in x, a partial last region in y: the epilogue's buffer stores with the rows below
                                                    # the image dropped by the range check (the output is NaN-filled and holds two images)
-                                                   (64, 64, 36, 64, 0), (64, 64, 44, 96, 1), (128, 128, 20, 32, 0)])
+                                                   (64, 64, 36, 64, 0), (64, 64, 44, 96, 1), (128, 128, 20, 32, 0),
+                                                   # maps LOWER than one 8-row region (conv3 / conv4 of a wide, flat tile): the scalar store offset of
+                                                   # a row below the image alone exceeds the descriptor's record count there - these must take the
+                                                   # compared-store path and leave the second image and the NaN fill around it alone
+                                                   (64, 64, 2, 32, 0), (128, 128, 4, 48, 0), (64, 128, 6, 32, 0), (64, 64, 6, 64, 1), (64, 64, 4, 32, 1)])
 def test_conv3x3_winograd(ctx, cin, cout, h, w, pool, relu):
     """Winograd F(2x2, 3x3) on the matrix cores against an fp64 direct convolution; its rounding error is a few 1e-6
     on O(1) outputs (the direct kernel is ~1e-6), far inside the 1e-4 budget of the path."""
@@ -127,11 +131,13 @@ def test_conv3x3_winograd(ctx, cin, cout, h, w, pool, relu):
         ref = F.max_pool2d(ref, 2, 2)
     dx = dev(x.permute(0, 2, 3, 1))
     ho, wo = ref.shape[-2:]
-    dout = torch.full((2, ho, wo, cout), float("nan"), device="cuda")
+    big = torch.full((4, ho, wo, cout), float("nan"), device="cuda")            # the two output images with a NaN image in front and behind
+    dout = big[1:3]
     ctx.call("im_conv3x3_winograd", ptr(dx), ptr(wt.contiguous()), ptr(b), ptr(dout), 2, h, w, cin, cout, relu, pool, stream_ptr())
     torch.cuda.synchronize()
     err = (dout.cpu().permute(0, 3, 1, 2).double() - ref).abs().max().item()
     assert err < 2e-5, err
+    assert torch.isnan(big[0]).all() and torch.isnan(big[3]).all()              # no stray store on either side
 
 
 @pytest.mark.parametrize("n0,n1,cross", [(128, 128, 0), (300, 257, 0), (300, 257, 1), (1000, 77, 1), (64, 1, 1)])

@@ -933,20 +933,30 @@ def test_preselection_call_equals_the_reference_golden():
     assert fixed._tile_selection(g["image0"], g["image1"], l0, l1, TileSelection.PRESELECTION, **kw) == want_fixed
 
 
-def test_resize_failure_is_retried_without_resize_like_the_reference():
-    """q7 (`matchers.py:1262-1267`): the reference wraps `extract(..., resize=resize)` in a bare `except` and silently extracts
-    without `resize` when that fails. Default: reproduced (a `resize` the preprocessor cannot use gives the plain result);
-    opt["reference_quirks"] = False: the error reaches the caller."""
+def test_resize_failure_is_retried_with_the_default_resize_like_the_reference():
+    """q7 (`matchers.py:1262-1267`): the reference wraps `extract(..., resize=resize)` in a bare `except` and on failure calls
+    `extract(image)` without the option - i.e. with the preprocessor's DEFAULT resize = 1024 (`lightglue/superpoint.py:106-110,
+    217-227`), not without resizing. Default: reproduced (a `resize` the preprocessor cannot use gives the resize=1024 result, which
+    differs from the full-resolution one); opt["reference_quirks"] = False: the error reaches the caller. Library / device errors
+    (RuntimeError out of `Context.check`) are never swallowed."""
     from icepy4d_amd.matching import LightGlueMatcher
     sds = {"superpoint": SP_SD, "lightglue": synthetic.lightglue_state_dict(0, "passthrough")}
     a, b = synthetic.translated_pair(3, 200, 304)
     m = LightGlueMatcher({"state_dicts": sds})
-    f0, f1, m0, conf = m._match_images(a, b, max_keypoints=256)
+    p0, _, pm0, _ = m._match_images(a, b, max_keypoints=256)
+    f0, f1, m0, conf = m._match_images(a, b, max_keypoints=256, resize=1024)
     g0, g1, n0, conf2 = m._match_images(a, b, max_keypoints=256, resize="not a size")
     assert np.array_equal(f0.keypoints, g0.keypoints) and np.array_equal(m0, n0) and np.array_equal(conf, conf2)
+    assert g0.keypoints[:, 0].max() > 304 and p0.keypoints[:, 0].max() < 304      # the 1024-wide frame, not the original one
     strict = LightGlueMatcher({"state_dicts": sds, "reference_quirks": False})
     with pytest.raises(Exception):
         strict._match_images(a, b, max_keypoints=256, resize="not a size")
+
+    def device_error(*a_, **k_):
+        raise RuntimeError("im_superpoint_forward failed (-31): out of device memory")
+    m._match_images_resized = device_error
+    with pytest.raises(RuntimeError, match="-31"):
+        m._match_images(a, b, max_keypoints=256, resize=500)
 
 
 def test_preselection_selects_the_oracle_tile_pairs():

@@ -1,6 +1,7 @@
 """CPU-side tests (no GPU): the C-ABI library loads and exports every declared symbol, host logic of the matcher
 API (tiler, pyramid, geometric verification, timers), the sequence sharding + match-table all-gather on gloo
 (world_size 2), and the synthetic data generators."""
+import json
 import os
 import re
 import subprocess
@@ -727,3 +728,106 @@ def test_kernels_keep_their_register_budget(tmp_path):
         conv[field2("name")] = (int(field2("vgpr_count")), int(field2("vgpr_spill_count")), int(field2("private_segment_fixed_size")))
     assert len(conv) == 7, sorted(conv)     # pool / plain x fused / plain x U through registers / LDS, minus the unpooled fused register form
     assert all(v <= 256 and sp == 0 and scratch == 0 for v, sp, scratch in conv.values()), conv
+
+
+# ------------------------------------------------------------------------------------------- failure isolation
+FAKE_SEQUENCE = r'''
+import torch
+from icepy4d_amd import sequence as sq
+
+class FakeEngine:
+    """What SequenceMatcher needs of an engine, on the CPU: the "forward" reads the parked inputs and fails for poisoned pairs
+    (first pixel 255); the "record" step writes n_matches = first pixel of image 0."""
+    max_kpts = 8
+    device = torch.device("cpu")
+
+def fake_matcher(P, bad_group_once=False):
+    sm = sq.SequenceMatcher.__new__(sq.SequenceMatcher)
+    sm.e, sm.P, sm.use_graph, sm._graph = FakeEngine(), P, False, None
+    sm._inp = torch.zeros(2 * P, 4, 4, dtype=torch.uint8)
+    sm._rec = sq.new_table(P, 8, "cpu")
+    sm._pending, sm.failed, sm._pinned, sm._pin_i = [], [], None, 0
+    state = {"seen": None}
+    def enqueue(pairs):
+        if (pairs[0::2, 0, 0] == 255).any():
+            raise RuntimeError("im_superpoint_forward: injected failure (-31)")
+        state["seen"] = pairs.clone()
+    def record(table, row, epoch, n_pairs):
+        for j in range(n_pairs):
+            r = table[row + j]
+            r[0] = epoch + j; r[1] = 8; r[2] = 8; r[3] = int(state["seen"][2 * j, 0, 0]); r[4] = 9
+    sm._enqueue, sm._record = enqueue, record
+    return sm
+'''
+
+
+def test_sequence_matcher_isolates_a_failing_pair():
+    """A pair whose enqueue raises (library error code, wrong input shape) gets the record {epoch, n0 = n1 = 0, n_matches = -1}, the
+    other pairs of its launch group are re-run one by one and keep their results, the sequence goes on (`matchers.py:199-207`,
+    `main_dev.py:270-274`: the reference logs and continues), `failed` names the epoch and `pending_epochs` hands it to a resumed run."""
+    ns = {}
+    exec(FAKE_SEQUENCE, ns)
+    sq = ns["sq"]
+    for P in (1, 3):
+        sm = ns["fake_matcher"](P)
+        table = sq.new_table(7, 8, "cpu")
+        for ep in range(7):
+            pair = torch.full((2, 4, 4), ep + 1, dtype=torch.uint8)
+            if ep == 4:
+                pair[0, 0, 0] = 255                                   # the forward of this pair fails
+            if ep == 5 and P > 1:
+                pair = torch.zeros(2, 5, 5, dtype=torch.uint8)        # cannot even be parked in the launch group's input buffer: wrong shape
+            elif ep == 5:
+                pair[0, 0, 0] = 255                                   # (one pair per direct launch takes any shape the workspace holds)
+            sm.match_pair(pair, ep, table, ep)
+        sm.flush()
+        assert table[:, 0].tolist() == list(range(7))
+        assert table[:, 3].tolist() == [1, 2, 3, 4, -1, -1, 7], (P, table[:, 3].tolist())
+        assert table[4, 1:3].tolist() == [0, 0] and [e for e, _ in sm.failed] == ([4, 5] if P == 1 else [5, 4])
+        assert "injected failure" in dict(sm.failed)[4]
+        rec = table.numpy()
+        assert sq.pending_epochs(7, rec) == [4, 5]
+        assert sq.decode_record(rec[4], 8)["n_matches"] == -1 and len(sq.decode_record(rec[4], 8)["matches0"]) == 0
+
+
+ISOLATION_WORKER = FAKE_SEQUENCE + r'''
+import os, sys, torch.distributed as dist
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+n_epochs = 9
+mine = sq.shard_epochs(n_epochs, rank, world)
+sm = fake_matcher(2)
+t = sq.new_table(len(mine), 8, "cpu")
+for row, ep in enumerate(mine):
+    pair = torch.full((2, 4, 4), ep + 1, dtype=torch.uint8)
+    if ep == 3:
+        pair[0, 0, 0] = 255             # rank 1's second pair fails
+    sm.match_pair(pair, ep, t, row)
+sm.flush()
+full = sq.all_gather_tables(t)          # every rank arrives here, also the one with the failed pair
+assert full[:, 0].tolist() == list(range(n_epochs)), full[:, 0].tolist()
+assert full[:, 3].tolist() == [1, 2, 3, -1, 5, 6, 7, 8, 9], full[:, 3].tolist()
+assert sq.pending_epochs(n_epochs, full.numpy()) == [3]
+assert [e for e, _ in sm.failed] == ([3] if rank == 1 else [])
+dist.barrier(); dist.destroy_process_group()
+print("ok", rank)
+'''
+
+
+def test_failed_pair_on_one_rank_does_not_stall_the_all_gather_gloo_world2(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(ISOLATION_WORKER)
+    env = dict(os.environ, PYTHONPATH=ROOT, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29537", str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert r.stdout.count("ok") == 2
+
+
+def test_bench_dry_run_lists_failed_epochs_and_still_gathers():
+    """`bench.py --gpus 2 --dry-run --fail-epochs`: the line carries `failed_epochs`, the gathered table is complete and in order."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "5", "--warmup", "1",
+                        "--fail-epochs", "3,6"], capture_output=True, text=True, timeout=300, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["failed_epochs"] == [3, 6] and line["ranks"]["epochs_complete_and_sorted"] and line["ranks"]["epochs_in_gathered_table"] == 10
