@@ -155,302 +155,29 @@ __global__ __launch_bounds__(256) void sinkhorn_col_combine_kernel(const float2*
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// One Sinkhorn iteration with ONE read of the coupling matrix (the two-sweep form above reads it twice): a block walks its
-// rows one at a time; the row lives in REGISTERS (512 threads x 32 columns = 16384), so after the row's log-sum-exp has
-// produced u_i the same registers feed the column statistics of that row (online (max, sum) per column, carried in registers
-// over all rows of the block). The next row's loads are in flight while the current one is reduced. Per element: one
-// exponential for the row sum, two for the online column update (v_exp_f32: the sweep stays bound by HBM, 1.07 GB per
-// iteration at 16384 x 16384 instead of 2.15 GB). Per-block column partials are merged by sinkhorn_col_combine_kernel.
+// One Sinkhorn iteration with ONE read of the coupling matrix (the two-sweep form above reads it twice): a block walks its rows two at
+// a time; a row lives in REGISTERS (512 threads x 32 columns = 16384), so after the row's log-sum-exp has produced u_i the same
+// registers feed the column statistics. The kernels this form went through (round 2: one row per step with online column maxima, three
+// exponentials per element, 281 us per iteration at 16385^2; round 4: two rows per step in the log2 domain, 222 us; 1024-thread variants)
+// are kept as a record in tools/experiments/sinkhorn_retired_forms.hip.txt - they are not part of the library any more.
 static constexpr int SKF_T = 512, SKF_Q = 8, SKF_MAXN = SKF_T * 4 * SKF_Q;   // 16384 columns
 static constexpr float SKF_NEG = -3.0e38f;
-__device__ __forceinline__ float sk_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
-
-__global__ __launch_bounds__(SKF_T, 2) void sinkhorn_fused_kernel(const float* __restrict__ sim, int ld, const int* __restrict__ m_ptr,
-                                                                  const int* __restrict__ n_ptr, float alpha, const float* __restrict__ v,
-                                                                  float* __restrict__ u, float2* __restrict__ part, int pstride) {
-    extern __shared__ __attribute__((aligned(16))) float sk_lds[];     // v of this iteration: [SKF_MAXN] (64 KB), then red[2][8]
-    float4* sv = reinterpret_cast<float4*>(sk_lds);
-    float2* red = reinterpret_cast<float2*>(sk_lds + SKF_MAXN);
-    const int m = *m_ptr, n = *n_ptr;
-    if (m <= 0 || n <= 0 || (int)blockIdx.x > m) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int G = gridDim.x;
-    float cM[4 * SKF_Q], cS[4 * SKF_Q];
-#pragma unroll
-    for (int q = 0; q < SKF_Q; ++q) {
-        const int j = q * (SKF_T * 4) + tid * 4;
-        // masked columns carry v = -3e38: z + v stays hugely negative, exp() of it is 0
-        sv[q * SKF_T + tid] = make_float4(j < n ? v[j] : SKF_NEG, j + 1 < n ? v[j + 1] : SKF_NEG, j + 2 < n ? v[j + 2] : SKF_NEG,
-                                          j + 3 < n ? v[j + 3] : SKF_NEG);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { cM[4 * q + e] = SKF_NEG; cS[4 * q + e] = 0.f; }
-    }
-    const float v_bin = v[n];
-    float bM = SKF_NEG, bS = 0.f;                 // dustbin column (thread 0): alpha + u_i over this block's rows
-    const float norm = sg_norm(m, n);
-    float4 ra[SKF_Q], rb[SKF_Q];
-    // (each thread reads back only the v entries it wrote: no barrier needed for sv)
-
-    auto load_row = [&](int row, float4 (&buf)[SKF_Q]) {
-        const float* p = sim + (long)row * ld;
-#pragma unroll
-        for (int q = 0; q < SKF_Q; ++q) {
-            const int j = q * (SKF_T * 4) + tid * 4;
-            float4 x = make_float4(alpha, alpha, alpha, alpha);        // the dustbin row is a row of alpha
-            if (row < m) {
-                x = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (j + 3 < n) x = *reinterpret_cast<const float4*>(p + j);
-                else {
-                    if (j < n) x.x = p[j];
-                    if (j + 1 < n) x.y = p[j + 1];
-                    if (j + 2 < n) x.z = p[j + 2];
-                }
-            }
-            buf[q] = x;
-        }
-    };
-    auto step = [&](int i, const float4 (&buf)[SKF_Q], int parity) {
-        const bool bin_row = i == m;
-        // ---- u_i = log_mu - logsumexp_j(z + v): lane-local (max, sum), wave, block
-        float mx = SKF_NEG;
-#pragma unroll
-        for (int q = 0; q < SKF_Q; ++q) {
-            const float4 w = sv[q * SKF_T + tid];
-            mx = fmaxf(fmaxf(mx, fmaxf(buf[q].x + w.x, buf[q].y + w.y)), fmaxf(buf[q].z + w.z, buf[q].w + w.w));
-        }
-        if (tid == 0) mx = fmaxf(mx, alpha + v_bin);
-        float sm = 0.f;
-#pragma unroll
-        for (int q = 0; q < SKF_Q; ++q) {
-            const float4 w = sv[q * SKF_T + tid];
-            sm += (sk_exp((buf[q].x + w.x) - mx) + sk_exp((buf[q].y + w.y) - mx)) + (sk_exp((buf[q].z + w.z) - mx) + sk_exp((buf[q].w + w.w) - mx));
-        }
-        if (tid == 0) sm += sk_exp((alpha + v_bin) - mx);
-        const float wM = wave_max(mx);
-        const float wS = wave_sum(sm * sk_exp(mx - wM));
-        if (lane == 0) red[parity * (SKF_T / 64) + wave] = make_float2(wM, wS);
-        __syncthreads();
-        float M = red[parity * (SKF_T / 64)].x;
-#pragma unroll
-        for (int w = 1; w < SKF_T / 64; ++w) M = fmaxf(M, red[parity * (SKF_T / 64) + w].x);
-        float S = 0.f;
-#pragma unroll
-        for (int w = 0; w < SKF_T / 64; ++w) S += red[parity * (SKF_T / 64) + w].y * sk_exp(red[parity * (SKF_T / 64) + w].x - M);
-        const float log_mu = bin_row ? logf((float)n) + norm : norm;
-        const float ui = log_mu - (logf(S) + M);
-        if (tid == 0) u[i] = ui;
-        // ---- column statistics of this row with the fresh u_i (the dustbin ROW is added by the combine kernel)
-        if (!bin_row) {
-#pragma unroll
-            for (int q = 0; q < SKF_Q; ++q) {
-                const float zz[4] = {buf[q].x, buf[q].y, buf[q].z, buf[q].w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float y = zz[e] + ui;
-                    const float nm = fmaxf(cM[4 * q + e], y);
-                    cS[4 * q + e] = cS[4 * q + e] * sk_exp(cM[4 * q + e] - nm) + sk_exp(y - nm);
-                    cM[4 * q + e] = nm;
-                }
-            }
-            if (tid == 0) {
-                const float y = alpha + ui;
-                const float nm = fmaxf(bM, y);
-                bS = bS * sk_exp(bM - nm) + sk_exp(y - nm);
-                bM = nm;
-            }
-        }
-    };
-
-    int i = blockIdx.x;
-    load_row(i, ra);
-    for (;;) {
-        if (i + G <= m) load_row(i + G, rb);
-        step(i, ra, 0);
-        i += G;
-        if (i > m) break;
-        if (i + G <= m) load_row(i + G, ra);
-        step(i, rb, 1);
-        i += G;
-        if (i > m) break;
-    }
-    float2* pp = part + (long)blockIdx.x * pstride;
-#pragma unroll
-    for (int q = 0; q < SKF_Q; ++q)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int j = q * (SKF_T * 4) + tid * 4 + e;
-            if (j < n) pp[j] = make_float2(cM[4 * q + e], cS[4 * q + e]);
-        }
-    if (tid == 0) pp[n] = make_float2(bM, bS);
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// Round 4, first step (IM_SINKHORN_FORM=2; the default is sinkhorn_fused4_kernel below, IM_SINKHORN_FORM=1 keeps the kernel above): the same
-// one read of the couplings per iteration, written for FEWER vector instructions per element and more waves per SIMD - the
-// kernel above issues ~26 VALU slots per element (three exponentials at a quarter of the rate each), which at 16384^2 is more
-// time than the 1.07 GB take to arrive:
-//   * TWO rows per step: both rows' log-sum-exps are reduced behind ONE block barrier, and the column statistics take both rows
-//     in one online update - max3(cM, yA, yB), one rescale of the running sum per two elements instead of per element: 1.75
-//     exponentials per element instead of 3;
-//   * everything in the log2 domain (v, u, the running column maxima pre-multiplied by log2 e once): z enters through one fma,
-//     the exponentials are bare v_exp_f32;
-//   * the cross-wave merge of a row's (max, sum) is a lane-indexed read + wave shuffles instead of one exponential per wave and
-//     thread;
-//   * 1024 threads x 16 columns (4 float4) instead of 512 x 32: four rows in flight (two being reduced, two loading) fit in
-//     ~128 registers, so 16 waves per CU cover the load latency.
-// Same arithmetic as above up to the order of the fp32 additions (parity tests: <= 1e-4 against the oracle at 16385^2).
 static constexpr float SK_L2E = 1.4426950408889634f, SK_LN2 = 0.6931471805599453f;
 
 // keeps the instruction scheduler from interleaving the unrolled column groups of a pass (it would hold the temporaries of all of
 // them at once: 290 registers wanted, 80 spilled); a group's dozen instructions are enough to cover the LDS read they start with
 #define IM_SK_FENCE() __builtin_amdgcn_sched_barrier(0)
-template <int SK2_T, int SK2_Q>     // SK2_T x SK2_Q float4 = 16384 columns
-__global__ __launch_bounds__(SK2_T, 1) void sinkhorn_fused2_kernel(const float* __restrict__ sim, int ld, const int* __restrict__ m_ptr,
-                                                                   const int* __restrict__ n_ptr, float alpha, const float* __restrict__ v,
-                                                                   float* __restrict__ u, float2* __restrict__ part, int pstride) {
-    static_assert(SK2_T * SK2_Q * 4 == SKF_MAXN, "columns");
-    constexpr int SK2_W = SK2_T / 64;
-    extern __shared__ __attribute__((aligned(16))) float sk_lds[];     // v * log2(e) of this iteration [SKF_MAXN] (64 KB), then red[2][waves] float4
-    float4* sv = reinterpret_cast<float4*>(sk_lds);
-    float4* red = reinterpret_cast<float4*>(sk_lds + SKF_MAXN);
-    const int m = *m_ptr, n = *n_ptr;
-    if (m <= 0 || n <= 0 || (int)blockIdx.x > m) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int G = gridDim.x;
-    float cM[4 * SK2_Q], cS[4 * SK2_Q];
-#pragma unroll
-    for (int q = 0; q < SK2_Q; ++q) {
-        const int j = q * (SK2_T * 4) + tid * 4;
-        // masked columns carry v = -3e38: z + v stays hugely negative, its exponential is 0
-        sv[q * SK2_T + tid] = make_float4(j < n ? v[j] * SK_L2E : SKF_NEG, j + 1 < n ? v[j + 1] * SK_L2E : SKF_NEG,
-                                          j + 2 < n ? v[j + 2] * SK_L2E : SKF_NEG, j + 3 < n ? v[j + 3] * SK_L2E : SKF_NEG);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { cM[4 * q + e] = SKF_NEG; cS[4 * q + e] = 0.f; }
-    }
-    const float bin2 = (alpha + v[n]) * SK_L2E;      // dustbin column of a row, log2 domain
-    float bM = SKF_NEG, bS = 0.f;                    // its column statistics (thread 0): alpha + u_i over this block's rows
-    const float norm = sg_norm(m, n);
-    float4 ra[SK2_Q], rb[SK2_Q], rc[SK2_Q], rd[SK2_Q];
-    // (each thread reads back only the v entries it wrote: no barrier needed for sv)
-
-    // A row through a buffer descriptor that covers exactly its n live floats: lanes past the row end read zero (per-dword range
-    // check), the lane offset is fixed for the whole kernel, the part of a row a float4 group starts at is a scalar offset - no
-    // address arithmetic or masks on the VALU, one address register in all
-    const unsigned voff = (unsigned)tid * 16u;
-    auto load_row = [&](int row, float4 (&buf)[SK2_Q]) {
-        if (row >= m) {                                                // the dustbin row is a row of alpha
-#pragma unroll
-            for (int q = 0; q < SK2_Q; ++q) buf[q] = make_float4(alpha, alpha, alpha, alpha);
-            return;
-        }
-        const __amdgpu_buffer_rsrc_t rs = gmake_rsrc(sim + (long)row * ld, (unsigned)n * 4u);
-#pragma unroll
-        for (int q = 0; q < SK2_Q; ++q) buf[q] = gbuf_load4(rs, voff, (unsigned)q * (SK2_T * 16u));
-    };
-    // rows iA and iB = iA + G (iB > m: absent) from A and B
-    auto step = [&](int iA, const float4 (&A)[SK2_Q], const float4 (&B)[SK2_Q], int parity) {
-        const int iB = iA + G;
-        const bool hasB = iB <= m;
-        // ---- row maxima of (z + v) log2(e), lane-local
-        float mA = SKF_NEG, mB = SKF_NEG;
-#pragma unroll
-        for (int q = 0; q < SK2_Q; ++q) {
-            const float4 w = sv[q * SK2_T + tid];
-            mA = fmaxf(fmaxf(mA, fmaxf(fmaf(A[q].x, SK_L2E, w.x), fmaf(A[q].y, SK_L2E, w.y))), fmaxf(fmaf(A[q].z, SK_L2E, w.z), fmaf(A[q].w, SK_L2E, w.w)));
-            mB = fmaxf(fmaxf(mB, fmaxf(fmaf(B[q].x, SK_L2E, w.x), fmaf(B[q].y, SK_L2E, w.y))), fmaxf(fmaf(B[q].z, SK_L2E, w.z), fmaf(B[q].w, SK_L2E, w.w)));
-            IM_SK_FENCE();
-        }
-        if (tid == 0) { mA = fmaxf(mA, bin2); mB = fmaxf(mB, bin2); }
-        float sA = 0.f, sB = 0.f;
-#pragma unroll
-        for (int q = 0; q < SK2_Q; ++q) {
-            const float4 w = sv[q * SK2_T + tid];
-            const float4 wa = make_float4(w.x - mA, w.y - mA, w.z - mA, w.w - mA), wb = make_float4(w.x - mB, w.y - mB, w.z - mB, w.w - mB);
-            sA += (__builtin_amdgcn_exp2f(fmaf(A[q].x, SK_L2E, wa.x)) + __builtin_amdgcn_exp2f(fmaf(A[q].y, SK_L2E, wa.y))) +
-                  (__builtin_amdgcn_exp2f(fmaf(A[q].z, SK_L2E, wa.z)) + __builtin_amdgcn_exp2f(fmaf(A[q].w, SK_L2E, wa.w)));
-            sB += (__builtin_amdgcn_exp2f(fmaf(B[q].x, SK_L2E, wb.x)) + __builtin_amdgcn_exp2f(fmaf(B[q].y, SK_L2E, wb.y))) +
-                  (__builtin_amdgcn_exp2f(fmaf(B[q].z, SK_L2E, wb.z)) + __builtin_amdgcn_exp2f(fmaf(B[q].w, SK_L2E, wb.w)));
-            IM_SK_FENCE();
-        }
-        if (tid == 0) { sA += __builtin_amdgcn_exp2f(bin2 - mA); sB += __builtin_amdgcn_exp2f(bin2 - mB); }
-        // ---- wave, then block: one barrier for both rows; the 16 per-wave (max, sum) pairs are merged by lane-indexed reads + shuffles
-        const float wMA = wave_max(mA), wMB = wave_max(mB);
-        const float wSA = wave_sum(sA * __builtin_amdgcn_exp2f(mA - wMA)), wSB = wave_sum(sB * __builtin_amdgcn_exp2f(mB - wMB));
-        if (lane == 0) red[parity * SK2_W + wave] = make_float4(wMA, wSA, wMB, wSB);
-        __syncthreads();
-        const float4 r = red[parity * SK2_W + (lane & (SK2_W - 1))];
-        float MA = r.x, MB = r.z;
-#pragma unroll
-        for (int o = SK2_W / 2; o > 0; o >>= 1) { MA = fmaxf(MA, __shfl_xor(MA, o)); MB = fmaxf(MB, __shfl_xor(MB, o)); }
-        float SA = r.y * __builtin_amdgcn_exp2f(r.x - MA), SB = r.w * __builtin_amdgcn_exp2f(r.z - MB);
-#pragma unroll
-        for (int o = SK2_W / 2; o > 0; o >>= 1) { SA += __shfl_xor(SA, o); SB += __shfl_xor(SB, o); }
-        // u_i = log_mu - logsumexp_j(z + v), natural domain for the output, log2 domain for the column pass
-        const float uA = ((iA == m) ? logf((float)n) + norm : norm) - (__builtin_amdgcn_logf(SA) + MA) * SK_LN2;
-        const float uB = ((iB == m) ? logf((float)n) + norm : norm) - (__builtin_amdgcn_logf(SB) + MB) * SK_LN2;
-        if (tid == 0) {
-            u[iA] = uA;
-            if (hasB) u[iB] = uB;
-        }
-        // ---- column statistics with the fresh u of both rows (the dustbin ROW is added by the combine kernel; an absent row
-        // contributes nothing): y = (z + u) log2(e), running (max, sum of 2^(y - max)) per column
-        const bool useA = iA < m, useB = iB < m;
-        const float uA2 = uA * SK_L2E, uB2 = uB * SK_L2E;
-#pragma unroll
-        for (int q = 0; q < SK2_Q; ++q) {
-            const float za[4] = {A[q].x, A[q].y, A[q].z, A[q].w}, zb[4] = {B[q].x, B[q].y, B[q].z, B[q].w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float ya = useA ? fmaf(za[e], SK_L2E, uA2) : SKF_NEG, yb = useB ? fmaf(zb[e], SK_L2E, uB2) : SKF_NEG;
-                const float nm = fmaxf(fmaxf(cM[4 * q + e], ya), yb);
-                cS[4 * q + e] = fmaf(cS[4 * q + e], __builtin_amdgcn_exp2f(cM[4 * q + e] - nm), __builtin_amdgcn_exp2f(ya - nm) + __builtin_amdgcn_exp2f(yb - nm));
-                cM[4 * q + e] = nm;
-            }
-            IM_SK_FENCE();
-        }
-        if (tid == 0) {
-            const float ya = useA ? (alpha + uA) * SK_L2E : SKF_NEG, yb = useB ? (alpha + uB) * SK_L2E : SKF_NEG;
-            const float nm = fmaxf(fmaxf(bM, ya), yb);
-            bS = fmaf(bS, __builtin_amdgcn_exp2f(bM - nm), __builtin_amdgcn_exp2f(ya - nm) + __builtin_amdgcn_exp2f(yb - nm));
-            bM = nm;
-        }
-    };
-
-    int i = blockIdx.x;
-    load_row(i, ra);
-    load_row(min(i + G, m), rb);                     // an absent second row re-reads a valid one; `step` ignores it
-    for (;;) {
-        const bool more = i + 2 * G <= m;
-        if (more) { load_row(i + 2 * G, rc); load_row(min(i + 3 * G, m), rd); }
-        step(i, ra, rb, 0);
-        i += 2 * G;
-        if (!more) break;
-        const bool more2 = i + 2 * G <= m;
-        if (more2) { load_row(i + 2 * G, ra); load_row(min(i + 3 * G, m), rb); }
-        step(i, rc, rd, 1);
-        i += 2 * G;
-        if (!more2) break;
-    }
-    float2* pp = part + (long)blockIdx.x * pstride;   // natural-log domain, as sinkhorn_fused_combine_kernel expects
-#pragma unroll
-    for (int q = 0; q < SK2_Q; ++q)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int j = q * (SK2_T * 4) + tid * 4 + e;
-            if (j < n) pp[j] = make_float2(cM[4 * q + e] * SK_LN2, cS[4 * q + e]);
-        }
-    if (tid == 0) pp[n] = make_float2(bM * SK_LN2, bS);
-}
 
 // ---------------------------------------------------------------------------------------------------------
-// The default form since the end of round 4 (IM_SINKHORN_FORM=2 keeps the two-row online-maximum kernel above for A/B): ONE exponential per element.
+// ONE exponential per element (round 4).
 // With u_i fresh from the row pass, exp(z_ij + u_i + v_j - norm) is the row-softmax value the row pass has just computed,
 //     p_ij = exp((z_ij + v_j) - M_i) / S_i,          e^(z_ij + u_i + v_j) = mu_i p_ij,
 // so the column update needs no exponential of its own:  logsumexp_i(z_ij + u_i) = -v_j + norm + log C_j,  C_j = sum_i w_i p_ij  (w = 1, n for the
 // dustbin row), hence     v_j <- v_j - log C_j   (+ log m for the dustbin column).   All terms are <= 1: no running maximum, no rescale.
 // The one thing the online-max form gives for free is lost: when every p_ij of a column underflows (all rows put less than 1e-38 there under the PREVIOUS v)
-// C_j is 0. Such columns are listed by the combine kernel (C_j < 1e-30) and recomputed exactly, by a strided column read, in a repair kernel that
-// exits at once when the list is empty (every launch; the list is double-buffered over iterations).
+// C_j is 0. Such columns are listed by the combine kernel (C_j < 1e-30) and recomputed exactly, by a strided column read, by the LAST combine block to
+// finish (an integer ticket, as in the attention kernel's split-KV merge) - two launches per iteration; round 4 had a third, a repair kernel that
+// found an empty list on practically every launch.
 template <int SK4_T, int SK4_Q>
 __global__ __launch_bounds__(SK4_T, 1) void sinkhorn_fused4_kernel(const float* __restrict__ sim, int ld, const int* __restrict__ m_ptr,
                                                                    const int* __restrict__ n_ptr, float alpha, const float* __restrict__ v,
@@ -569,15 +296,18 @@ __global__ __launch_bounds__(SK4_T, 1) void sinkhorn_fused4_kernel(const float* 
     if (tid == 0) pp[n] = bS;
 }
 
-// v_j <- v_j - log C_j (+ log m for the dustbin column) from the per-block column sums; columns whose sum underflowed go on the repair list
+// v_j <- v_j - log C_j (+ log m for the dustbin column) from the per-block column sums; columns whose sum underflowed go on the repair list,
+// which the last block to arrive (integer ticket, self-resetting) works off: exact v_j = log_nu_j - logsumexp_i(z_ij + u_i) by a strided column
+// read, one listed column at a time - nothing to do, normally. u is complete (the sweep kernel has finished), every v_j has one writer.
 __global__ __launch_bounds__(256) void sinkhorn_fused4_combine_kernel(const float* __restrict__ csum, int pstride, int n_parts,
                                                                        const int* __restrict__ m_ptr, const int* __restrict__ n_ptr, float* __restrict__ v,
-                                                                       float* __restrict__ norm_out, int* __restrict__ list, int* __restrict__ cnt_this,
-                                                                       int* __restrict__ cnt_next, float c_min) {
+                                                                       float* __restrict__ norm_out, int* list, int* cnt, int* ticket, float c_min,
+                                                                       const float* __restrict__ sim, int ld, float alpha, const float* __restrict__ u) {
     __shared__ float red[8][32];
+    __shared__ float2 red2[4];
+    __shared__ int s_last;
     const int m = *m_ptr, n = *n_ptr;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *cnt_next = 0;      // the other iteration's counter: nobody uses it during this one
-    if (m <= 0 || n <= 0 || (int)blockIdx.x * 32 > n) return;
+    if (m <= 0 || n <= 0 || (int)blockIdx.x * 32 > n) return;     // n / 32 + 1 blocks take part (and a ticket)
     const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
     const int j = blockIdx.x * 32 + c;
     const int ns = min(n_parts, m + 1);
@@ -591,78 +321,37 @@ __global__ __launch_bounds__(256) void sinkhorn_fused4_combine_kernel(const floa
 #pragma unroll
         for (int k = 0; k < 8; ++k) C += red[k][c];
         if (C > c_min) v[j] = v[j] - logf(C) + (j == n ? logf((float)m) : 0.f);
-        else list[atomicAdd(cnt_this, 1)] = j;                  // order does not matter: the repair kernel recomputes each entry on its own
+        else list[atomicAdd(cnt, 1)] = j;                       // order does not matter: each entry is recomputed on its own
         if (j == 0) *norm_out = sg_norm(m, n);
     }
-}
-
-// exact v_j = log_nu_j - logsumexp_i(z_ij + u_i) for the listed columns (one block per entry, strided column read); nothing to do, normally
-__global__ __launch_bounds__(256) void sinkhorn_fused4_repair_kernel(const float* __restrict__ sim, int ld, const int* __restrict__ m_ptr,
-                                                                      const int* __restrict__ n_ptr, float alpha, const float* __restrict__ u,
-                                                                      float* __restrict__ v, const int* __restrict__ list, const int* __restrict__ cnt) {
-    __shared__ float2 red[4];
-    const int count = *cnt;
-    const int m = *m_ptr, n = *n_ptr;
-    for (int idx = blockIdx.x; idx < count; idx += gridDim.x) {
-        const int j = list[idx];
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int old = atomicAdd(ticket, 1);
+        s_last = old == n / 32;
+        if (s_last) *ticket = 0;                                 // ready for the next launch
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    const int count = *reinterpret_cast<volatile int*>(cnt);
+    for (int idx = 0; idx < count; ++idx) {
+        const int jr = reinterpret_cast<volatile int*>(list)[idx];
         OnlineLSE t;
-        for (int i = threadIdx.x; i <= m; i += 256) t.add(((i < m && j < n) ? sim[(long)i * ld + j] : alpha) + u[i]);
+        for (int i = threadIdx.x; i <= m; i += 256) t.add(((i < m && jr < n) ? sim[(long)i * ld + jr] : alpha) + u[i]);
         const float wm = wave_max(t.m);
         const float wsum = wave_sum(wm == -INFINITY ? 0.f : t.s * expf(t.m - wm));
         __syncthreads();
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = make_float2(wm, wsum);
+        if ((threadIdx.x & 63) == 0) red2[threadIdx.x >> 6] = make_float2(wm, wsum);
         __syncthreads();
         if (threadIdx.x == 0) {
             OnlineLSE a;
-            for (int w = 0; w < 4; ++w) a.merge(red[w].x, red[w].y);
+            for (int w = 0; w < 4; ++w) a.merge(red2[w].x, red2[w].y);
             const float norm = sg_norm(m, n);
-            v[j] = ((j == n) ? logf((float)m) + norm : norm) - (logf(a.s) + a.m);
+            v[jr] = ((jr == n) ? logf((float)m) + norm : norm) - (logf(a.s) + a.m);
         }
     }
-}
-
-// v from the per-block column partials of sinkhorn_fused_kernel: 32 columns x 8 partial groups per block
-__global__ __launch_bounds__(256) void sinkhorn_fused_combine_kernel(const float2* __restrict__ part, int pstride, int n_parts,
-                                                                      const int* __restrict__ m_ptr, const int* __restrict__ n_ptr,
-                                                                      float alpha, const float* __restrict__ u, float* __restrict__ v,
-                                                                      float* __restrict__ norm_out) {
-    __shared__ float2 red[8][32];
-    const int m = *m_ptr, n = *n_ptr;
-    if (m <= 0 || n <= 0 || (int)blockIdx.x * 32 > n) return;
-    const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
-    const int j = blockIdx.x * 32 + c;
-    const int ns = min(n_parts, m + 1);
-    float M = SKF_NEG, S = 0.f;
-    if (j <= n)
-        for (int s0 = g; s0 < ns; s0 += 64) {
-            float2 p[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) p[k] = (s0 + 8 * k < ns) ? part[(long)(s0 + 8 * k) * pstride + j] : make_float2(SKF_NEG, 0.f);
-            float mx = p[0].x;
-#pragma unroll
-            for (int k = 1; k < 8; ++k) mx = fmaxf(mx, p[k].x);
-            const float nm = fmaxf(M, mx);
-            float acc = 0.f;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) acc += p[k].y * sk_exp(p[k].x - nm);
-            S = S * sk_exp(M - nm) + acc;
-            M = nm;
-        }
-    red[g][c] = make_float2(M, S);
-    __syncthreads();
-    if (g == 0 && j <= n) {
-        const float bin = alpha + u[m];                 // dustbin row
-        float Mx = bin;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) Mx = fmaxf(Mx, red[k][c].x);
-        float Sx = sk_exp(bin - Mx);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) Sx += red[k][c].y * sk_exp(red[k][c].x - Mx);
-        const float norm = sg_norm(m, n);
-        const float log_nu = (j == n) ? logf((float)m) + norm : norm;
-        v[j] = log_nu - (logf(Sx) + Mx);
-        if (j == 0) *norm_out = norm;
-    }
+    if (threadIdx.x == 0) *cnt = 0;                              // the list is empty again for the next iteration
 }
 
 // full (m+1) x (n+1) transport matrix, only for the stage entry point / tests
@@ -687,52 +376,25 @@ static int sinkhorn(im_ctx* ctx, hipStream_t s, const float* sim, int ld, const 
     const int nstrips = (m_max + SK_STRIP - 1) / SK_STRIP;
     const int pstride = n_max + 1;
     // single-read form: needs the row in the registers of one block (n <= 16384), 16-byte aligned rows, and as many partial
-    // strips as blocks (the workspace holds (K + 15) / 16 + 1 of them)
-    static const bool two_sweep = getenv("IM_SINKHORN_TWO_SWEEP") && getenv("IM_SINKHORN_TWO_SWEEP")[0] == '1';   // A/B switch
+    // strips as blocks (the workspace holds (K + 15) / 16 + 1 of them). Otherwise (and with IM_SINKHORN_TWO_SWEEP=1, the A/B switch):
+    // round 1's row sweep + column sweep, two reads of the couplings per iteration, any size.
+    static const bool two_sweep = getenv("IM_SINKHORN_TWO_SWEEP") && getenv("IM_SINKHORN_TWO_SWEEP")[0] == '1';
     const int max_parts = (ctx->max_kpts + 15) / 16;
     if (!two_sweep && n_max <= SKF_MAXN && (ld % 4) == 0 && (reinterpret_cast<uintptr_t>(sim) % 16) == 0 && max_parts >= 1 && iters > 0) {
-        // IM_SINKHORN_FORM=1: the round-2 kernel (one row per step, 512 threads); default: two rows per step, 1024 threads
-        static const bool form1 = getenv("IM_SINKHORN_FORM") && getenv("IM_SINKHORN_FORM")[0] == '1';
-        static const bool wide = getenv("IM_SINKHORN_FORM") && getenv("IM_SINKHORN_FORM")[0] == '3';   // 1024 threads x 16 columns
-        static const int blocks_env = getenv("IM_SINKHORN_BLOCKS") ? atoi(getenv("IM_SINKHORN_BLOCKS")) : 0;   // tuning knob
-        // default: form 4 (one exponential per element + repair list, see sinkhorn_fused4_kernel). IM_SINKHORN_FORM = 4w: the same on 1024
-        // threads x 16 columns; 2: the two-row online-maximum kernel; 3: that on 1024 threads; 1: the round-2 one-row kernel
-        static const char* const form_env = getenv("IM_SINKHORN_FORM");
-        static const int form4 = (!form_env || !form_env[0] || form_env[0] == '4') ? ((form_env && form_env[0] == '4' && form_env[1] == 'w') ? 2 : 1) : 0;
-        if (form4) {
-            const int G4 = std::min(std::min(blocks_env > 0 ? blocks_env : 256, 2 * max_parts), m_max + 1);
-            const size_t lds4 = (SKF_MAXN + 2 * 16 * 4) * sizeof(float);
-            static size_t lo4[IM_MAX_DEVICES] = {0}, lo4w[IM_MAX_DEVICES] = {0};
-            if (form4 == 2) IM_HIP(ctx, ensure_dyn_lds(reinterpret_cast<const void*>(&sinkhorn_fused4_kernel<1024, 4>), lds4, lo4w));
-            else IM_HIP(ctx, ensure_dyn_lds(reinterpret_cast<const void*>(&sinkhorn_fused4_kernel<512, 8>), lds4, lo4));
-            float* csum = reinterpret_cast<float*>(ws->part);       // [G4][pstride] floats in the partials buffer (room for 2 x max_parts rows)
-            int* list = ws->ridx;                                   // free until the assignment stage: [0 .. n] column list, then the two counters
-            int* cnt = ws->ridx + (ctx->max_kpts + 1);
-            IM_HIP(ctx, launch_zero_words(cnt, 2, s));
-            // IM_SINKHORN_REPAIR_ALL=1 (tests): every column goes through the exact repair kernel
-            static const float c_min = (getenv("IM_SINKHORN_REPAIR_ALL") && getenv("IM_SINKHORN_REPAIR_ALL")[0] == '1') ? 3.0e38f : 1e-30f;
-            for (int it = 0; it < iters; ++it) {
-                if (form4 == 2) hipLaunchKernelGGL((sinkhorn_fused4_kernel<1024, 4>), dim3(G4), dim3(1024), lds4, s, sim, ld, m_ptr, n_ptr, alpha, v, u, csum, pstride);
-                else hipLaunchKernelGGL((sinkhorn_fused4_kernel<512, 8>), dim3(G4), dim3(512), lds4, s, sim, ld, m_ptr, n_ptr, alpha, v, u, csum, pstride);
-                hipLaunchKernelGGL(sinkhorn_fused4_combine_kernel, dim3((n_max + 1 + 31) / 32), dim3(256), 0, s, csum, pstride, G4, m_ptr, n_ptr, v, norm_out,
-                                   list, cnt + (it & 1), cnt + ((it + 1) & 1), c_min);
-                hipLaunchKernelGGL(sinkhorn_fused4_repair_kernel, dim3(64), dim3(256), 0, s, sim, ld, m_ptr, n_ptr, alpha, u, v, list, cnt + (it & 1));
-            }
-            IM_HIP(ctx, hipGetLastError());
-            return 0;
-        }
-        const int G = std::min(std::min(blocks_env > 0 ? blocks_env : 256, max_parts), m_max + 1);
-        const size_t skf_lds = form1 ? (SKF_MAXN + 2 * 2 * (SKF_T / 64)) * sizeof(float) : (SKF_MAXN + 2 * 16 * 4) * sizeof(float);
-        static size_t lds_optin[IM_MAX_DEVICES] = {0}, lds_optin2[IM_MAX_DEVICES] = {0}, lds_optin3[IM_MAX_DEVICES] = {0};
-        if (form1) IM_HIP(ctx, ensure_dyn_lds(reinterpret_cast<const void*>(&sinkhorn_fused_kernel), skf_lds, lds_optin));
-        else if (wide) IM_HIP(ctx, ensure_dyn_lds(reinterpret_cast<const void*>(&sinkhorn_fused2_kernel<1024, 4>), skf_lds, lds_optin3));
-        else IM_HIP(ctx, ensure_dyn_lds(reinterpret_cast<const void*>(&sinkhorn_fused2_kernel<512, 8>), skf_lds, lds_optin2));
+        const int G4 = std::min(std::min(256, 2 * max_parts), m_max + 1);
+        const size_t lds4 = (SKF_MAXN + 2 * 16 * 4) * sizeof(float);
+        static size_t lo4[IM_MAX_DEVICES] = {0};
+        IM_HIP(ctx, ensure_dyn_lds(reinterpret_cast<const void*>(&sinkhorn_fused4_kernel<512, 8>), lds4, lo4));
+        float* csum = reinterpret_cast<float*>(ws->part);       // [G4][pstride] floats in the partials buffer (room for 2 x max_parts rows)
+        int* list = ws->ridx;                                   // free until the assignment stage: [0 .. n] column list, then counter and ticket
+        int* cnt = ws->ridx + (ctx->max_kpts + 1);
+        IM_HIP(ctx, launch_zero_words(cnt, 2, s));
+        // IM_SINKHORN_REPAIR_ALL=1 (tests): every column goes through the exact repair path
+        static const float c_min = (getenv("IM_SINKHORN_REPAIR_ALL") && getenv("IM_SINKHORN_REPAIR_ALL")[0] == '1') ? 3.0e38f : 1e-30f;
         for (int it = 0; it < iters; ++it) {
-            if (form1) hipLaunchKernelGGL(sinkhorn_fused_kernel, dim3(G), dim3(SKF_T), skf_lds, s, sim, ld, m_ptr, n_ptr, alpha, v, u, ws->part, pstride);
-            else if (wide) hipLaunchKernelGGL((sinkhorn_fused2_kernel<1024, 4>), dim3(G), dim3(1024), skf_lds, s, sim, ld, m_ptr, n_ptr, alpha, v, u, ws->part, pstride);
-            else hipLaunchKernelGGL((sinkhorn_fused2_kernel<512, 8>), dim3(G), dim3(512), skf_lds, s, sim, ld, m_ptr, n_ptr, alpha, v, u, ws->part, pstride);
-            hipLaunchKernelGGL(sinkhorn_fused_combine_kernel, dim3((n_max + 1 + 31) / 32), dim3(256), 0, s, ws->part, pstride, G, m_ptr, n_ptr,
-                               alpha, u, v, norm_out);
+            hipLaunchKernelGGL((sinkhorn_fused4_kernel<512, 8>), dim3(G4), dim3(512), lds4, s, sim, ld, m_ptr, n_ptr, alpha, v, u, csum, pstride);
+            hipLaunchKernelGGL(sinkhorn_fused4_combine_kernel, dim3((n_max + 1 + 31) / 32), dim3(256), 0, s, csum, pstride, G4, m_ptr, n_ptr, v, norm_out,
+                               list, cnt, cnt + 1, c_min, sim, ld, alpha, u);
         }
         IM_HIP(ctx, hipGetLastError());
         return 0;

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Sinkhorn solve (`im_log_optimal_transport`, 20 iterations) at n x n couplings for the kernel forms and block counts the library
+"""Sinkhorn solve (`im_log_optimal_transport`, 20 iterations) at n x n couplings for the kernel paths the library
 can be switched to (environment read once per process, so every setting runs in a child process). Times the stage entry point with
 HIP events over `reps` solves (the final materialisation of the (n+1)^2 output included: one more read + write of the matrix, so the
 per-iteration figure is (t_20 - t_0) / 20 from a second run with 0 iterations), and checks every form against the first one.
@@ -13,16 +13,8 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SETTINGS = [("form 1 (round 2: one row per step, 512 threads), 256 blocks", {"IM_SINKHORN_FORM": "1"}),
-            ("form 1, 512 blocks", {"IM_SINKHORN_FORM": "1", "IM_SINKHORN_BLOCKS": "512"}),
-            ("form 2 (two rows per step, online column maxima, 512 threads), 256 blocks", {"IM_SINKHORN_FORM": "2"}),
-            ("form 2, 512 blocks", {"IM_SINKHORN_FORM": "2", "IM_SINKHORN_BLOCKS": "512"}),
-            ("form 2, 128 blocks", {"IM_SINKHORN_FORM": "2", "IM_SINKHORN_BLOCKS": "128"}),
-            ("form 3 (two rows per step, 1024 threads), 256 blocks", {"IM_SINKHORN_FORM": "3"}),
-            ("form 4 = DEFAULT (one exponential per element + repair list, 512 threads), 256 blocks", {}),
-            ("form 4, 512 blocks", {"IM_SINKHORN_BLOCKS": "512"}),
-            ("form 4w (1024 threads x 16 columns), 256 blocks", {"IM_SINKHORN_FORM": "4w"}),
-            ("two sweeps (round 1)", {"IM_SINKHORN_TWO_SWEEP": "1"})]
+SETTINGS = [("default (one exponential per element, repair folded into the combine kernel: 2 launches per iteration)", {}),
+            ("two sweeps (round 1; the fallback for n > 16384 / unaligned rows)", {"IM_SINKHORN_TWO_SWEEP": "1"})]
 
 
 def child(n, reps):
