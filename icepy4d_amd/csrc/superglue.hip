@@ -285,50 +285,82 @@ __global__ __launch_bounds__(SK4_T, 1) void sinkhorn_fused4_kernel(const float* 
         i += 2 * G;
         if (!more2) break;
     }
+    // column partials of this block: whole 16-byte quads (pstride % 4 == 0), streamed past L2 (the combine kernel is the only reader, on
+    // other CUs; 16.8 MB of dirty lines at the kernel boundary cost 3 us, MI355X_MICROARCH.md "boundary"). The dustbin column's sum sits
+    // in the quad that holds column n (thread 0 broadcasts it through LDS), or behind the last quad when n is a multiple of 4.
+    float* bS_slot = reinterpret_cast<float*>(red + 2 * SK4_W);
+    __syncthreads();
+    if (tid == 0) *bS_slot = bS;
+    __syncthreads();
+    const float bSv = *bS_slot;
     float* pp = csum + (long)blockIdx.x * pstride;
 #pragma unroll
-    for (int q = 0; q < SK4_Q; ++q)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int j = q * (SK4_T * 4) + tid * 4 + e;
-            if (j < n) pp[j] = cS[4 * q + e];
+    for (int q = 0; q < SK4_Q; ++q) {
+        const int j = q * (SK4_T * 4) + tid * 4;
+        if (j <= n) {
+            f32x4 o = {cS[4 * q], cS[4 * q + 1], cS[4 * q + 2], cS[4 * q + 3]};
+            const int d = n - j;
+            if (d == 0) o[0] = bSv; else if (d == 1) o[1] = bSv; else if (d == 2) o[2] = bSv; else if (d == 3) o[3] = bSv;
+            __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(pp + j));
         }
-    if (tid == 0) pp[n] = bS;
+    }
+    if (tid == 0 && n >= SKF_MAXN) pp[n] = bSv;
 }
 
 // v_j <- v_j - log C_j (+ log m for the dustbin column) from the per-block column sums; columns whose sum underflowed go on the repair list,
 // which the last block to arrive (integer ticket, self-resetting) works off: exact v_j = log_nu_j - logsumexp_i(z_ij + u_i) by a strided column
 // read, one listed column at a time - nothing to do, normally. u is complete (the sweep kernel has finished), every v_j has one writer.
+static constexpr int SK4_CB = 128;      // columns per combine block: a wave reads 512 contiguous bytes of one partial row per instruction
 __global__ __launch_bounds__(256) void sinkhorn_fused4_combine_kernel(const float* __restrict__ csum, int pstride, int n_parts,
                                                                        const int* __restrict__ m_ptr, const int* __restrict__ n_ptr, float* __restrict__ v,
                                                                        float* __restrict__ norm_out, int* list, int* cnt, int* ticket, float c_min,
                                                                        const float* __restrict__ sim, int ld, float alpha, const float* __restrict__ u) {
-    __shared__ float red[8][32];
+    __shared__ float2 red[4][64];
     __shared__ float2 red2[4];
     __shared__ int s_last;
     const int m = *m_ptr, n = *n_ptr;
-    if (m <= 0 || n <= 0 || (int)blockIdx.x * 32 > n) return;     // n / 32 + 1 blocks take part (and a ticket)
-    const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
-    const int j = blockIdx.x * 32 + c;
+    if (m <= 0 || n <= 0 || (int)blockIdx.x * SK4_CB > n) return;     // n / SK4_CB + 1 blocks take part (and a ticket)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = blockIdx.x * SK4_CB + 2 * lane;                        // this lane's two columns (pstride is even: 8-byte aligned pairs)
     const int ns = min(n_parts, m + 1);
-    float S = 0.f;
-    if (j <= n)
-        for (int s0 = g; s0 < ns; s0 += 8) S += csum[(long)s0 * pstride + j];
-    red[g][c] = S;
-    __syncthreads();
-    if (g == 0 && j <= n) {
-        float C = 0.f;
+    // wave w sums the partial rows w, w + 4, ...: eight loads in flight per lane; the order of the additions is fixed (deterministic)
+    float2 acc = make_float2(0.f, 0.f);
+    if (j <= n) {
+        const float* cp = csum + j;
+        int s0 = wave;
+        for (; s0 + 28 < ns; s0 += 32) {
+            float2 t[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) C += red[k][c];
-        if (C > c_min) v[j] = v[j] - logf(C) + (j == n ? logf((float)m) : 0.f);
-        else list[atomicAdd(cnt, 1)] = j;                       // order does not matter: each entry is recomputed on its own
+            for (int k = 0; k < 8; ++k) t[k] = *reinterpret_cast<const float2*>(cp + (long)(s0 + 4 * k) * pstride);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { acc.x += t[k].x; acc.y += t[k].y; }
+        }
+        for (; s0 < ns; s0 += 4) {
+            const float2 t = *reinterpret_cast<const float2*>(cp + (long)s0 * pstride);
+            acc.x += t.x; acc.y += t.y;
+        }
+    }
+    red[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && j <= n) {
+        const float C[2] = {(red[0][lane].x + red[1][lane].x) + (red[2][lane].x + red[3][lane].x),
+                            (red[0][lane].y + red[1][lane].y) + (red[2][lane].y + red[3][lane].y)};
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int jc = j + e;
+            if (jc > n) break;
+            if (C[e] > c_min) v[jc] = v[jc] - logf(C[e]) + (jc == n ? logf((float)m) : 0.f);
+            else {                                               // order does not matter: each entry is recomputed on its own
+                list[atomicAdd(cnt, 1)] = jc;
+                __threadfence();                                 // rare path only: the entry must be out of this XCD's L2 before the ticket is taken
+            }                                                    // (a fence in EVERY block - an L2 write-back each - cost 29 us per launch at 16385 columns)
+        }
         if (j == 0) *norm_out = sg_norm(m, n);
     }
-    __threadfence();
     __syncthreads();
     if (threadIdx.x == 0) {
         const int old = atomicAdd(ticket, 1);
-        s_last = old == n / 32;
+        s_last = old == n / SK4_CB;
         if (s_last) *ticket = 0;                                 // ready for the next launch
     }
     __syncthreads();
@@ -374,7 +406,7 @@ static int sinkhorn(im_ctx* ctx, hipStream_t s, const float* sim, int ld, const 
     IM_HIP(ctx, launch_zero_words(u, m_max + 1, s));
     IM_HIP(ctx, launch_zero_words(v, n_max + 1, s));
     const int nstrips = (m_max + SK_STRIP - 1) / SK_STRIP;
-    const int pstride = n_max + 1;
+    const int pstride = (n_max + 4) & ~3;       // >= n_max + 1 floats, rows 16-byte aligned (the partials are written and read as vectors)
     // single-read form: needs the row in the registers of one block (n <= 16384), 16-byte aligned rows, and as many partial
     // strips as blocks (the workspace holds (K + 15) / 16 + 1 of them). Otherwise (and with IM_SINKHORN_TWO_SWEEP=1, the A/B switch):
     // round 1's row sweep + column sweep, two reads of the couplings per iteration, any size.
@@ -393,7 +425,7 @@ static int sinkhorn(im_ctx* ctx, hipStream_t s, const float* sim, int ld, const 
         static const float c_min = (getenv("IM_SINKHORN_REPAIR_ALL") && getenv("IM_SINKHORN_REPAIR_ALL")[0] == '1') ? 3.0e38f : 1e-30f;
         for (int it = 0; it < iters; ++it) {
             hipLaunchKernelGGL((sinkhorn_fused4_kernel<512, 8>), dim3(G4), dim3(512), lds4, s, sim, ld, m_ptr, n_ptr, alpha, v, u, csum, pstride);
-            hipLaunchKernelGGL(sinkhorn_fused4_combine_kernel, dim3((n_max + 1 + 31) / 32), dim3(256), 0, s, csum, pstride, G4, m_ptr, n_ptr, v, norm_out,
+            hipLaunchKernelGGL(sinkhorn_fused4_combine_kernel, dim3((n_max + SK4_CB) / SK4_CB), dim3(256), 0, s, csum, pstride, G4, m_ptr, n_ptr, v, norm_out,
                                list, cnt, cnt + 1, c_min, sim, ld, alpha, u);
         }
         IM_HIP(ctx, hipGetLastError());
