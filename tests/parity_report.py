@@ -273,6 +273,9 @@ def main():
     ap.add_argument("--no-full", action="store_true")
     ap.add_argument("--epochs", type=int, default=0, help="additional configs[1] bench pairs (epochs 1..N), LightGlue")
     ap.add_argument("--superglue", action="store_true", help="SuperGlue-flavour cases (SuperPoint nms 3 + SuperGlue), incl. 1080p / 4096")
+    ap.add_argument("--adaptive", type=int, default=0, help="ONLY the adaptive-path campaign: bench epochs 0..N-1 (1080x1920, K=4096) under the "
+                    "`prune_gradual` weights (default options and depth_confidence=-1) and `earlystop_late`: pruning / early stop at work in every layer, "
+                    "live counts per layer against the oracle (tests/test_gpu_adaptive.py runs one pair of each)")
     ap.add_argument("--config5", action="store_true", help="ONLY the BASELINE configs[4] size: 3000x4000 pair, 16384 keypoints, SuperGlue with 20 "
                     "Sinkhorn iterations, incl. the Sinkhorn / score-matrix comparison at 16385 x 16385 (minutes of oracle time)")
     ap.add_argument("--config5-mid", action="store_true", help="with --config5: also the 2000x3000 / 8192-keypoint case of the GPU suite")
@@ -285,6 +288,28 @@ def main():
     eng.load_state_dict("superpoint", sp_sd)
     eng.load_state_dict("lightglue", lg_sd)
     report = {"conv": "direct" if os.environ.get("IM_CONV_DIRECT") == "1" else "winograd", "cases": {}}
+    if args.adaptive:
+        # calibration of the one-channel weights: keypoint descriptors of image 0 of epoch 0, from the device (as in tests/test_gpu_adaptive.py)
+        a, b = synthetic.stereo_pair(0, 1080, 1920)
+        eng.reserve(1080, 1920, 2, 4096)
+        eng.superpoint(torch.from_numpy(np.stack([a, b])).cuda(), 4, 0.0005, 4, 4096)
+        torch.cuda.synchronize()
+        d0 = torch.from_numpy(eng.features_to_host(0)[1])
+        stats = (d0.mean(0), d0.std(0))
+        live_equal = 0
+        for variant, conf in (("prune_gradual", {}), ("prune_gradual", {"depth_confidence": -1}), ("earlystop_late", {})):
+            v_sd = synthetic.lightglue_state_dict(0, variant, channel_stats=stats if variant == "prune_gradual" else None)
+            eng.load_state_dict("lightglue", v_sd)
+            for e in range(args.adaptive):
+                a, b = (synthetic.translated_pair(e, 1080, 1920, 40, 8) if e % 2 else synthetic.stereo_pair(e, 1080, 1920))
+                name = f"adaptive {variant} {conf or 'default options'}: {'translated' if e % 2 else 'bench'} pair, epoch {e} (1080x1920, K=4096)"
+                t = time.time()
+                report["cases"][name] = run_case(eng, a, b, sp_sd, v_sd, 4096, lg_conf=conf)
+                c = report["cases"][name]["matching_same_features"]
+                live_equal += int(c["live_device"] == c["live_oracle"] and c["stop_device"] == c["stop_oracle"] and c["prune0_equal"] and c["prune1_equal"])
+                report["cases"][name]["seconds"] = round(time.time() - t, 1)
+                print(name, json.dumps(report["cases"][name]), flush=True)
+        report["adaptive_cases_with_equal_stop_layer_prune_counters_and_live_counts"] = live_equal
     if args.config5:
         sg_sd = synthetic.superglue_state_dict(0, "passthrough")
         eng.load_state_dict("superglue", sg_sd)
@@ -297,7 +322,7 @@ def main():
             report["cases"][name] = run_case_superglue(eng, a, b, sp_sd, sg_sd, k, check_ot=True)
             report["cases"][name]["seconds"] = round(time.time() - t, 1)
             print(name, json.dumps(report["cases"][name]), flush=True)
-    for name, a, b, k in ([] if args.config5 else cases(not args.no_full)):
+    for name, a, b, k in ([] if (args.config5 or args.adaptive) else cases(not args.no_full)):
         t = time.time()
         report["cases"][name] = run_case(eng, a, b, sp_sd, lg_sd, k)
         report["cases"][name]["seconds"] = round(time.time() - t, 1)
