@@ -79,7 +79,7 @@ hipError_t launch_det_softmax(const float* logits, int ld, float* smap, int B, i
 // simple_nms (`lightglue/superpoint.py:50-65`), staged form: five (2r+1)^2 max-pools (stride 1, -inf padding) chained with
 // exact fp32 equality tests, one launch per stage; the pooled quantity of a 32 x 64 tile plus halo r is staged in LDS and
 // reduced separably. Only used for radius 5..8 and map widths that are not a multiple of 4; the forward pass with the
-// reference's radii (3, 4) runs nms_fused_kernel below.
+// reference's radii (3, 4) runs nms_round_kernel below.
 static constexpr int NT_H = 32, NT_W = 64, NMS_RMAX = 8;
 
 template <typename LoadF>
@@ -165,32 +165,6 @@ static hipError_t launch_nms_staged(const float* s, float* out, uint8_t* mask, u
     return hipGetLastError();
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// simple_nms in ONE launch (`lightglue/superpoint.py:50-65`): the score tile plus a 20-pixel halo sits in LDS and all
-// three rounds run there; the map is read from HBM once (halo overlap served by L2) and written once. Exact: only
-// max and == on fp32 values, no arithmetic.
-//   keep0 = (S == pool(S))                          needed on tile + 4r   (pool = (2r+1)^2 max, -inf padding)
-//   near1 = dilate_r(keep0)   rest1 = near1 ? 0 : S  needed on tile + 3r
-//   keep1 = keep0 | (rest1 == pool(rest1) & ~near1)  needed on tile + 2r
-//   near2 = dilate_r(keep1)   rest2 = near2 ? 0 : S  needed on tile + r      (near2 contains near1, so S is zeroed in place)
-//   keep2 = keep1 | (rest2 == pool(rest2) & ~near2)  on the tile             -> out = keep2 ? S : 0
-// S therefore needs a halo of 5r <= 20 pixels (r <= 4). Geometry is fixed for every r: 32 x 56 output tile, region 72 x 96
-// = three 32-bit mask words per row. Pools are separable sliding maxima computed in registers (a thread takes 16 outputs
-// of a column, then 16 outputs of a row, two v_max3 per output: ~0.2 LDS instructions per pixel and pass instead of
-// 2 (2r+1)); keep / near are BIT masks, their dilation is ORs of 96-bit rows and shifts, one (row, word) per thread.
-// Where the time goes (timing ablation on 2 x 1080p maps, kernel alone 44 us): launch + mask clear + tile stores 7, region
-// load 5, per round vertical pass 4 + horizontal pass 5.6, dilation + zeroing 6 per refinement round - every phase is a
-// barrier-separated latency chain of a few LDS round trips (the instruction-throughput bound of the whole kernel is ~14 us).
-// Epilogue (optional): the tile's keypoint candidates (score > threshold, outside the border frame; `superpoint.py:177-187`)
-// are appended to the image's key list (one global atomic per block; order does not matter: the selection stage ranks) and
-// counted into the first radix histogram of the top-k selection.
-namespace nf {
-constexpr int TH = 32, TW = 56, HALO = 20, RH = TH + 2 * HALO, RW = TW + 2 * HALO, PAD = 4, PITCH = 108, NW = 3;
-constexpr int NT = 512;   // threads per block: two blocks per CU (LDS), so 16 waves to hide the load / barrier latency
-constexpr int LDS_FLOATS = 2 * RH * PITCH + 2 * RH * 4;   // S, T (scratch: vertical maxima / dilation rows / candidate staging), keep, near
-static_assert(RW == 32 * NW, "three mask words per row");
-}  // namespace nf
-
 struct SelState {            // per image, zeroed by launch_* before every use
     unsigned hist[4][256];   // radix histograms of the score bits, 8 bits per pass, most significant first
     int n_sel, n_eq, pad0, pad1;
@@ -227,22 +201,39 @@ __device__ __forceinline__ unsigned long long cand_key(float v, unsigned flat_id
     return ((unsigned long long)__float_as_uint(v) << 32) | (unsigned long long)(0xFFFFFFFFu - flat_idx);
 }
 
-template <int R>
-__global__ __launch_bounds__(nf::NT, 4) void nms_fused_kernel(const float* __restrict__ s, float* __restrict__ out, int H, int W, int tiles_x,
-                                                            int tiles_per_img, int total_tiles, int border, float thr,
-                                                            unsigned long long* __restrict__ keys, long key_stride,
-                                                            int* __restrict__ n_cand, SelState* __restrict__ sel) {
-    using namespace nf;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+// ---------------------------------------------------------------------------------------------------------
+// simple_nms as THREE launches, one per round (`lightglue/superpoint.py:50-65`), with the maxima kept as BIT masks in global memory
+// between the rounds (1 bit per pixel: 0.26 MB per 1080p image):
+//   round 0:  keep0 = (S == pool(S))
+//   round 1:  near = dilate_r(keep0), rest = near ? 0 : S, keep1 = keep0 | (rest == pool(rest) & ~near)
+//   round 2:  the same from keep1 -> keep2, out = keep2 ? S : 0 (+ the candidate epilogue)
+// A round needs the scores on tile + r and the previous mask on tile + 2r, so a 32 x 64 tile stages 40 x 72 floats (1.4 x its own
+// pixels) and runs ONE separable pool there - against the single-launch kernel of rounds 2-4 (tools/experiments/nms_fused_single_launch.hip.txt), whose 5r
+// halo made it stage 72 x 96 floats (3.9 x) and run three pools on them behind twelve barriers: 40 against 26 us for two 1080p maps. Three barriers per block here, 23 KB of LDS (six blocks per CU), every
+// thread busy in the compare pass. The score map is read three times, from L2 / Infinity Cache after the first. Exact by construction:
+// max and == on fp32 only.
+namespace nr {
+constexpr int TH = 32, TW = 64, CH = 4, RW = TW + 2 * CH, PITCH = 76, NT = 256;
+constexpr int SROWS = TH + 8, KROWS = TH + 16;     // at r = 4
+}  // namespace nr
+
+template <int R, int STAGE>
+__global__ __launch_bounds__(nr::NT) void nms_round_kernel(const float* __restrict__ s, const unsigned* __restrict__ keep_in,
+                                                           unsigned char* __restrict__ keep_out, float* __restrict__ out, int H, int W, int WW,
+                                                           int tiles_x, int tiles_per_img, int total_tiles, int border, float thr,
+                                                           unsigned long long* __restrict__ keys, long key_stride, int* __restrict__ n_cand,
+                                                           SelState* __restrict__ sel) {
+    using namespace nr;
+    constexpr int SR = TH + 2 * R;                  // rows of S: y0 - R .. y0 + TH + R - 1
+    constexpr int KR = TH + 4 * R;                  // rows of the previous mask: y0 - 2R ..
+    __shared__ __attribute__((aligned(16))) float lds[(SROWS + TH) * PITCH];
+    __shared__ __attribute__((aligned(16))) unsigned kw[KROWS * 4];      // previous keep, words x0 / 32 - 1 .. + 2
+    __shared__ __attribute__((aligned(16))) unsigned nw[SROWS * 4];      // near = dilate_r(previous keep), same words, rows of S
     float* S = lds;
-    float* T = lds + RH * PITCH;
-    unsigned* keepm = reinterpret_cast<unsigned*>(lds + 2 * RH * PITCH);   // [RH][4]
-    unsigned* nearm = keepm + RH * 4;                                        // [RH][4]
+    float* T = lds + SROWS * PITCH;
     const int tid = threadIdx.x;
-    // XCD-aware block -> tile map: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8), each with its own L2. XCD x
-    // takes the x-th contiguous eighth of the tile list (a band of tile rows), so the 20-pixel halos neighbouring tiles share are
-    // re-read from that XCD's L2 instead of from HBM (PMC before: 100 MB per launch at 1080p x 2 for 33 MB algorithmic).
-    const int per_xcd = (int)gridDim.x / 8;          // the grid is padded to a multiple of 8 blocks
+    const int per_xcd = (int)gridDim.x / 8;          // XCD-aware block -> tile map: XCD x takes the x-th contiguous eighth of the tile list (a band of tile rows), so the halos
+    // neighbouring tiles share are re-read from that XCD's L2 (blocks are dealt round-robin over the 8 XCDs; the grid is padded to a multiple of 8)
     const int tile_lin = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
     if (tile_lin >= total_tiles) return;
     const int b = tile_lin / tiles_per_img;
@@ -251,176 +242,160 @@ __global__ __launch_bounds__(nf::NT, 4) void nms_fused_kernel(const float* __res
     const long img = (long)b * H * W;
     const float NINF = -INFINITY;
 
-    // ---- load the region (-inf outside the image: max_pool2d's implicit padding), clear the masks
-    for (int idx = tid; idx < RH * (RW / 4); idx += NT) {
+    // ---- scores of the region (-inf outside the image: max_pool2d's implicit padding) and the previous mask
+    for (int idx = tid; idx < SR * (RW / 4); idx += NT) {
         const int ry = idx / (RW / 4), q = idx - ry * (RW / 4);
-        const int gy = y0 - HALO + ry, gx = x0 - HALO + 4 * q;
+        const int gy = y0 - R + ry, gx = x0 - CH + 4 * q;
         float4 v = make_float4(NINF, NINF, NINF, NINF);
         if (gy >= 0 && gy < H && gx >= 0 && gx + 3 < W) v = *reinterpret_cast<const float4*>(s + img + (long)gy * W + gx);
-        *reinterpret_cast<float4*>(S + ry * PITCH + PAD + 4 * q) = v;
+        *reinterpret_cast<float4*>(S + ry * PITCH + 4 * q) = v;
     }
-    for (int idx = tid; idx < RH * 8; idx += NT) keepm[idx] = 0u;           // keep and near
-    // the tile's own scores stay in registers for the epilogue (the LDS copy gets zeroed around maxima): one float4 per thread
-    static_assert(TH * (TW / 4) <= NT, "one output quad per thread");
-    const int e_ty = tid / (TW / 4), e_q = tid - e_ty * (TW / 4);
-    const int e_gy = y0 + e_ty, e_gx = x0 + 4 * e_q;
-    const bool e_on = tid < TH * (TW / 4) && e_gy < H && e_gx < W;
-    float4 e_sv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (e_on) e_sv = *reinterpret_cast<const float4*>(s + img + (long)e_gy * W + e_gx);
-    // in-image column mask of each word, row validity is tested per task
-    unsigned colmask[NW];
-#pragma unroll
-    for (int w = 0; w < NW; ++w) {
-        const int g0 = x0 - HALO + 32 * w;                                    // global x of bit 0
-        unsigned m = 0xFFFFFFFFu;
-        if (g0 < 0) m &= (g0 <= -32) ? 0u : (0xFFFFFFFFu << (-g0));
-        if (g0 + 32 > W) m &= (g0 >= W) ? 0u : (0xFFFFFFFFu >> (g0 + 32 - W));
-        colmask[w] = m;
+    if constexpr (STAGE > 0) {
+        for (int idx = tid; idx < KR * 4; idx += NT) {
+            const int kr = idx >> 2, w = idx & 3;
+            const int gy = y0 - 2 * R + kr, gw = (x0 >> 5) - 1 + w;
+            kw[idx] = (gy >= 0 && gy < H && gw >= 0 && gw < WW) ? keep_in[((long)b * H + gy) * WW + gw] : 0u;
+        }
     }
     __syncthreads();
 
+    if constexpr (STAGE > 0) {
+        // ---- near on the rows of S: vertical OR of the 128-bit mask rows, then the horizontal dilation (the two commute); the scores under
+        // it are zeroed in place (in-image pixels only: the padding stays -inf). One (row, word) per thread.
+        if (tid < SR * 4) {
+            const int ry = tid >> 2, w = tid & 3;
+            unsigned k0 = 0, k1 = 0, k2 = 0, k3 = 0;
 #pragma unroll
-    for (int st = 0; st < 3; ++st) {
-        const int inset = HALO - (2 - st) * 2 * R;       // keep_st is needed on rows / columns [inset, R? - inset)
-        if (st > 0) {
-            // ---- near = dilate_r(keep) on rows / columns [inset - R, ..): vertical OR of the 96-bit keep rows, then the horizontal
-            // dilation of the OR (the two commute), one (row, word) per thread, no intermediate buffer and no barrier in between
-            const int n_lo = inset - R, n_rows = RH - 2 * (inset - R);
-            if (tid < n_rows * NW) {
-                const int w = tid / n_rows, ry = n_lo + tid - w * n_rows;
-                unsigned k0 = 0, k1 = 0, k2 = 0;
+            for (int d = 0; d <= 2 * R; ++d) {
+                const uint4 kr = *reinterpret_cast<const uint4*>(kw + (ry + d) * 4);
+                k0 |= kr.x; k1 |= kr.y; k2 |= kr.z; k3 |= kr.w;
+            }
+            const unsigned lo = w == 0 ? 0u : (w == 1 ? k0 : (w == 2 ? k1 : k2));       // the word to the left / right of this one
+            const unsigned me = w == 0 ? k0 : (w == 1 ? k1 : (w == 2 ? k2 : k3));
+            const unsigned hi = w == 0 ? k1 : (w == 1 ? k2 : (w == 2 ? k3 : 0u));
+            unsigned m = me;
 #pragma unroll
-                for (int dy = -R; dy <= R; ++dy) {
-                    const uint4 kr = *reinterpret_cast<const uint4*>(keepm + (ry + dy) * 4);
-                    k0 |= kr.x; k1 |= kr.y; k2 |= kr.z;
+            for (int i = 1; i <= R; ++i) m |= (me << i) | (me >> i) | (lo >> (32 - i)) | (hi << (32 - i));
+            nw[tid] = m;
+            const int gy = y0 - R + ry;
+            const int g0 = x0 - 32 + 32 * w;                                            // global x of bit 0
+            unsigned cm = 0xFFFFFFFFu;
+            if (g0 < 0) cm = 0u;                                                        // (x0 is a multiple of 64: a word is inside or outside)
+            if (g0 + 32 > W) cm = (g0 >= W) ? 0u : (0xFFFFFFFFu >> (g0 + 32 - W));
+            const unsigned z = (gy >= 0 && gy < H) ? (m & cm) : 0u;
+            if (z) {
+                // word 1 / 2 = region columns 4 .. 35 / 36 .. 67; of word 0 only bits 28 .. 31 (columns 0 .. 3), of word 3 bits 0 .. 3 (68 .. 71)
+                const int q_lo = w == 0 ? 7 : 0, q_hi = w == 3 ? 1 : 8;
+                float4* row = reinterpret_cast<float4*>(S + ry * PITCH + CH + 32 * (w - 1));
+                for (int q = q_lo; q < q_hi; ++q) {
+                    const unsigned nib = (z >> (4 * q)) & 15u;
+                    if (nib) {
+                        float4 v = row[q];
+                        if (nib & 1u) v.x = 0.f;
+                        if (nib & 2u) v.y = 0.f;
+                        if (nib & 4u) v.z = 0.f;
+                        if (nib & 8u) v.w = 0.f;
+                        row[q] = v;
+                    }
                 }
-                unsigned m = w == 0 ? k0 : (w == 1 ? k1 : k2);           // 96-bit row k2:k1:k0, bit x = column x
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- vertical pass: T[t][c] = max over S rows t .. t + 2R (= tile row t +- R), every column of the region
+    for (int t = tid; t < RW * 2; t += NT) {
+        const int seg = t / RW, c = t - seg * RW;
+        float v[16 + 8];
 #pragma unroll
-                for (int i = 1; i <= R; ++i) {
-                    if (w == 0) m |= (k0 << i) | (k0 >> i) | (k1 << (32 - i));
-                    else if (w == 1) m |= (k1 << i) | (k0 >> (32 - i)) | (k1 >> i) | (k2 << (32 - i));
-                    else m |= (k2 << i) | (k1 >> (32 - i)) | (k2 >> i);
-                }
-                nearm[ry * 4 + w] = m;
-                // rest = near ? 0 : S, in place (in-image pixels only: the padding stays -inf)
-                const int gy = y0 - HALO + ry;
-                const unsigned z = (gy >= 0 && gy < H) ? (m & colmask[w]) : 0u;
-                if (z) {
-                    float4* row = reinterpret_cast<float4*>(S + ry * PITCH + PAD + 32 * w);
+        for (int i = 0; i < 16 + 2 * R; ++i) v[i] = S[(16 * seg + i) * PITCH + c];
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const unsigned nib = (z >> (4 * q)) & 15u;
-                        if (nib) {
-                            float4 v = row[q];
-                            if (nib & 1u) v.x = 0.f;
-                            if (nib & 2u) v.y = 0.f;
-                            if (nib & 4u) v.z = 0.f;
-                            if (nib & 8u) v.w = 0.f;
-                            row[q] = v;
-                        }
+        for (int i = 16 + 2 * R; i < 24; ++i) v[i] = NINF;
+        sliding_max<R, 16>(v);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) T[(16 * seg + i) * PITCH + c] = v[i];
+    }
+    __syncthreads();
+
+    // ---- horizontal pass + equality test: 8 outputs of one tile row per thread = one byte of the mask
+    const int t_row = tid >> 3, seg = tid & 7;
+    const int gy = y0 + t_row, gx = x0 + 8 * seg;
+    unsigned kout;
+    {
+        const float4* tr = reinterpret_cast<const float4*>(T + t_row * PITCH + 8 * seg);      // region columns 8 seg .. 8 seg + 15
+        float v[8 + 8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const float4 t4 = tr[q]; v[4 * q] = t4.x; v[4 * q + 1] = t4.y; v[4 * q + 2] = t4.z; v[4 * q + 3] = t4.w; }
+        if constexpr (R < 4) {      // the window of output i starts at region column 8 seg + CH + i - R
+#pragma unroll
+            for (int i = 0; i < 8 + 2 * R; ++i) v[i] = v[i + CH - R];
+        }
+        sliding_max<R, 8>(v);
+        const float4* cr = reinterpret_cast<const float4*>(S + (t_row + R) * PITCH + CH + 8 * seg);
+        unsigned eq = 0;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float4 c4 = cr[q];
+            eq |= (c4.x == v[4 * q] ? 1u : 0u) << (4 * q);
+            eq |= (c4.y == v[4 * q + 1] ? 1u : 0u) << (4 * q + 1);
+            eq |= (c4.z == v[4 * q + 2] ? 1u : 0u) << (4 * q + 2);
+            eq |= (c4.w == v[4 * q + 3] ? 1u : 0u) << (4 * q + 3);
+        }
+        unsigned vm = 0u;                                                             // in-image outputs of this byte
+        if (gy < H && gx < W) vm = (gx + 8 <= W) ? 0xFFu : (0xFFu >> (gx + 8 - W));
+        if constexpr (STAGE == 0) {
+            kout = eq & vm;
+        } else {
+            const int w = 1 + (seg >> 2), sh = 8 * (seg & 3);
+            const unsigned nearb = (nw[(t_row + R) * 4 + w] >> sh) & 0xFFu;
+            const unsigned prev = (kw[(t_row + 2 * R) * 4 + w] >> sh) & 0xFFu;
+            kout = prev | (eq & vm & ~nearb);
+        }
+    }
+    if constexpr (STAGE < 2) {
+        if (gy < H && gx < 32 * WW) keep_out[(((long)b * H + gy) * WW) * 4 + (gx >> 3)] = (unsigned char)kout;
+        return;
+    } else {
+        // ---- epilogue: out = keep2 ? S : 0 (S from global: the LDS copy is zeroed around the maxima) and the candidate keys
+        const bool e_on = gy < H && gx < W;              // W % 4 == 0: whole quads
+        const bool e_on2 = e_on && gx + 4 < W;
+        float4 sv0 = make_float4(0.f, 0.f, 0.f, 0.f), sv1 = sv0;
+        if (e_on) sv0 = *reinterpret_cast<const float4*>(s + img + (long)gy * W + gx);
+        if (e_on2) sv1 = *reinterpret_cast<const float4*>(s + img + (long)gy * W + gx + 4);
+        const float ov[8] = {(kout & 1u) ? sv0.x : 0.f, (kout & 2u) ? sv0.y : 0.f, (kout & 4u) ? sv0.z : 0.f, (kout & 8u) ? sv0.w : 0.f,
+                             (kout & 16u) ? sv1.x : 0.f, (kout & 32u) ? sv1.y : 0.f, (kout & 64u) ? sv1.z : 0.f, (kout & 128u) ? sv1.w : 0.f};
+        int* cnt = reinterpret_cast<int*>(lds);                                   // [0] candidates of this block, [1] global base
+        unsigned* lhist = reinterpret_cast<unsigned*>(lds) + 4;                   // [256]
+        unsigned long long* stage = reinterpret_cast<unsigned long long*>(lds + 512);   // up to TH * TW keys: 16 KB of the 21.9
+        static_assert(512 + 2 * TH * TW <= (SROWS + TH) * PITCH, "candidate staging fits in the S / T area");
+        int n = 0;
+        if (keys) {
+            __syncthreads();                             // every thread is done with S and T
+            for (int i = tid; i < 260; i += NT) reinterpret_cast<unsigned*>(lds)[i] = 0u;
+            __syncthreads();
+            if (kout && gy >= border && gy < H - border) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int x = gx + j;
+                    if (ov[j] > thr && x >= border && x < W - border) {
+                        const int p = atomicAdd(&cnt[0], 1);
+                        stage[p] = cand_key(ov[j], (unsigned)(gy * W + x));
+                        atomicAdd(&lhist[__float_as_uint(ov[j]) >> 24], 1u);
                     }
                 }
             }
             __syncthreads();
+            n = cnt[0];
+            if (n > 0 && tid == 0) cnt[1] = atomicAdd(&n_cand[b], n);       // its latency hides behind the map store below
+            if (n > 0 && lhist[tid]) atomicAdd(&sel[b].hist[0][tid], lhist[tid]);
         }
-        // ---- vertical pass: T[ry][rx] = max_{|dy| <= R} S[ry + dy][rx], rows [inset, RH - inset), columns [inset - R, RW - inset + R)
-        {
-            const int c_lo = inset - R, ncol = RW - 2 * (inset - R);
-            const int r_lo = inset, nrow = RH - 2 * inset;
-            const int nseg = (nrow + 15) / 16;
-            for (int t = tid; t < ncol * nseg; t += NT) {
-                const int seg = t / ncol, rx = c_lo + t - seg * ncol;
-                const int ry0 = r_lo + 16 * seg;
-                float v[16 + 8];
-#pragma unroll
-                for (int i = 0; i < 16 + 2 * R; ++i) v[i] = S[min(ry0 - R + i, RH - 1) * PITCH + PAD + rx];
-#pragma unroll
-                for (int i = 16 + 2 * R; i < 24; ++i) v[i] = NINF;
-                sliding_max<R, 16>(v);
-#pragma unroll
-                for (int i = 0; i < 16; ++i)
-                    if (ry0 + i < r_lo + nrow) T[(ry0 + i) * PITCH + PAD + rx] = v[i];
-            }
+        if (out && e_on) *reinterpret_cast<float4*>(out + img + (long)gy * W + gx) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+        if (out && e_on2) *reinterpret_cast<float4*>(out + img + (long)gy * W + gx + 4) = make_float4(ov[4], ov[5], ov[6], ov[7]);
+        if (n > 0) {
+            __syncthreads();
+            unsigned long long* kd = keys + (long)b * key_stride + cnt[1];
+            for (int i = tid; i < n; i += NT) kd[i] = stage[i];
         }
-        __syncthreads();
-        // ---- horizontal pass + equality test: 16 outputs of one row per thread -> one half of a mask word (6 x nrow tasks keep
-        // most of the 512 threads busy; a thread owns its half word, so keep is updated without atomics)
-        {
-            const int r_lo = inset, nrow = RH - 2 * inset;
-            if (tid < nrow * 2 * NW) {
-                const int seg = tid / nrow, ry = r_lo + tid - seg * nrow;
-                const int w = seg >> 1, sh = 16 * (seg & 1);
-                const float4* tr = reinterpret_cast<const float4*>(T + ry * PITCH + PAD + 16 * seg - 4);   // columns 16 seg - 4 .. 16 seg + 19
-                float v[16 + 8];
-#pragma unroll
-                for (int q = 0; q < 6; ++q) { const float4 t4 = tr[q]; v[4 * q] = t4.x; v[4 * q + 1] = t4.y; v[4 * q + 2] = t4.z; v[4 * q + 3] = t4.w; }
-                // window of output i starts at column 16 seg + i - R = v index i + 4 - R
-                if constexpr (R < 4) {
-#pragma unroll
-                    for (int i = 0; i < 16 + 2 * R; ++i) v[i] = v[i + 4 - R];
-                }
-                sliding_max<R, 16>(v);
-                const float4* cr = reinterpret_cast<const float4*>(S + ry * PITCH + PAD + 16 * seg);
-                unsigned eq = 0;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 c4 = cr[q];
-                    eq |= (c4.x == v[4 * q] ? 1u : 0u) << (4 * q);
-                    eq |= (c4.y == v[4 * q + 1] ? 1u : 0u) << (4 * q + 1);
-                    eq |= (c4.z == v[4 * q + 2] ? 1u : 0u) << (4 * q + 2);
-                    eq |= (c4.w == v[4 * q + 3] ? 1u : 0u) << (4 * q + 3);
-                }
-                // valid outputs: columns [inset, RW - inset) of this half word, inside the image, not suppressed
-                const int lo = max(inset - 16 * seg, 0), hi = min(RW - inset - 16 * seg, 16);
-                unsigned vm = (hi > lo) ? (((1u << (hi - lo)) - 1u) << lo) : 0u;
-                const int gy = y0 - HALO + ry;
-                vm = (gy >= 0 && gy < H) ? (vm & (colmask[w] >> sh)) : 0u;
-                if (st > 0) vm &= ~(nearm[ry * 4 + w] >> sh);
-                unsigned short* kh = reinterpret_cast<unsigned short*>(keepm) + ry * 8 + seg;
-                *kh = (unsigned short)(*kh | (eq & vm & 0xFFFFu));
-            }
-        }
-        __syncthreads();
-    }
-
-    // ---- epilogue: out = keep2 ? S : 0 on the tile (S re-read from global: the LDS copy has been zeroed around maxima)
-    int* cnt = reinterpret_cast<int*>(T);                                     // [0] candidates of this block, [1] global base
-    unsigned* lhist = reinterpret_cast<unsigned*>(T) + 4;                     // [256]
-    unsigned long long* stage = reinterpret_cast<unsigned long long*>(T + 512);
-    if (keys) {
-        for (int i = tid; i < 260; i += NT) reinterpret_cast<unsigned*>(T)[i] = 0u;
-        __syncthreads();
-    }
-    float4 e_o = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (e_on) {
-        const int ry = HALO + e_ty, rx = HALO + 4 * e_q;
-        const unsigned bits = (keepm[ry * 4 + (rx >> 5)] >> (rx & 31)) & 15u;
-        e_o = make_float4((bits & 1u) ? e_sv.x : 0.f, (bits & 2u) ? e_sv.y : 0.f, (bits & 4u) ? e_sv.z : 0.f, (bits & 8u) ? e_sv.w : 0.f);
-        if (keys && bits && e_gy >= border && e_gy < H - border) {
-            const float ov[4] = {e_o.x, e_o.y, e_o.z, e_o.w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int x = e_gx + j;
-                if (ov[j] > thr && x >= border && x < W - border) {
-                    const int p = atomicAdd(&cnt[0], 1);
-                    stage[p] = cand_key(ov[j], (unsigned)(e_gy * W + x));
-                    atomicAdd(&lhist[__float_as_uint(ov[j]) >> 24], 1u);
-                }
-            }
-        }
-    }
-    int n = 0;
-    if (keys) {
-        __syncthreads();
-        n = cnt[0];
-        if (n > 0 && tid == 0) cnt[1] = atomicAdd(&n_cand[b], n);       // its latency hides behind the map store below
-        if (n > 0 && tid < 256 && lhist[tid]) atomicAdd(&sel[b].hist[0][tid], lhist[tid]);
-    }
-    if (out && e_on) *reinterpret_cast<float4*>(out + img + (long)e_gy * W + e_gx) = e_o;
-    if (n > 0) {
-        __syncthreads();
-        unsigned long long* kd = keys + (long)b * key_stride + cnt[1];
-        for (int i = tid; i < n; i += NT) kd[i] = stage[i];
     }
 }
 
@@ -668,17 +643,31 @@ static SelState* sel_states(int* n_cand, int B) {
 }
 
 template <int R>
-static hipError_t launch_nms_fused_r(const float* s, float* out, int B, int H, int W, int border, float thr, unsigned long long* keys,
-                                     long key_stride, int* n_cand, hipStream_t st) {
-    static size_t cache[IM_MAX_DEVICES] = {0};
-    const size_t lds = nf::LDS_FLOATS * sizeof(float);
-    hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(&nms_fused_kernel<R>), lds, cache);
-    if (e != hipSuccess) return e;
-    const int tx = (W + nf::TW - 1) / nf::TW, ty = (H + nf::TH - 1) / nf::TH;
+static hipError_t launch_nms_rounds_r(const float* s, float* out, uint8_t* keep_a, uint8_t* keep_b, int B, int H, int W, int border, float thr,
+                                      unsigned long long* keys, long key_stride, int* n_cand, hipStream_t st) {
+    const int tx = (W + nr::TW - 1) / nr::TW, ty = (H + nr::TH - 1) / nr::TH, WW = (W + 31) / 32;
     const int total = tx * ty * B;
-    hipLaunchKernelGGL(nms_fused_kernel<R>, dim3(((total + 7) / 8) * 8), dim3(nf::NT), lds, st, s, out, H, W, tx, tx * ty, total, border, thr, keys, key_stride,
-                       n_cand, keys ? sel_states(n_cand, B) : nullptr);
+    const dim3 grid(((total + 7) / 8) * 8), block(nr::NT);
+    unsigned* ka = reinterpret_cast<unsigned*>(keep_a);      // [B][H][WW] words in the byte-mask buffers of the staged form (4 WW <= W)
+    unsigned* kb = reinterpret_cast<unsigned*>(keep_b);
+    SelState* ss = keys ? sel_states(n_cand, B) : nullptr;
+    hipLaunchKernelGGL((nms_round_kernel<R, 0>), grid, block, 0, st, s, (const unsigned*)nullptr, keep_a, (float*)nullptr, H, W, WW, tx, tx * ty, total, border, thr,
+                       (unsigned long long*)nullptr, 0L, (int*)nullptr, (SelState*)nullptr);
+    hipLaunchKernelGGL((nms_round_kernel<R, 1>), grid, block, 0, st, s, (const unsigned*)ka, keep_b, (float*)nullptr, H, W, WW, tx, tx * ty, total, border, thr,
+                       (unsigned long long*)nullptr, 0L, (int*)nullptr, (SelState*)nullptr);
+    hipLaunchKernelGGL((nms_round_kernel<R, 2>), grid, block, 0, st, s, (const unsigned*)kb, (unsigned char*)nullptr, out, H, W, WW, tx, tx * ty, total, border, thr,
+                       keys, key_stride, n_cand, ss);
     return hipGetLastError();
+}
+
+static hipError_t launch_nms_rounds(const float* s, float* out, uint8_t* keep_a, uint8_t* keep_b, int B, int H, int W, int r, int border, float thr,
+                                    unsigned long long* keys, long key_stride, int* n_cand, hipStream_t st) {
+    switch (r) {
+        case 1: return launch_nms_rounds_r<1>(s, out, keep_a, keep_b, B, H, W, border, thr, keys, key_stride, n_cand, st);
+        case 2: return launch_nms_rounds_r<2>(s, out, keep_a, keep_b, B, H, W, border, thr, keys, key_stride, n_cand, st);
+        case 3: return launch_nms_rounds_r<3>(s, out, keep_a, keep_b, B, H, W, border, thr, keys, key_stride, n_cand, st);
+        default: return launch_nms_rounds_r<4>(s, out, keep_a, keep_b, B, H, W, border, thr, keys, key_stride, n_cand, st);
+    }
 }
 
 static bool nms_fusable(int H, int W, int r) {
@@ -686,20 +675,10 @@ static bool nms_fusable(int H, int W, int r) {
     return !staged && r >= 1 && r <= 4 && (W % 4) == 0;
 }
 
-static hipError_t launch_nms_fused(const float* s, float* out, int B, int H, int W, int r, int border, float thr, unsigned long long* keys,
-                                   long key_stride, int* n_cand, hipStream_t st) {
-    switch (r) {
-        case 1: return launch_nms_fused_r<1>(s, out, B, H, W, border, thr, keys, key_stride, n_cand, st);
-        case 2: return launch_nms_fused_r<2>(s, out, B, H, W, border, thr, keys, key_stride, n_cand, st);
-        case 3: return launch_nms_fused_r<3>(s, out, B, H, W, border, thr, keys, key_stride, n_cand, st);
-        default: return launch_nms_fused_r<4>(s, out, B, H, W, border, thr, keys, key_stride, n_cand, st);
-    }
-}
-
 hipError_t launch_nms(const float* s, float* out, uint8_t* mask, uint8_t* supp, float* rest, int B, int H, int W, int r,
                       hipStream_t st) {
     if (r < 0 || r > NMS_RMAX) return hipErrorInvalidValue;
-    if (nms_fusable(H, W, r)) return launch_nms_fused(s, out, B, H, W, r, 0, 0.f, nullptr, 0, nullptr, st);
+    if (nms_fusable(H, W, r)) return launch_nms_rounds(s, out, mask, supp, B, H, W, r, 0, 0.f, nullptr, 0, nullptr, st);
     return launch_nms_staged(s, out, mask, supp, rest, B, H, W, r, st);
 }
 
@@ -727,7 +706,7 @@ hipError_t launch_nms_select(const float* s, float* nms_out, uint8_t* mask, uint
     if (e != hipSuccess) return e;
     const long npix = (long)H * W;
     if (nms_fusable(H, W, r)) {
-        e = launch_nms_fused(s, nms_out, B, H, W, r, border, thr, sb.keys, npix, sb.n_cand, st);
+        e = launch_nms_rounds(s, nms_out, mask, supp, B, H, W, r, border, thr, sb.keys, npix, sb.n_cand, st);
         if (e != hipSuccess) return e;
     } else {
         e = launch_nms_staged(s, nms_out, mask, supp, rest, B, H, W, r, st);

@@ -817,15 +817,16 @@ def test_matchers_with_different_weights_do_not_share_a_context():
 # ------------------------------------------------------------------------------------------- fused NMS / multi-block top-k
 @pytest.mark.parametrize("radius", [1, 2, 3, 4, 5])
 def test_nms_fused_kernel_random_maps(radius):
-    """The one-launch LDS-resident simple_nms (radius <= 4; 5 runs the staged fallback) against the oracle, bit-exact, on
-    maps whose sizes do not divide into its 32 x 56 tiles, with continuous values (no ties), coarsely quantised values (large
-    tie plateaus, including across tile borders) and a constant map."""
+    """simple_nms as one launch per round with bit masks between the rounds (radius <= 4 and widths that are multiples of 4; radius 5
+    and the other widths run the staged fallback) against the oracle, bit-exact, on maps whose sizes do not divide into its 32 x 64
+    tiles (incl. widths that end inside a mask word and inside a mask byte), with continuous values (no ties), coarsely quantised
+    values (large tie plateaus, including across tile borders) and a constant map."""
     from icepy4d_amd.engine import Engine
     from icepy4d_amd._lib import stream_ptr
     o = oracle()
     e = Engine(0)
     e.reserve(272, 480, 3, 64)
-    for (h, w) in ((8, 8), (40, 56), (72, 96), (136, 200), (264, 472)):
+    for (h, w) in ((8, 8), (40, 56), (72, 96), (136, 200), (264, 472), (33, 68), (64, 128), (31, 132), (96, 36), (30, 50)):
         rng = np.random.default_rng(h * 1000 + w + radius)
         a = rng.uniform(0, 1, size=(h, w)).astype(np.float32)
         b = (np.round(rng.uniform(0, 1, size=(h, w)) * 6) / 6).astype(np.float32)
