@@ -5,6 +5,8 @@
 #include "common.h"
 #include "lg_misc.h"
 
+#include "assign_sweep.h"
+
 namespace im {
 
 // ---------------------------------------------------------------------------------------------------------
@@ -332,53 +334,14 @@ hipError_t launch_lg_select_layer(LGState* st, int n_pairs, int n_layers, int* s
 // loads; rows reduce across the lanes of a wave, columns inside a lane over the block's rows):
 //   lse_stats  : row (max, log sum exp) complete per block; column (max, sum) partials per 16-row strip -> col_lse_combine
 //   best_sweep : with both normalisers known, row arg-max complete per block; column arg-max partials per strip -> col_best_combine
-static constexpr int AS_ROWS = 16;       // rows per block (= per strip of the column partials)
-static constexpr int AS_CHUNK = 1024;    // columns a wave takes per pass: 4 x (64 lanes x float4)
-static constexpr float AS_NEG = -3.0e38f;  // stands in for -inf on masked entries (finite: no inf - inf in the online merges)
-
-// the arguments of pair `pr` of a batch (blockIdx.y of every assignment kernel): every buffer is laid out [pair][...]
-__device__ __forceinline__ AssignArgs for_pair(AssignArgs a, int pr) {
-    a.sim += (long)pr * a.sim_ps;
-    a.m_ptr += (long)pr * a.state_ps; a.n_ptr += (long)pr * a.state_ps;
-    if (a.lz0) { a.lz0 += (long)pr * a.lz_ps; a.lz1 += (long)pr * a.lz_ps; }
-    a.rmax += (long)pr * a.vec_ps; a.rlog += (long)pr * a.vec_ps; a.cmax += (long)pr * a.vec_ps; a.clog += (long)pr * a.vec_ps;
-    a.ridx += (long)pr * a.vec_ps; a.rval += (long)pr * a.vec_ps; a.cbest += (long)pr * a.vec_ps;
-    a.part += (long)pr * a.part_ps;
-    if (a.ind0) { a.ind0 += (long)pr * a.out_ps; a.ind1 += (long)pr * a.out_ps; }
-    a.out_m0 += (long)pr * a.out_ps; a.out_m1 += (long)pr * a.out_ps; a.out_s0 += (long)pr * a.out_ps; a.out_s1 += (long)pr * a.out_ps;
-    return a;
-}
-
-// 16 values of row `p` (chunk base c0): columns c0 + q * 256 + lane * 4 + e; entries >= n read as AS_NEG. Branch-free: a quad that
-// starts past the row's end is loaded from the row's last quad instead and masked (n = 0 masks the whole row: callers pass that for
-// rows past the strip's end). With the loads behind `if (j < n)` every load was a basic block of its own, the compiler collected the
-// loads of all 16 rows of a strip at the top of the chunk loop, and the sweeps needed 284-320 registers: one wave per SIMD.
-template <bool VEC>
-__device__ __forceinline__ void load_row16(const float* __restrict__ p, int c0, int lane, int n, float (&x)[16]) {
-    const int last = max(n - 1, 0);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int j = c0 + q * 256 + lane * 4;
-        if constexpr (VEC) {
-            const float4 v = *reinterpret_cast<const float4*>(p + min(j, last & ~3));   // ld % 4 == 0: the quad lies inside the row's storage
-            x[4 * q] = (j < n) ? v.x : AS_NEG; x[4 * q + 1] = (j + 1 < n) ? v.y : AS_NEG;
-            x[4 * q + 2] = (j + 2 < n) ? v.z : AS_NEG; x[4 * q + 3] = (j + 3 < n) ? v.w : AS_NEG;
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) x[4 * q + e] = (j + e < n) ? p[min(j + e, last)] : AS_NEG;
-        }
-    }
-}
-
-// exp of a non-positive difference to a running maximum: v_exp_f32 on x * log2(e) (2 instructions instead of expf's ~12; the
-// sweeps below evaluate 2.3 of them per matrix entry). Relative error <= 2^-22 for |x| < 16, growing with |x| * 2^-24.
-__device__ __forceinline__ float fexp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+// (AS_* constants, for_pair, load_row16, fexp, assign_score: assign_sweep.h, shared with the one-pair-per-launch forms in lg_assign_pipe.hip)
 
 // The running (max, sum) of the strip's 16 rows live in LDS between row groups ([row][thread]: every thread touches its own slots only,
 // no synchronisation), so that the row groups are a real loop - four rows of loads in flight, then their arithmetic - instead of 16 rows
 // of registers: 320 -> 118 registers (four waves per SIMD instead of one), same operations in the same order (results bit-identical).
 template <bool VEC>
-__global__ __launch_bounds__(256, VEC ? 4 : 3) void lse_stats_kernel(AssignArgs aa) {
+__global__ __launch_bounds__(256, 3) void lse_stats_kernel(AssignArgs aa) {      // (four blocks per CU = 128 registers: 5 of them spilled since the
+                                                                                  // row group's 16 loads are issued together, round 5)
     __shared__ float2 rs[AS_ROWS][4];
     __shared__ float2 rst[AS_ROWS][256];
     const AssignArgs a = for_pair(aa, blockIdx.y);
@@ -400,11 +363,9 @@ __global__ __launch_bounds__(256, VEC ? 4 : 3) void lse_stats_kernel(AssignArgs 
 #pragma unroll 1
         for (int g = 0; g < AS_ROWS / 4; ++g) {
             float x[4][16];
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const int r = 4 * g + rr;      // rows past the strip's end: clamped address, every column masked
-                load_row16<VEC>(sim + (long)min(i0 + r, m - 1) * ld, c0, lane, r < nrow ? n : 0, x[rr]);
-            }
+            // rows past the strip's end: clamped address, every column masked
+            load_rows16<VEC, 4>([&](int rr) { return sim + (long)min(i0 + 4 * g + rr, m - 1) * ld; },
+                                [&](int rr) { return 4 * g + rr < nrow ? n : 0; }, c0, lane, x);
             // rows: one online step per row with the lane's 16 entries
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
@@ -427,14 +388,23 @@ __global__ __launch_bounds__(256, VEC ? 4 : 3) void lse_stats_kernel(AssignArgs 
                 cM[e] = nm;
             }
         }
+        // the strip's column partials: a lane's four columns of a quad are 32 contiguous bytes, the wave's 2 KB - two 16-byte stores per
+        // quad (eight 8-byte stores scattered over the same 2 KB before: a quarter of every store instruction's bytes)
         float2* cp = cpart + (long)blockIdx.x * kmax;
+        const bool pvec = (kmax & 1) == 0;          // 16-byte aligned strip rows (block-uniform)
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < 4; ++q) {
+            const int j = c0 + q * 256 + lane * 4;
+            if (pvec && j + 3 < n) {
+                float4* d = reinterpret_cast<float4*>(cp + j);
+                d[0] = make_float4(cM[4 * q], cS[4 * q], cM[4 * q + 1], cS[4 * q + 1]);
+                d[1] = make_float4(cM[4 * q + 2], cS[4 * q + 2], cM[4 * q + 3], cS[4 * q + 3]);
+            } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int j = c0 + q * 256 + lane * 4 + e;
-                if (j < n) cp[j] = make_float2(cM[4 * q + e], cS[4 * q + e]);   // rows >= nrow contributed exp(AS_NEG - max) = 0
+                for (int e = 0; e < 4; ++e)
+                    if (j + e < n) cp[j + e] = make_float2(cM[4 * q + e], cS[4 * q + e]);   // rows >= nrow contributed exp(AS_NEG - max) = 0
             }
+        }
     }
 #pragma unroll 4
     for (int r = 0; r < AS_ROWS; ++r) {
@@ -457,6 +427,10 @@ __global__ __launch_bounds__(256, VEC ? 4 : 3) void lse_stats_kernel(AssignArgs 
 static constexpr int CC_COLS = 32, CC_GROUPS = 8;
 
 __global__ __launch_bounds__(256) void col_lse_combine_kernel(AssignArgs aa) {
+    // Products are rounded, then added - never fused. Whether `a + b * c` becomes one fused operation is otherwise the compiler's choice per
+    // code shape: with the loads behind branches (rounds 3-4) nothing here was fused, with the grouped loads below five of the eight products
+    // were - a last-bit change of clog and, through it, of every matching score. (`__fmul_rn` / `__fadd_rn` do not prevent it on this toolchain.)
+#pragma clang fp contract(off)
     __shared__ float2 red[CC_GROUPS][CC_COLS];
     const AssignArgs a = for_pair(aa, blockIdx.y);
     const float2* __restrict__ cpart = a.part;
@@ -470,12 +444,13 @@ __global__ __launch_bounds__(256) void col_lse_combine_kernel(AssignArgs aa) {
     float M = AS_NEG, S = 0.f;
     if (j < n)
         for (int s0 = g; s0 < ns; s0 += 8 * CC_GROUPS) {
-            float2 p[8];
+            float2 p[8];      // eight loads in flight: clamped address + fence + mask (behind `sidx < ns ? .. : ..` each load was a branch with its own wait)
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int sidx = s0 + u * CC_GROUPS;
-                p[u] = sidx < ns ? cpart[(long)sidx * kmax + j] : make_float2(AS_NEG, 0.f);
-            }
+            for (int u = 0; u < 8; ++u) p[u] = cpart[(long)min(s0 + u * CC_GROUPS, ns - 1) * kmax + j];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (s0 + u * CC_GROUPS >= ns) p[u] = make_float2(AS_NEG, 0.f);
             float mx = p[0].x;
 #pragma unroll
             for (int u = 1; u < 8; ++u) mx = fmaxf(mx, p[u].x);
@@ -504,14 +479,6 @@ __global__ __launch_bounds__(256) void logsig_kernel(const float* __restrict__ z
                                                       float* __restrict__ lz) {
     const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
     if (i < st[b >> 1].n[b & 1]) lz[(long)b * bstride + i] = log_sigmoid(z[(long)b * bstride + i]);
-}
-
-// MODE 0 (LightGlue): score = log_softmax_row + log_softmax_col + certainties
-// MODE 1 (SuperGlue, `superglue.py:160, 185`): score = ((x + u_i) + v_j) - norm, with u in rmax, v in cmax, norm in *rlog
-template <int MODE>
-__device__ __forceinline__ float assign_score(float x, float rm, float rl, float cm, float cl, float l0, float l1) {
-    if constexpr (MODE == 0) return (((x - rm) - rl) + ((x - cm) - cl)) + (l0 + l1);
-    else return ((x + rm) + cm) - rl;
 }
 
 // One sweep: row arg-max (first column among ties: torch.max semantics) complete per block; per-strip column arg-max keys
@@ -562,10 +529,8 @@ __global__ __launch_bounds__(256, 3) void best_sweep_kernel(AssignArgs aa) {
 #pragma unroll 1
         for (int g = 0; g < AS_ROWS / 2; ++g) {      // two rows per trip: 155 registers = three waves per SIMD (four rows: 187 = two)
             if (2 * g >= nrow) break;     // block-uniform
-            float x[2][16];
-#pragma unroll
-            for (int rr = 0; rr < 2; ++rr)      // two rows = 8 sixteen-byte loads in flight per lane
-                load_row16<VEC>(sim + (long)min(i0 + 2 * g + rr, m - 1) * ld, c0, lane, n, x[rr]);
+            float x[2][16];      // two rows = 8 sixteen-byte loads in flight per lane
+            load_rows16<VEC, 2>([&](int rr) { return sim + (long)min(i0 + 2 * g + rr, m - 1) * ld; }, [&](int) { return n; }, c0, lane, x);
 #pragma unroll
             for (int rr = 0; rr < 2; ++rr) {
                 const int r = 2 * g + rr;
@@ -580,7 +545,8 @@ __global__ __launch_bounds__(256, 3) void best_sweep_kernel(AssignArgs aa) {
                         const int j = c0 + q * 256 + lane * 4 + e;
                         const int k = 4 * q + e;
                         const float v = assign_score<MODE>(x[rr][k], rm, rl, cm[k], cl[k], l0, l1[k]);
-                        if (j < n) {
+                        if (j < n) {      // (as selects instead of branches this kernel spills 1,700 registers at its 168-register budget; the
+                            // one-pair form in lg_assign_pipe.hip, which has the whole register file, is branch-free)
                             if (v > bv || bj == 0x7fffffff) { bv = v; bj = j; }      // ascending j in a lane's visit order
                             if (v > cbv[k] || cbi[k] < 0) { cbv[k] = v; cbi[k] = i0 + r; }
                         }
@@ -590,13 +556,24 @@ __global__ __launch_bounds__(256, 3) void best_sweep_kernel(AssignArgs aa) {
             }
         }
         unsigned long long* cb = cbpart + (long)blockIdx.x * kmax;
+        const bool pvec = (kmax & 1) == 0;          // as in lse_stats_kernel: two 16-byte stores per quad
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < 4; ++q) {
+            const int j = c0 + q * 256 + lane * 4;
+            unsigned long long key[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int j = c0 + q * 256 + lane * 4 + e;
-                if (j < n) cb[j] = ((unsigned long long)f2ord(cbv[4 * q + e]) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)cbi[4 * q + e]);
+            for (int e = 0; e < 4; ++e)
+                key[e] = ((unsigned long long)f2ord(cbv[4 * q + e]) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)cbi[4 * q + e]);
+            if (pvec && j + 3 < n) {
+                ulonglong2* d = reinterpret_cast<ulonglong2*>(cb + j);
+                d[0] = make_ulonglong2(key[0], key[1]);
+                d[1] = make_ulonglong2(key[2], key[3]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (j + e < n) cb[j + e] = key[e];
             }
+        }
     }
     // rows: lanes / chunks visit columns out of order, so ties resolve on the column index explicitly
 #pragma unroll 4
@@ -640,12 +617,13 @@ __global__ __launch_bounds__(256) void col_best_combine_kernel(AssignArgs aa) {
     unsigned long long best = 0ull;
     if (j < n)
         for (int s0 = g; s0 < ns; s0 += 8 * CC_GROUPS) {
-            unsigned long long k[8];
+            unsigned long long k[8];      // as in col_lse_combine_kernel: eight loads in flight
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int sidx = s0 + u * CC_GROUPS;
-                k[u] = sidx < ns ? cbpart[(long)sidx * kmax + j] : 0ull;
-            }
+            for (int u = 0; u < 8; ++u) k[u] = cbpart[(long)min(s0 + u * CC_GROUPS, ns - 1) * kmax + j];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (s0 + u * CC_GROUPS >= ns) k[u] = 0ull;
 #pragma unroll
             for (int u = 0; u < 8; ++u) best = k[u] > best ? k[u] : best;
         }
@@ -714,14 +692,20 @@ hipError_t launch_assign(const AssignArgs& a, hipStream_t s) {
     const int nstrips = (kr + AS_ROWS - 1) / AS_ROWS;
     const bool vec = (a.ld % 4) == 0 && (reinterpret_cast<uintptr_t>(a.sim) % 16) == 0 && (a.sim_ps % 4) == 0;
     const dim3 gs(nstrips, P), gc((kc + CC_COLS - 1) / CC_COLS, P);
+    // one pair per launch and at most ~one strip block per CU (4096 keypoints: 256 strips): the software-pipelined forms of the two sweeps
+    // (bit-identical; they take the whole register file, so only where there is one wave per SIMD anyway)
+    const bool pipe = vec && P == 1 && nstrips <= 384;
     if (a.mode == 0) {
-        if (vec) hipLaunchKernelGGL(lse_stats_kernel<true>, gs, dim3(256), 0, s, a);
+        if (pipe) launch_lse_stats_pipe(a, gs, s);
+        else if (vec) hipLaunchKernelGGL(lse_stats_kernel<true>, gs, dim3(256), 0, s, a);
         else hipLaunchKernelGGL(lse_stats_kernel<false>, gs, dim3(256), 0, s, a);
         hipLaunchKernelGGL(col_lse_combine_kernel, gc, dim3(256), 0, s, a);
-        if (vec) hipLaunchKernelGGL((best_sweep_kernel<0, true>), gs, dim3(256), 0, s, a);
+        if (pipe) launch_best_sweep_pipe(a, gs, s);
+        else if (vec) hipLaunchKernelGGL((best_sweep_kernel<0, true>), gs, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((best_sweep_kernel<0, false>), gs, dim3(256), 0, s, a);
     } else {  // optimal transport: rmax = u, cmax = v, rlog[0] = norm were produced by the Sinkhorn sweeps
-        if (vec) hipLaunchKernelGGL((best_sweep_kernel<1, true>), gs, dim3(256), 0, s, a);
+        if (pipe) launch_best_sweep_pipe(a, gs, s);
+        else if (vec) hipLaunchKernelGGL((best_sweep_kernel<1, true>), gs, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((best_sweep_kernel<1, false>), gs, dim3(256), 0, s, a);
     }
     hipLaunchKernelGGL(col_best_combine_kernel, gc, dim3(256), 0, s, a);

@@ -192,33 +192,39 @@ __global__ __launch_bounds__(SK4_T, 1) void sinkhorn_fused4_kernel(const float* 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int G = gridDim.x;
     float cS[4 * SK4_Q];
+    const unsigned voff = (unsigned)tid * 16u;
+    {
+        // v -> LDS (times log2 e, masked columns very negative): eight range-checked 16-byte loads in flight per lane. As `j < n ? v[j] : ..`
+        // per element this was 32 dword loads behind 32 exec-masked branches, each waited for on its own: ~9 us of every launch (round 5)
+        const __amdgpu_buffer_rsrc_t rv = gmake_rsrc(v, (unsigned)n * 4u);
+        float4 vq[SK4_Q];
 #pragma unroll
-    for (int q = 0; q < SK4_Q; ++q) {
-        const int j = q * (SK4_T * 4) + tid * 4;
-        sv[q * SK4_T + tid] = make_float4(j < n ? v[j] * SK_L2E : SKF_NEG, j + 1 < n ? v[j + 1] * SK_L2E : SKF_NEG,
-                                          j + 2 < n ? v[j + 2] * SK_L2E : SKF_NEG, j + 3 < n ? v[j + 3] * SK_L2E : SKF_NEG);
+        for (int q = 0; q < SK4_Q; ++q) vq[q] = gbuf_load4(rv, voff, (unsigned)q * (SK4_T * 16u));
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) cS[4 * q + e] = 0.f;
+        for (int q = 0; q < SK4_Q; ++q) {
+            const int j = q * (SK4_T * 4) + tid * 4;
+            sv[q * SK4_T + tid] = make_float4(j < n ? vq[q].x * SK_L2E : SKF_NEG, j + 1 < n ? vq[q].y * SK_L2E : SKF_NEG,
+                                              j + 2 < n ? vq[q].z * SK_L2E : SKF_NEG, j + 3 < n ? vq[q].w * SK_L2E : SKF_NEG);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) cS[4 * q + e] = 0.f;
+        }
     }
     const float bin2 = (alpha + v[n]) * SK_L2E;
     float bS = 0.f;                                   // dustbin column (thread 0)
     const float norm = sg_norm(m, n);
     float4 ra[SK4_Q], rb[SK4_Q], rc[SK4_Q], rd[SK4_Q];
-    const unsigned voff = (unsigned)tid * 16u;
+    // a REAL row (< m) through a range-checked descriptor; a row past the last one gets a descriptor of zero records - the loads are issued all
+    // the same and return zeros that nothing uses (weight 0 in `step`). No branch here: with the dustbin row filled in behind `if (row >= m)`
+    // the two paths met in register copies right behind the loads, i.e. every prefetched row was waited for as soon as it had been requested.
     auto load_row = [&](int row, float4 (&buf)[SK4_Q]) {
-        if (row >= m) {
-#pragma unroll
-            for (int q = 0; q < SK4_Q; ++q) buf[q] = make_float4(alpha, alpha, alpha, alpha);
-            return;
-        }
-        const __amdgpu_buffer_rsrc_t rs = gmake_rsrc(sim + (long)row * ld, (unsigned)n * 4u);
+        const __amdgpu_buffer_rsrc_t rs = gmake_rsrc(sim + (long)min(row, m - 1) * ld, row < m ? (unsigned)n * 4u : 0u);
 #pragma unroll
         for (int q = 0; q < SK4_Q; ++q) buf[q] = gbuf_load4(rs, voff, (unsigned)q * (SK4_T * 16u));
     };
-    // rows iA and iB = iA + G (iB > m: absent); on return A and B hold the exponentials exp2(t - lane maximum)
-    auto step = [&](int iA, float4 (&A)[SK4_Q], float4 (&B)[SK4_Q], int parity) {
+    // rows iA and iB = iA + G (hasB false: absent); on return A and B hold the exponentials exp2(t - lane maximum)
+    auto step = [&](int iA, float4 (&A)[SK4_Q], float4 (&B)[SK4_Q], int parity, bool hasB) {
         const int iB = iA + G;
-        const bool hasB = iB <= m;
         float mA = SKF_NEG, mB = SKF_NEG;
 #pragma unroll
         for (int q = 0; q < SK4_Q; ++q) {
@@ -270,20 +276,35 @@ __global__ __launch_bounds__(SK4_T, 1) void sinkhorn_fused4_kernel(const float* 
         }
         if (tid == 0) bS = fmaf(ebB, fB, fmaf(ebA, fA, bS));
     };
+    // the block's real rows i = blockIdx.x, + G, .. < m, two per step, the next step's two rows in flight behind the current step's arithmetic
     int i = blockIdx.x;
-    load_row(i, ra);
-    load_row(min(i + G, m), rb);
-    for (;;) {
-        const bool more = i + 2 * G <= m;
-        if (more) { load_row(i + 2 * G, rc); load_row(min(i + 3 * G, m), rd); }
-        step(i, ra, rb, 0);
-        i += 2 * G;
-        if (!more) break;
-        const bool more2 = i + 2 * G <= m;
-        if (more2) { load_row(i + 2 * G, ra); load_row(min(i + 3 * G, m), rb); }
-        step(i, rc, rd, 1);
-        i += 2 * G;
-        if (!more2) break;
+    int parity = 0;
+    if (i < m) {
+        load_row(i, ra);
+        load_row(i + G, rb);
+        for (;;) {
+            // (the prefetch is unconditional - rows past the end come back as zeros through their empty descriptors: behind `if (more)` the
+            // loaded and the not-loaded path met in 64 register copies right behind the loads, which waited for every one of them)
+            const bool more = i + 2 * G < m;
+            load_row(i + 2 * G, rc); load_row(i + 3 * G, rd);
+            step(i, ra, rb, 0, i + G < m);
+            parity = 1;
+            i += 2 * G;
+            if (!more) break;
+            const bool more2 = i + 2 * G < m;
+            load_row(i + 2 * G, ra); load_row(i + 3 * G, rb);
+            step(i, rc, rd, 1, i + G < m);
+            parity = 0;
+            i += 2 * G;
+            if (!more2) break;
+        }
+    }
+    // the dustbin row (index m, every entry = alpha, weight n): the last row of the block that owns it, a step of its own without loads - the
+    // same arithmetic in the same order as when it rode in the B slot of that block's last step (an absent B adds exactly 0 to every sum)
+    if ((int)blockIdx.x == m % G) {
+#pragma unroll
+        for (int q = 0; q < SK4_Q; ++q) ra[q] = make_float4(alpha, alpha, alpha, alpha);
+        step(m, ra, rb, parity, false);
     }
     // column partials of this block: whole 16-byte quads (pstride % 4 == 0), streamed past L2 (the combine kernel is the only reader, on
     // other CUs; 16.8 MB of dirty lines at the kernel boundary cost 3 us, MI355X_MICROARCH.md "boundary"). The dustbin column's sum sits

@@ -694,7 +694,10 @@ def test_kernels_keep_their_register_budget(tmp_path):
     """Occupancy is a property of the compiled code, not of the source: the assignment sweeps once needed 284-320 registers (every row
     load a basic block of its own, all of a strip's loads collected at the top of the loop) and ran at one wave per SIMD whatever the
     grid. Compile the HBM / latency-bound kernels' file for gfx950 (no GPU needed) and hold every kernel to the budget its launch
-    bounds promise: no scratch spills, `lse_stats` <= 128 VGPRs (four waves per SIMD), `best_sweep` <= 168 (three)."""
+    bounds promise: no scratch spills, `lse_stats` and `best_sweep` <= 168 VGPRs (three waves per SIMD; `lse_stats` was held at 128 = four
+    waves until round 5 found WHY it fitted: the compiler reused one 4-register temporary for all 16 row loads of a group and waited for each
+    load on its own - one kilobyte in flight per wave). So the listing is also checked for what the budget is for: in each sweep at least
+    eight 16-byte row loads are issued back to back before the first wait."""
     hipcc = "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("no hipcc")
@@ -713,8 +716,19 @@ def test_kernels_keep_their_register_budget(tmp_path):
     lse = [v for k, v in seen.items() if "lse_stats_kernelILb1" in k]
     best = [v for k, v in seen.items() if "best_sweep_kernel" in k]
     assert lse and best
-    assert all(v <= 128 for v, _ in lse), lse
+    assert all(v <= 168 for v, _ in lse), lse
     assert all(v <= 168 for v, _ in best), best
+    text = out.read_text()
+    for sym in ("_ZN2im16lse_stats_kernelILb1EEEvNS_10AssignArgsE", "_ZN2im17best_sweep_kernelILi0ELb1EEEvNS_10AssignArgsE",
+                "_ZN2im22col_lse_combine_kernelENS_10AssignArgsE", "_ZN2im23col_best_combine_kernelENS_10AssignArgsE"):
+        body = text[text.index(sym + ":"):]
+        body = body[:body.index(".Lfunc_end")]
+        mem = [l.strip() for l in body.split("\n") if l.strip().startswith(("global_load_dwordx4", "global_load_dwordx2", "s_waitcnt vmcnt"))]
+        run = best_run = 0
+        for l in mem:
+            run = run + 1 if l.startswith("global_load") else 0
+            best_run = max(best_run, run)
+        assert best_run >= 8, (sym, best_run)      # loads in flight together, not one at a time
     # the Winograd convolution: every instantiation at two waves per SIMD (<= 256 registers) without scratch
     out2 = tmp_path / "conv_wino.s"
     r = subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only", "-I" + os.path.join(ROOT, "include"),
