@@ -147,6 +147,9 @@ __device__ __forceinline__ void dma16(wu32x4 rsrc, unsigned lds_byte_addr, unsig
 }
 #pragma clang diagnostic pop
 #define IM_DMA_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+// the same when eight register loads (the next slab's U fragments) were issued BEHIND the transfers: loads return in order, so "at most
+// eight outstanding" means the transfers have landed while the U loads stay in flight across the barrier (round 5)
+#define IM_DMA_WAIT_BEFORE_8_LOADS() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
 
 template <bool POOL, bool FUSE1A, bool UREG>
 __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
@@ -369,26 +372,26 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
     // slab 0 is peeled so that its first MFMAs start the accumulators from a literal zero: zeroing 128 registers ahead of the
     // loop was 256 v_mov per wave (the compiler emitted the zeroing twice), a fifth of the kernel's non-MFMA vector instructions,
     // and fp32 MFMA and VALU never co-execute on this part
-#define IM_USTEP(slab, FIRST, ucur, unext)                                                              \
+#define IM_USTEP(slab, FIRST, ucur, unext, LAST)                                                        \
     {                                                                                                   \
-        if ((slab) + 1 < nslab) {                                                                       \
+        if (!(LAST)) {                                                                                  \
             if constexpr (!RESIDENT) IM_SSTAGE((slab) + 1)                                              \
             IM_ULOAD(unext, (slab) + 1)                                                                 \
         }                                                                                               \
         IM_SMMA_U(slab, FIRST, ucur)                                                                    \
         if constexpr (!FUSE1A && !RESIDENT) {                                                           \
             __builtin_amdgcn_sched_barrier(0);                                                          \
-            IM_DMA_WAIT();                                                                              \
+            if (LAST) IM_DMA_WAIT(); else IM_DMA_WAIT_BEFORE_8_LOADS();                                 \
         }                                                                                               \
         if constexpr (!RESIDENT) __syncthreads();      /* resident patch + U in registers: nothing to wait for */ \
     }
     if constexpr (UREG) {      // two register sets of U alternate: steps in pairs (nslab is even)
-        IM_USTEP(0, true, uA, uB)
+        IM_USTEP(0, true, uA, uB, false)
         for (int slab = 1; slab + 1 < nslab; slab += 2) {
-            IM_USTEP(slab, false, uB, uA)
-            IM_USTEP(slab + 1, false, uA, uB)
+            IM_USTEP(slab, false, uB, uA, false)
+            IM_USTEP(slab + 1, false, uA, uB, false)
         }
-        IM_USTEP(nslab - 1, false, uB, uA)
+        IM_USTEP(nslab - 1, false, uB, uA, true)
     } else {
         IM_SSTEP(0, true)
         for (int slab = 1; slab < nslab; ++slab) IM_SSTEP(slab, false)
