@@ -1,10 +1,10 @@
 #!/bin/bash
 # Runs the measurement passes behind profiles/ on the GPU box (one gpurun call):
-#   /usr/local/graft/bin/gpurun --timeout 3000 -- 'bash tools/collect_profiles.sh r04'
+#   /usr/local/graft/bin/gpurun --timeout 3000 -- 'bash tools/collect_profiles.sh r05'
 # rocprofv3 wants cwd=/tmp and TMPDIR=/tmp on this pool; PMC passes are separate runs with --kernel-trace only.
 # A second argument "core" re-measures only what a kernel change moves (bench lines, traces, counters of the LightGlue pair, parity
 # report) and leaves the rehearsal / SuperGlue / per-phase files of the last full collection in place.
-tag=${1:-r04}
+tag=${1:-r05}
 mode=${2:-full}
 root=${GRAFT_REPO_ROOT:-/root/repo}
 out=$root/gpurun_out/$tag
@@ -26,7 +26,11 @@ IM_BENCH_ONE_DEVICE=1 python3 $root/bench.py --gpus 2 --steps 40 --warmup 10 --n
 # the shape of the first 8-GPU lease on the one device of this box: eight ranks, gloo, 32 pairs each of configs[3]
 IM_BENCH_ONE_DEVICE=1 python3 $root/bench.py --gpus 8 --config 4 --steps 32 --warmup 4 --no-cpu-baseline --no-side-measurements > $out/bench_config4_8ranks_one_device_gloo.json 2> $out/bench_8ranks.err
 python3 $root/tools/profile_match_call.py > $out/match_call_phases.txt 2>&1
-python3 $root/tools/bench_sinkhorn.py > $out/sinkhorn_forms.txt 2>&1
+python3 $root/tools/bench_sinkhorn.py > $out/sinkhorn.txt 2>&1
+python3 $root/tools/bench_nms.py > $out/nms.txt 2>&1
+python3 $root/tools/bench_assign.py > $out/assign.txt 2>&1
+python3 $root/tools/bench_assign_pairs.py >> $out/assign.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_assign -- python3 $root/tools/bench_assign.py > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_config5 -- python3 $root/bench.py --config 5 --steps 3 --warmup 1 > $out/bench_config5_under_rocprof.json 2> /dev/null
 fi
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -37,5 +41,6 @@ done
 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $out/pmc_sq_all -- python3 $root/tools/run_pair_once.py lightglue 2 > /dev/null 2>&1
 cd $root
 python3 tests/parity_report.py --epochs 30 --superglue --out $out/parity_winograd.json > $out/parity_winograd.log 2>&1
+python3 tests/parity_report.py --adaptive 10 --out $out/parity_adaptive_10epochs.json > $out/parity_adaptive.log 2>&1
 [ "$mode" = full ] && IM_CONV_DIRECT=1 python3 tests/parity_report.py --out $out/parity_direct_conv.json > $out/parity_direct_conv.log 2>&1
 python3 tools/summarize_profiles.py $tag

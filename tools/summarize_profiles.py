@@ -1,7 +1,7 @@
 """Condenses the rocprofv3 outputs of tools/collect_profiles.sh (gpurun_out/<tag>/) into the small files kept under profiles/:
 per-kernel duration tables (median / mean over the launches of the kernel trace) and PMC-derived HBM traffic per launch."""
 import collections, csv, glob, json, os, statistics, sys
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, "gpurun_out", tag), os.path.join(root, "profiles")
 
@@ -28,7 +28,7 @@ def durations(sub):
 
 
 for sub, outname in (("stats1", f"{tag}_kernel_stats_streams1_batch1.csv"), ("stats_default", f"{tag}_kernel_stats_default.csv"),
-                     ("stats_config5", f"{tag}_kernel_stats_config5.csv")):
+                     ("stats_config5", f"{tag}_kernel_stats_config5.csv"), ("stats_assign", f"{tag}_kernel_stats_assign_one_pair.csv")):
     d = durations(sub)
     if not d:
         continue
@@ -97,7 +97,7 @@ for fn in newest(glob.glob(f"{src}/pmc_sq_all/**/*counter_collection.csv", recur
 for name in ("bench.json", "bench_streams1_under_rocprof.json", "bench_default_under_rocprof.json", "bench_config5.json", "bench_config3.json", "bench_steps20_warmup5.json",
              "bench_config5_under_rocprof.json", "parity_winograd.json", "parity_direct_conv.json", "bench_config4_1gpu_256epochs.json",
              "bench_config4_nccl_world1.json", "bench_2ranks_one_device_gloo.json", "bench_config4_8ranks_one_device_gloo.json",
-             "match_call_phases.txt", "sinkhorn_forms.txt"):
+             "match_call_phases.txt", "sinkhorn.txt", "nms.txt", "assign.txt", "parity_adaptive_10epochs.json"):
     p = os.path.join(src, name)
     if os.path.exists(p) and os.path.getsize(p):
         open(os.path.join(dst, f"{tag}_{name}"), "w").write(open(p).read())
