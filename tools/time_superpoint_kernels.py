@@ -4,6 +4,7 @@
 tools/build_variant.sh). Each library runs in its own child process (ICEMATCH_LIB is read at import).
 
     python tools/time_superpoint_kernels.py [build_abl/<name>/libicematch.so ...]      (no argument: the in-tree library)
+    IM_TSK_IMAGES=20 python tools/time_superpoint_kernels.py ...     the same for ten pairs per launch (times per forward of 20 images)
 """
 import ctypes
 import json
@@ -22,8 +23,9 @@ def child():
     eng = Engine(0)
     eng.load_state_dict("superpoint", synthetic.superpoint_state_dict(0))
     a, b = synthetic.stereo_pair(0, 1080, 1920)
-    img = torch.from_numpy(__import__("numpy").stack([a, b])).cuda()
-    eng.reserve(1080, 1920, 2, 4096)
+    n_img = int(os.environ.get("IM_TSK_IMAGES", "2"))
+    img = torch.from_numpy(__import__("numpy").stack([a, b])).cuda().repeat(n_img // 2, 1, 1).contiguous()
+    eng.reserve(1080, 1920, n_img, 4096)
     for _ in range(4):
         eng.superpoint(img, max_kpts=4096)
     torch.cuda.synchronize()
