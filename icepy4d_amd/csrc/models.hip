@@ -328,7 +328,8 @@ int im_ctx_reserve(im_ctx* ctx, int max_h, int max_w, int max_images, int max_kp
     A(ws->supp, (size_t)B * H8 * W8);
     A(ws->kpsel.n_cand, (sel_state_bytes((int)B) + 3) / 4);
     A(ws->kpsel.keys, (size_t)B * H8 * W8);
-    A(ws->kpsel.ties, (size_t)B * H8 * W8);
+    ws->kpsel.ties_cap = (size_t)B * (H8 + 32) * (W8 + 64);      // whole 32 x 64 tiles per image: the candidate staging of the last NMS round
+    A(ws->kpsel.ties, ws->kpsel.ties_cap);
     A(ws->kpsel.chosen, (size_t)B * K);
     // matcher buffers: NP pairs = 2 NP images side by side (batch over pairs: one launch serves every pair)
     const size_t NP = (size_t)(B + 1) / 2, NI = 2 * NP;

@@ -9,6 +9,7 @@ struct SelBuffers {
     unsigned long long* keys = nullptr;
     unsigned long long* ties = nullptr;
     unsigned long long* chosen = nullptr;
+    size_t ties_cap = 0;   // entries of `ties`: also the per-tile staging of the candidate keys (32 x 64 entries per NMS tile), while it is free
 };
 size_t sel_state_bytes(int B);
 hipError_t ensure_dyn_lds(const void* fn, size_t bytes, size_t* cache);   // cache: static size_t [IM_MAX_DEVICES] of the call site

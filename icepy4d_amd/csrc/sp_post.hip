@@ -222,7 +222,8 @@ __global__ __launch_bounds__(nr::NT) void nms_round_kernel(const float* __restri
                                                            unsigned char* __restrict__ keep_out, float* __restrict__ out, int H, int W, int WW,
                                                            int tiles_x, int tiles_per_img, int total_tiles, int border, float thr,
                                                            unsigned long long* __restrict__ keys, long key_stride, int* __restrict__ n_cand,
-                                                           SelState* __restrict__ sel) {
+                                                           SelState* __restrict__ sel, unsigned long long* __restrict__ gstage,
+                                                           int* __restrict__ tile_cnt) {
     using namespace nr;
     constexpr int SR = TH + 2 * R;                  // rows of S: y0 - R .. y0 + TH + R - 1
     constexpr int KR = TH + 4 * R;                  // rows of the previous mask: y0 - 2R ..
@@ -386,12 +387,19 @@ __global__ __launch_bounds__(nr::NT) void nms_round_kernel(const float* __restri
             }
             __syncthreads();
             n = cnt[0];
-            if (n > 0 && tid == 0) cnt[1] = atomicAdd(&n_cand[b], n);       // its latency hides behind the map store below
+            // where the block's keys go: into the tile's own 2048-entry slot of a staging buffer with its count next to it (cand_compact_kernel
+            // makes the dense list) - or, without staging, behind the image's counter: ONE returning atomic per block on ONE address per
+            // image, ~1000 of them queueing up in L2 while their blocks wait for the answer (~20 of the round's 32 us, round 5)
+            if (!gstage && n > 0 && tid == 0) cnt[1] = atomicAdd(&n_cand[b], n);
             if (n > 0 && lhist[tid]) atomicAdd(&sel[b].hist[0][tid], lhist[tid]);
         }
         if (out && e_on) *reinterpret_cast<float4*>(out + img + (long)gy * W + gx) = make_float4(ov[0], ov[1], ov[2], ov[3]);
         if (out && e_on2) *reinterpret_cast<float4*>(out + img + (long)gy * W + gx + 4) = make_float4(ov[4], ov[5], ov[6], ov[7]);
-        if (n > 0) {
+        if (gstage) {
+            if (tid == 0) tile_cnt[tile_lin] = n;
+            unsigned long long* kd = gstage + (long)tile_lin * (TH * TW);
+            for (int i = tid; i < n; i += NT) kd[i] = stage[i];
+        } else if (n > 0) {
             __syncthreads();
             unsigned long long* kd = keys + (long)b * key_stride + cnt[1];
             for (int i = tid; i < n; i += NT) kd[i] = stage[i];
@@ -642,31 +650,57 @@ static SelState* sel_states(int* n_cand, int B) {
     return reinterpret_cast<SelState*>(reinterpret_cast<char*>(n_cand) + (((size_t)B * sizeof(int) + 15) & ~(size_t)15));
 }
 
+// The dense candidate list of an image from the per-tile slots the last NMS round filled: block (t, b) sums the counts of the tiles in front
+// of its own (<= 16 per lane) and copies its keys behind them; the last tile's block writes the image's count. Tile order instead of arrival
+// order - every consumer of the list ranks or reduces with order-independent integer operations.
+__global__ __launch_bounds__(64) void cand_compact_kernel(const unsigned long long* __restrict__ gstage, const int* __restrict__ tile_cnt,
+                                                         int tiles_per_img, unsigned long long* __restrict__ keys, long key_stride,
+                                                         int* __restrict__ n_cand) {
+    const int t = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    const int* tc = tile_cnt + (long)b * tiles_per_img;
+    int part = 0;
+    for (int i = lane; i < t; i += 64) part += tc[i];
+    const int prefix = wave_sum_i(part);
+    const int n = tc[t];
+    const unsigned long long* src = gstage + ((long)b * tiles_per_img + t) * (nr::TH * nr::TW);
+    unsigned long long* dst = keys + (long)b * key_stride + prefix;
+    for (int j = lane; j < n; j += 64) dst[j] = src[j];
+    if (t == tiles_per_img - 1 && lane == 0) n_cand[b] = prefix + n;
+}
+
 template <int R>
-static hipError_t launch_nms_rounds_r(const float* s, float* out, uint8_t* keep_a, uint8_t* keep_b, int B, int H, int W, int border, float thr,
-                                      unsigned long long* keys, long key_stride, int* n_cand, hipStream_t st) {
+static hipError_t launch_nms_rounds_r(const float* s, float* out, uint8_t* keep_a, uint8_t* keep_b, size_t mask_bytes, int B, int H, int W, int border,
+                                      float thr, unsigned long long* keys, long key_stride, int* n_cand, unsigned long long* gstage, size_t gstage_cap,
+                                      hipStream_t st) {
     const int tx = (W + nr::TW - 1) / nr::TW, ty = (H + nr::TH - 1) / nr::TH, WW = (W + 31) / 32;
     const int total = tx * ty * B;
     const dim3 grid(((total + 7) / 8) * 8), block(nr::NT);
     unsigned* ka = reinterpret_cast<unsigned*>(keep_a);      // [B][H][WW] words in the byte-mask buffers of the staged form (4 WW <= W)
     unsigned* kb = reinterpret_cast<unsigned*>(keep_b);
     SelState* ss = keys ? sel_states(n_cand, B) : nullptr;
+    // per-tile candidate staging (no returning atomic in the last round) when the staging buffer holds a slot per tile and the tile counts fit
+    // behind the bit masks; otherwise the blocks append behind the image's counter
+    const size_t bits = (((size_t)B * H * WW * 4) + 15) & ~(size_t)15;
+    const bool staged = keys && gstage && (size_t)total * (nr::TH * nr::TW) <= gstage_cap && bits + (size_t)total * sizeof(int) <= mask_bytes;
+    int* tile_cnt = staged ? reinterpret_cast<int*>(keep_a + bits) : nullptr;      // (keep_a is read by round 1 only: free again in round 2)
     hipLaunchKernelGGL((nms_round_kernel<R, 0>), grid, block, 0, st, s, (const unsigned*)nullptr, keep_a, (float*)nullptr, H, W, WW, tx, tx * ty, total, border, thr,
-                       (unsigned long long*)nullptr, 0L, (int*)nullptr, (SelState*)nullptr);
+                       (unsigned long long*)nullptr, 0L, (int*)nullptr, (SelState*)nullptr, (unsigned long long*)nullptr, (int*)nullptr);
     hipLaunchKernelGGL((nms_round_kernel<R, 1>), grid, block, 0, st, s, (const unsigned*)ka, keep_b, (float*)nullptr, H, W, WW, tx, tx * ty, total, border, thr,
-                       (unsigned long long*)nullptr, 0L, (int*)nullptr, (SelState*)nullptr);
+                       (unsigned long long*)nullptr, 0L, (int*)nullptr, (SelState*)nullptr, (unsigned long long*)nullptr, (int*)nullptr);
     hipLaunchKernelGGL((nms_round_kernel<R, 2>), grid, block, 0, st, s, (const unsigned*)kb, (unsigned char*)nullptr, out, H, W, WW, tx, tx * ty, total, border, thr,
-                       keys, key_stride, n_cand, ss);
+                       keys, key_stride, n_cand, ss, staged ? gstage : (unsigned long long*)nullptr, tile_cnt);
+    if (staged) hipLaunchKernelGGL(cand_compact_kernel, dim3(tx * ty, B), dim3(64), 0, st, gstage, tile_cnt, tx * ty, keys, key_stride, n_cand);
     return hipGetLastError();
 }
 
-static hipError_t launch_nms_rounds(const float* s, float* out, uint8_t* keep_a, uint8_t* keep_b, int B, int H, int W, int r, int border, float thr,
-                                    unsigned long long* keys, long key_stride, int* n_cand, hipStream_t st) {
+static hipError_t launch_nms_rounds(const float* s, float* out, uint8_t* keep_a, uint8_t* keep_b, size_t mask_bytes, int B, int H, int W, int r, int border,
+                                    float thr, unsigned long long* keys, long key_stride, int* n_cand, unsigned long long* gstage, size_t gstage_cap,
+                                    hipStream_t st) {
     switch (r) {
-        case 1: return launch_nms_rounds_r<1>(s, out, keep_a, keep_b, B, H, W, border, thr, keys, key_stride, n_cand, st);
-        case 2: return launch_nms_rounds_r<2>(s, out, keep_a, keep_b, B, H, W, border, thr, keys, key_stride, n_cand, st);
-        case 3: return launch_nms_rounds_r<3>(s, out, keep_a, keep_b, B, H, W, border, thr, keys, key_stride, n_cand, st);
-        default: return launch_nms_rounds_r<4>(s, out, keep_a, keep_b, B, H, W, border, thr, keys, key_stride, n_cand, st);
+        case 1: return launch_nms_rounds_r<1>(s, out, keep_a, keep_b, mask_bytes, B, H, W, border, thr, keys, key_stride, n_cand, gstage, gstage_cap, st);
+        case 2: return launch_nms_rounds_r<2>(s, out, keep_a, keep_b, mask_bytes, B, H, W, border, thr, keys, key_stride, n_cand, gstage, gstage_cap, st);
+        case 3: return launch_nms_rounds_r<3>(s, out, keep_a, keep_b, mask_bytes, B, H, W, border, thr, keys, key_stride, n_cand, gstage, gstage_cap, st);
+        default: return launch_nms_rounds_r<4>(s, out, keep_a, keep_b, mask_bytes, B, H, W, border, thr, keys, key_stride, n_cand, gstage, gstage_cap, st);
     }
 }
 
@@ -678,7 +712,7 @@ static bool nms_fusable(int H, int W, int r) {
 hipError_t launch_nms(const float* s, float* out, uint8_t* mask, uint8_t* supp, float* rest, int B, int H, int W, int r,
                       hipStream_t st) {
     if (r < 0 || r > NMS_RMAX) return hipErrorInvalidValue;
-    if (nms_fusable(H, W, r)) return launch_nms_rounds(s, out, mask, supp, B, H, W, r, 0, 0.f, nullptr, 0, nullptr, st);
+    if (nms_fusable(H, W, r)) return launch_nms_rounds(s, out, mask, supp, (size_t)B * H * W, B, H, W, r, 0, 0.f, nullptr, 0, nullptr, nullptr, 0, st);
     return launch_nms_staged(s, out, mask, supp, rest, B, H, W, r, st);
 }
 
@@ -706,7 +740,7 @@ hipError_t launch_nms_select(const float* s, float* nms_out, uint8_t* mask, uint
     if (e != hipSuccess) return e;
     const long npix = (long)H * W;
     if (nms_fusable(H, W, r)) {
-        e = launch_nms_rounds(s, nms_out, mask, supp, B, H, W, r, border, thr, sb.keys, npix, sb.n_cand, st);
+        e = launch_nms_rounds(s, nms_out, mask, supp, (size_t)B * H * W, B, H, W, r, border, thr, sb.keys, npix, sb.n_cand, sb.ties, sb.ties_cap, st);
         if (e != hipSuccess) return e;
     } else {
         e = launch_nms_staged(s, nms_out, mask, supp, rest, B, H, W, r, st);
