@@ -300,6 +300,22 @@ def test_committed_bench_line_has_the_contract_fields():
         assert sm["config3_distinct_epochs"]["pairs"] >= 60 and sm["config3_distinct_epochs"]["epochs_distinct_and_in_order"] is True
         assert sm["config5"]["mean_keypoints"] == 16384 and sm["config5"]["sinkhorn"]["solve_ms"] > 0 and sm["config5"]["attention"]["frac_of_fp32_mfma_peak"] < 1
         assert sm["match_call_ms"]["keypoints"] == 4096 and sm["match_call_ms"]["median"] > 0
+    if latest >= os.path.join(ROOT, "profiles", "r05_bench.json"):
+        # since round 5: `value` is the median of five back-to-back timed regions, the line lists failed epochs, the production call of
+        # main_dev.py:115-132 and the adaptive variants (with the check of the timed launch mode against direct launches); no roofline
+        # fraction above 1 anywhere
+        vr = d["value_repeats"]["pairs_per_s"]
+        assert len(vr) == 5 and abs(sorted(vr)[2] - d["value"]) < 1e-9 * d["value"] and d["failed_epochs"] == []
+        assert sm["production_call_ms"]["median"] > 0 and set(sm["production_call_ms"]["split_ms_of_the_median_call"]) >= {"preselection", "matching", "geometric_verification"}
+        ad = sm["adaptive_depth_and_width"]
+        for variant in ("prune_gradual", "earlystop_late"):
+            assert ad[variant]["matches_equal_to_direct_launches"] is True and ad[variant]["pairs_per_s"] > d["value"]
+        live = ad["prune_gradual"]["live_points_per_layer_of_one_pair"]
+        assert live[0] == [4096, 4096] and live[-1][0] < 1024 and any(1024 < w[0] <= 2048 for w in live) and any(2048 < w[0] < 4096 for w in live)
+        assert d["roofline"]["frac"] < 1 and sm["config5"]["sinkhorn"]["frac_of_hbm_peak_moved"] < 1
+        c5 = os.path.join(ROOT, "profiles", "r05_bench_config5.json")
+        if os.path.exists(c5):
+            assert json.loads(open(c5).read().strip().splitlines()[-1])["roofline_sinkhorn"]["frac"] < 1
 
 
 def test_sfm_relative_orientation_and_triangulation():
