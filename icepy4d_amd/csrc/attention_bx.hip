@@ -1,0 +1,342 @@
+// Flash attention with fp32 accuracy on the bf16 matrix cores (round 5). Same operation, arguments, block map, split-KV protocol
+// and output layout as attention.hip (the reference materialises the attention matrix on the CPU: `lightglue/lightglue.py:120-123`
+// via SDPA, `:200-210` explicit einsum / softmax, `SuperGlue/models/superglue.py:87-93`).
+//
+// Why: gfx950's f32-input MFMA runs at the VECTOR rate (157 TFLOP/s, 1 / 16 of the bf16 matrix cores) and holds the vector issue port
+// while it runs; the bf16 MFMA does neither. An fp32 value is the exact sum of three bf16 values (8 + 8 + 8 significant bits, each cut
+// rounded to nearest: x = x0 + x1 + x2 with |x1| <= 2^-9 |x|, |x2| <= 2^-18 |x|, remainder <= 2^-27 |x|), a bf16 product is exact in
+// the matrix core's fp32 accumulation, and of the nine products of two such triples the six with i + j <= 2 carry everything above
+// 2^-26 |a b| - less than the rounding of ONE fp32 accumulation. `tools/bf16x_probe.hip` measured it on the part
+// (`profiles/r05_bf16x_probe.txt`): error against an f64 sum, in units of 2^-24 sum |a b|, rms 0.37-0.39 for six products against
+// 0.45-0.47 for the f32 MFMA chain at K = 64 .. 4096 (the matrix core adds 16 products before it rounds once), nine products no
+// better than six, three 4-30 x worse; and six `v_mfma_f32_32x32x16_bf16` per 16 k run at 2.2-2.35 PFLOP/s = 2.4-2.5 x the f32 MFMA,
+// 1.8-2.15 x with four to five vector instructions between the MFMAs - the vector instructions of the splits and of the softmax run
+// BESIDE the matrix cores instead of in front of them.
+//
+// Both products keep the QUERY on the MFMA lane, as attention.hip does:
+//     S^T (32 keys x 32 queries) = K . Q^T     A = three bf16 planes of a K tile in LDS (16-byte row reads), B = Q planes in registers
+//     O^T (64 d x 32 queries)   += V^T . P^T   A = three bf16 planes of a V tile in LDS, read TRANSPOSED by ds_read_b64_tr_b16,
+//                                              B = the planes of P = exp2(S^T - m), cut from the accumulator registers in place
+// (an accumulator tile is the next MFMA's B operand with the k order `16 s + 8 (j >> 2) + 4 h + (j & 3)`; the V reads use the same order).
+// A block is 128 queries of one (image, head): 4 waves x 32 queries, 32 keys per step, K / V tiles loaded as fp32 by range-checked buffer
+// loads one step ahead, cut into planes ONCE per block when they are written to LDS (two stages of 31.5 KB: two blocks per CU, each with
+// its own barrier, so that one block's vector phases sit beside the other's MFMAs).
+#include "common.h"
+#include "kernels.h"
+#include "sp_post.h"
+
+namespace im {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+static constexpr int BKT = 32;                    // keys per step
+static constexpr int BKS = 144;                   // bytes per key row of a K plane: 64 bf16 + 16 (conflict-free 16-byte row reads)
+static constexpr int BVS = 192;                   // bytes per key row of a V plane: four consecutive rows fall on disjoint bank windows
+static constexpr int BK_PLANE = BKT * BKS, BV_PLANE = BKT * BVS;
+static constexpr int B_STAGE = 3 * BK_PLANE + 3 * BV_PLANE;     // 32,256 bytes
+static constexpr int B_LDS = 2 * B_STAGE;
+
+__device__ __forceinline__ f32x16 mfma_bf(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ unsigned cvt_pk(float a, float b) {            // v_cvt_pk_bf16_f32: a in the low half, round to nearest even
+    const bf16x2 v = __builtin_convertvector(f32x2{a, b}, bf16x2);
+    return __builtin_bit_cast(unsigned, v);
+}
+// (a, b) -> three packed bf16 pairs with a = h.lo + m.lo + l.lo (remainder below 2^-27 |a|): the subtractions are exact
+__device__ __forceinline__ void split2(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
+    h = cvt_pk(a, b);
+    float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
+    m = cvt_pk(ra, rb);
+    ra -= __uint_as_float(m << 16);
+    rb -= __uint_as_float(m & 0xffff0000u);
+    l = cvt_pk(ra, rb);
+}
+
+__device__ __forceinline__ float4 bx_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t bx_rsrc(const float* base, int rows) {
+    const unsigned long long b = reinterpret_cast<unsigned long long>(base);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    void* p = reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo);
+    return __builtin_amdgcn_make_buffer_rsrc(p, 0, __builtin_amdgcn_readfirstlane(rows) * 256, 0x00020000);
+}
+
+struct Planes { u32x4 h, m, l; };
+__device__ __forceinline__ Planes split8(float x0, float x1, float x2, float x3, float x4, float x5, float x6, float x7) {
+    unsigned h[4], m[4], l[4];
+    split2(x0, x1, h[0], m[0], l[0]);
+    split2(x2, x3, h[1], m[1], l[1]);
+    split2(x4, x5, h[2], m[2], l[2]);
+    split2(x6, x7, h[3], m[3], l[3]);
+    return Planes{u32x4{h[0], h[1], h[2], h[3]}, u32x4{m[0], m[1], m[2], m[3]}, u32x4{l[0], l[1], l[2], l[3]}};
+}
+
+// one float4 of a tile row -> 8 bytes in each of the three planes
+__device__ __forceinline__ void stage4(unsigned char* plane0, int plane_bytes, int off, float4 x) {
+    unsigned h0, m0, l0, h1, m1, l1;
+    split2(x.x, x.y, h0, m0, l0);
+    split2(x.z, x.w, h1, m1, l1);
+    *reinterpret_cast<u32x2*>(plane0 + off) = u32x2{h0, h1};
+    *reinterpret_cast<u32x2*>(plane0 + plane_bytes + off) = u32x2{m0, m1};
+    *reinterpret_cast<u32x2*>(plane0 + 2 * plane_bytes + off) = u32x2{l0, l1};
+}
+
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+__device__ __forceinline__ u32x2 tr_read(const unsigned char* p) {
+    const bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p));
+    return __builtin_bit_cast(u32x2, v);
+}
+
+static constexpr float BX_SLACK = 8.f;   // as attention.hip: the running max is a reference, raised when a row exceeds it by 2^8
+__device__ __forceinline__ float bmax3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
+
+template <bool TAIL>
+__device__ __forceinline__ void softmax32(f32x16& s, int kb, int nk, int hh, float& m_run, float& l_run, f32x16& o0, f32x16& o1) {
+    if (TAIL) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (kb + acc_row(r, hh) >= nk) s[r] = -INFINITY;
+    }
+    float mx0 = bmax3(s[0], s[1], s[2]), mx1 = bmax3(s[3], s[4], s[5]);
+    mx0 = bmax3(mx0, s[6], s[7]); mx1 = bmax3(mx1, s[8], s[9]);
+    mx0 = bmax3(mx0, s[10], s[11]); mx1 = bmax3(mx1, s[12], s[13]);
+    float mx = bmax3(mx0, mx1, fmaxf(s[14], s[15]));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    if (__builtin_amdgcn_ballot_w64(mx > m_run + BX_SLACK) != 0) {     // wave-uniform: raise the reference, rescale
+        asm volatile("" ::: "memory");
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);     // m_run = -inf at the first tile: alpha = 0
+        l_run *= alpha;
+        o0 *= alpha;
+        o1 *= alpha;
+        m_run = m_new;
+    }
+    const float m_use = (TAIL && m_run == -INFINITY) ? 0.f : m_run;    // a split whose every key lies past the end keeps m = -inf, l = 0
+    float r0 = 0.f, r1 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        s[r] = __builtin_amdgcn_exp2f(s[r] - m_use);
+        s[r + 1] = __builtin_amdgcn_exp2f(s[r + 1] - m_use);
+        r0 += s[r]; r1 += s[r + 1];
+    }
+    float rs = r0 + r1;
+    rs += __shfl_xor(rs, 32);
+    l_run += rs;
+}
+
+__global__ __launch_bounds__(256, 2) void flash_attn_bx_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char bsm[];
+
+    // block -> (pair, image, head, query block, key split): attention.hip's XCD-aware map
+    const int gsz = (a.batch % 2 == 0) ? 2 : a.batch;
+    const int hz = a.heads * gsz;
+    const int nqb = (a.n_max + 127) / 128;
+    const int per_group = hz * nqb * (a.part ? ATTN_MAX_SPLIT : 1);
+    const int grp_idx = blockIdx.x / per_group;
+    const int bid = blockIdx.x - grp_idx * per_group;
+    const int head = (bid % hz) % a.heads, z = grp_idx * gsz + (bid % hz) / a.heads;
+    const int y = a.cross ? (z ^ 1) : z;
+    if (a.active && a.active[(z >> 1) * a.pstride] == 0) return;
+    const int nq = a.n_ptr ? a.n_ptr[(z >> 1) * a.pstride + (z & 1)] : a.n_max;
+    const int nk_all = a.n_ptr ? a.n_ptr[(y >> 1) * a.pstride + (y & 1)] : a.n_max;
+    const int qblk = (bid / hz) % nqb, split = (bid / hz) / nqb;
+    const int qb = qblk * 128;
+    if (qb >= nq || nk_all <= 0) return;
+    int n_split = 1, k0 = 0, nk = nk_all;
+    if (a.part) {       // split-KV, decided on the device (attention.hip): few live queries -> the keys of a query block on up to 4 blocks
+        const int steps_all = (nk_all + BKT - 1) / BKT;
+        const int want = nq > 2048 ? 1 : (nq > 1024 ? 2 : ATTN_MAX_SPLIT);
+        const int steps_per = (steps_all + want - 1) / want;
+        n_split = (steps_all + steps_per - 1) / steps_per;
+        k0 = split * steps_per * BKT;
+        nk = min(nk_all - k0, steps_per * BKT);
+    }
+    if (split >= n_split) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 31, hh = lane >> 5;
+    const int qrow = qb + wave * 32 + c;
+
+    const float* Q = a.q + (long)z * a.bstride + (long)head * a.hstride;
+    const __amdgpu_buffer_rsrc_t K = bx_rsrc(a.k + (long)y * a.bstride + (long)head * a.hstride + (long)k0 * 64, nk);
+    const __amdgpu_buffer_rsrc_t V = bx_rsrc(a.v + (long)y * a.bstride + (long)head * a.hstride + (long)k0 * 64, nk);
+    const unsigned voff = ((tid >> 4) * 64 + (tid & 15) * 4) * sizeof(float);     // staging: rows tid >> 4 and + 16, floats 4 (tid & 15) ..
+
+    // Q planes: lane (c, hh) keeps Q[qrow][16 s + 8 hh + j], j = 0..7, of d-chunk s; the softmax scale and log2 e folded in before the cut
+    u32x4 qh[4], qm[4], ql[4];
+    {
+        const float* qp = Q + (long)min(qrow, nq - 1) * 64 + hh * 8;
+        const float c2 = a.scale * 1.4426950408889634f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float4 u = *reinterpret_cast<const float4*>(qp + 16 * s), w = *reinterpret_cast<const float4*>(qp + 16 * s + 4);
+            const Planes p = split8(u.x * c2, u.y * c2, u.z * c2, u.w * c2, w.x * c2, w.y * c2, w.z * c2, w.w * c2);
+            qh[s] = p.h; qm[s] = p.m; ql[s] = p.l;
+        }
+    }
+
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+    const int nt = (nk + BKT - 1) / BKT;
+
+    // staging offsets of this thread inside a plane; fragment read offsets of this lane
+    const int st_k = (tid >> 4) * BKS + (tid & 15) * 8, st_v = (tid >> 4) * BVS + (tid & 15) * 8;
+    const int rd_k = c * BKS + hh * 16;                                                                // + plane, + 32 s
+    const int rd_v = (4 * hh + ((lane & 15) >> 2)) * BVS + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;    // + plane, + (16 s + 8 half) rows, + 64 dt
+
+    float4 rk0, rk1, rv0, rv1;
+#define BX_LOAD(tile)                                                       \
+    {                                                                       \
+        const unsigned so_ = (unsigned)(tile) * (BKT * 256u);               \
+        rk0 = bx_load4(K, voff, so_); rk1 = bx_load4(K, voff, so_ + 16 * 256u); \
+        rv0 = bx_load4(V, voff, so_); rv1 = bx_load4(V, voff, so_ + 16 * 256u); \
+    }
+#define BX_STAGE(stage)                                                     \
+    {                                                                       \
+        unsigned char* const kp_ = bsm + (stage) * B_STAGE;                 \
+        unsigned char* const vp_ = kp_ + 3 * BK_PLANE;                      \
+        stage4(kp_, BK_PLANE, st_k, rk0); stage4(kp_, BK_PLANE, st_k + 16 * BKS, rk1); \
+        stage4(vp_, BV_PLANE, st_v, rv0); stage4(vp_, BV_PLANE, st_v + 16 * BVS, rv1); \
+    }
+    BX_LOAD(0)
+    BX_STAGE(0)
+    BX_LOAD(1)
+    __syncthreads();
+
+    for (int t = 0; t < nt; ++t) {
+        const bool tail = t == nt - 1;
+        const unsigned char* const kp = bsm + (t & 1) * B_STAGE;
+        const unsigned char* const vp = kp + 3 * BK_PLANE;
+        if (!tail) {
+            BX_STAGE((t + 1) & 1)
+            BX_LOAD(t + 2)
+        }
+        // ---- S^T = K . Q^T: two accumulators (even / odd d-chunks), small products first
+        f32x16 sa, sb;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sa[r] = 0.f; sb[r] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const u32x4 kh = *reinterpret_cast<const u32x4*>(kp + rd_k + 32 * s);
+            const u32x4 km = *reinterpret_cast<const u32x4*>(kp + BK_PLANE + rd_k + 32 * s);
+            const u32x4 kl = *reinterpret_cast<const u32x4*>(kp + 2 * BK_PLANE + rd_k + 32 * s);
+            f32x16& x = (s & 1) ? sb : sa;
+            x = mfma_bf(kh, ql[s], x);
+            x = mfma_bf(kl, qh[s], x);
+            x = mfma_bf(km, qm[s], x);
+            x = mfma_bf(kh, qm[s], x);
+            x = mfma_bf(km, qh[s], x);
+            x = mfma_bf(kh, qh[s], x);
+        }
+        sa += sb;
+        if (tail) softmax32<true>(sa, t * BKT, nk, hh, m_run, l_run, o0, o1);
+        else softmax32<false>(sa, 0, nk, hh, m_run, l_run, o0, o1);
+        // ---- P planes: registers 8 s .. 8 s + 7 are the eight k slots of key chunk s
+        u32x4 ph[2], pm[2], pl[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const Planes p = split8(sa[8 * s + 0], sa[8 * s + 1], sa[8 * s + 2], sa[8 * s + 3], sa[8 * s + 4], sa[8 * s + 5], sa[8 * s + 6], sa[8 * s + 7]);
+            ph[s] = p.h; pm[s] = p.m; pl[s] = p.l;
+        }
+        // ---- O^T += V^T . P^T
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const unsigned char* vb = vp + rd_v + (16 * s) * BVS + 64 * dt;
+                const u32x2 h0 = tr_read(vb), h1 = tr_read(vb + 8 * BVS);
+                const u32x2 m0 = tr_read(vb + BV_PLANE), m1 = tr_read(vb + BV_PLANE + 8 * BVS);
+                const u32x2 l0 = tr_read(vb + 2 * BV_PLANE), l1 = tr_read(vb + 2 * BV_PLANE + 8 * BVS);
+                const u32x4 vh = {h0.x, h0.y, h1.x, h1.y}, vm = {m0.x, m0.y, m1.x, m1.y}, vl = {l0.x, l0.y, l1.x, l1.y};
+                f32x16& o = dt ? o1 : o0;
+                o = mfma_bf(vh, pl[s], o);
+                o = mfma_bf(vl, ph[s], o);
+                o = mfma_bf(vm, pm[s], o);
+                o = mfma_bf(vh, pm[s], o);
+                o = mfma_bf(vm, ph[s], o);
+                o = mfma_bf(vh, ph[s], o);
+            }
+        }
+        if (!tail) __syncthreads();
+    }
+#undef BX_LOAD
+#undef BX_STAGE
+
+    // ---- split-KV: park the partial (O, m, l); the last block of this query block merges all of them in split order (attention.hip)
+    if (n_split > 1) {
+        const long prow = (((long)z * a.heads + head) * a.n_max + min(qrow, a.n_max - 1)) * 66;
+        const long pstride = (long)a.batch * a.heads * a.n_max * 66;
+        float* pp = a.part + (long)split * pstride + prow;
+        if (qrow < nq) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                *reinterpret_cast<float2*>(pp + 8 * g + 4 * hh) = make_float2(o0[4 * g], o0[4 * g + 1]);
+                *reinterpret_cast<float2*>(pp + 8 * g + 4 * hh + 2) = make_float2(o0[4 * g + 2], o0[4 * g + 3]);
+                *reinterpret_cast<float2*>(pp + 32 + 8 * g + 4 * hh) = make_float2(o1[4 * g], o1[4 * g + 1]);
+                *reinterpret_cast<float2*>(pp + 32 + 8 * g + 4 * hh + 2) = make_float2(o1[4 * g + 2], o1[4 * g + 3]);
+            }
+            if (hh == 0) { pp[64] = m_run; pp[65] = l_run; }
+        }
+        __threadfence();
+        __syncthreads();
+        int* flag = reinterpret_cast<int*>(bsm);
+        if (tid == 0) {
+            int* cnt = a.counters + ((long)z * a.heads + head) * nqb + qblk;
+            const int old = atomicAdd(cnt, 1);
+            *flag = (old == n_split - 1);
+            if (old == n_split - 1) *cnt = 0;            // ready for the next launch
+        }
+        __syncthreads();
+        if (!*flag) return;
+        __threadfence();
+        float m = -INFINITY;
+        for (int sidx = 0; sidx < n_split; ++sidx) m = fmaxf(m, a.part[(long)sidx * pstride + prow + 64]);
+        l_run = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+        for (int sidx = 0; sidx < n_split; ++sidx) {
+            const float* ps = a.part + (long)sidx * pstride + prow;
+            const float w = __builtin_amdgcn_exp2f(ps[64] - m);
+            l_run += w * ps[65];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    o0[4 * g + q] += w * ps[8 * g + 4 * hh + q];
+                    o1[4 * g + q] += w * ps[32 + 8 * g + 4 * hh + q];
+                }
+        }
+    }
+
+    // ---- epilogue: lane (c, hh) holds query qrow, d = 32 dt + 8 g + 4 hh + (0..3) in registers 4g..4g+3 of o<dt>
+    if (qrow < nq) {
+        const float inv = 1.f / l_run;
+        float* op = a.out + (long)z * a.out_bstride + (long)qrow * a.ldo + head * 64;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 w0 = make_float4(o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+            const float4 w1 = make_float4(o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+            *reinterpret_cast<float4*>(op + 8 * g + 4 * hh) = w0;
+            *reinterpret_cast<float4*>(op + 32 + 8 * g + 4 * hh) = w1;
+        }
+    }
+}
+
+hipError_t launch_flash_attn_bx(const AttnArgs& a, hipStream_t s) {
+    static size_t lds_optin[IM_MAX_DEVICES] = {0};
+    if (hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(&flash_attn_bx_kernel), B_LDS, lds_optin); e != hipSuccess) return e;
+    dim3 grid(((a.n_max + 127) / 128) * a.heads * a.batch * (a.part ? ATTN_MAX_SPLIT : 1)), block(256);
+    hipLaunchKernelGGL(flash_attn_bx_kernel, grid, block, B_LDS, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace im

@@ -82,7 +82,8 @@ struct AttnArgs {
 static constexpr int ATTN_MAX_SPLIT = 4;
 inline size_t attn_part_floats(int n_max, int batch, int heads) { return (size_t)ATTN_MAX_SPLIT * batch * heads * n_max * 66; }
 inline size_t attn_counter_ints(int n_max, int batch, int heads) { return (size_t)batch * heads * ((n_max + 127) / 128); }
-hipError_t launch_flash_attn(const AttnArgs& a, hipStream_t s);
+hipError_t launch_flash_attn(const AttnArgs& a, hipStream_t s);      // attention_bx.hip unless IM_ATTN_F32=1 (attention.hip: the f32-input MFMA form)
+hipError_t launch_flash_attn_bx(const AttnArgs& a, hipStream_t s);   // fp32 accuracy from six bf16 products per fp32 product on the bf16 matrix cores
 
 // ------------------------------------------------------------------ conv.hip
 struct ConvArgs {
