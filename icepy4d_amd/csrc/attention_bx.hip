@@ -61,11 +61,11 @@ __device__ __forceinline__ float4 bx_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t bx_rsrc(const float* base, int rows) {
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t bx_rsrc_bytes(const void* base, int bytes) {     // reads past `bytes` return zero
     const unsigned long long b = reinterpret_cast<unsigned long long>(base);
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
     void* p = reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo);
-    return __builtin_amdgcn_make_buffer_rsrc(p, 0, __builtin_amdgcn_readfirstlane(rows) * 256, 0x00020000);
+    return __builtin_amdgcn_make_buffer_rsrc(p, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
 }
 
 struct Planes { u32x4 h, m, l; };
@@ -97,8 +97,9 @@ __device__ __forceinline__ u32x2 tr_read(const unsigned char* p) {
 static constexpr float BX_SLACK = 8.f;   // as attention.hip: the running max is a reference, raised when a row exceeds it by 2^8
 __device__ __forceinline__ float bmax3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
 
+// softmax of one 32-key tile, first half: mask the keys past the end (last step only), row maximum, and - rarely - a new reference
 template <bool TAIL>
-__device__ __forceinline__ void softmax32(f32x16& s, int kb, int nk, int hh, float& m_run, float& l_run, f32x16& o0, f32x16& o1) {
+__device__ __forceinline__ float softmax_ref(f32x16& s, int kb, int nk, int hh, float& m_run, float& l_run, f32x16& o0, f32x16& o1) {
     if (TAIL) {
 #pragma unroll
         for (int r = 0; r < 16; ++r)
@@ -118,7 +119,10 @@ __device__ __forceinline__ void softmax32(f32x16& s, int kb, int nk, int hh, flo
         o1 *= alpha;
         m_run = m_new;
     }
-    const float m_use = (TAIL && m_run == -INFINITY) ? 0.f : m_run;    // a split whose every key lies past the end keeps m = -inf, l = 0
+    return (TAIL && m_run == -INFINITY) ? 0.f : m_run;                 // a split whose every key lies past the end keeps m = -inf, l = 0
+}
+// second half: P = exp2(S - m) in place, row sum
+__device__ __forceinline__ void softmax_exp(f32x16& s, float m_use, float& l_run) {
     float r0 = 0.f, r1 = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; r += 2) {
@@ -131,6 +135,28 @@ __device__ __forceinline__ void softmax32(f32x16& s, int kb, int nk, int hh, flo
     l_run += rs;
 }
 
+// K and V of every (image, head) as bf16 triples, once per launch instead of once per 128-query block: [image][head][row][plane][64].
+// blockIdx.y: 0 = K, 1 = V; eight threads per row. Rows past an image's live count are neither read nor written.
+__global__ __launch_bounds__(256) void kv_planes_kernel(AttnArgs a) {
+    const long rid = (long)blockIdx.x * 32 + (threadIdx.x >> 3);            // (z * heads + head) * n_max + row
+    const int d8 = threadIdx.x & 7;
+    const long per_image = (long)a.heads * a.n_max;
+    if (rid >= per_image * a.batch) return;
+    const int z = (int)(rid / per_image), rem = (int)(rid - (long)z * per_image), head = rem / a.n_max, row = rem - head * a.n_max;
+    if (a.active && a.active[(z >> 1) * a.pstride] == 0) return;
+    const int n = a.n_ptr ? a.n_ptr[(z >> 1) * a.pstride + (z & 1)] : a.n_max;
+    if (row >= n) return;
+    const float* src = (blockIdx.y ? a.v : a.k) + (long)z * a.bstride + (long)head * a.hstride + (long)row * 64 + d8 * 8;
+    const float4 u = *reinterpret_cast<const float4*>(src), w = *reinterpret_cast<const float4*>(src + 4);
+    const Planes p = split8(u.x, u.y, u.z, u.w, w.x, w.y, w.z, w.w);
+    unsigned char* dst = reinterpret_cast<unsigned char*>(a.planes) + ((long)blockIdx.y * per_image * a.batch + rid) * 384 + d8 * 16;
+    *reinterpret_cast<u32x4*>(dst) = p.h;
+    *reinterpret_cast<u32x4*>(dst + 128) = p.m;
+    *reinterpret_cast<u32x4*>(dst + 256) = p.l;
+}
+
+// PRE: K / V arrive as planes (kv_planes_kernel; staging is a copy). !PRE: fp32 K / V cut while they are staged (no workspace).
+template <bool PRE>
 __global__ __launch_bounds__(256, 2) void flash_attn_bx_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char bsm[];
 
@@ -165,9 +191,16 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bx_kernel(AttnArgs a) {
     const int qrow = qb + wave * 32 + c;
 
     const float* Q = a.q + (long)z * a.bstride + (long)head * a.hstride;
-    const __amdgpu_buffer_rsrc_t K = bx_rsrc(a.k + (long)y * a.bstride + (long)head * a.hstride + (long)k0 * 64, nk);
-    const __amdgpu_buffer_rsrc_t V = bx_rsrc(a.v + (long)y * a.bstride + (long)head * a.hstride + (long)k0 * 64, nk);
-    const unsigned voff = ((tid >> 4) * 64 + (tid & 15) * 4) * sizeof(float);     // staging: rows tid >> 4 and + 16, floats 4 (tid & 15) ..
+    __amdgpu_buffer_rsrc_t K, V;
+    if constexpr (PRE) {
+        const long rows = (long)a.heads * a.n_max * a.batch;
+        const unsigned char* kp = reinterpret_cast<const unsigned char*>(a.planes) + (((long)y * a.heads + head) * a.n_max + k0) * 384;
+        K = bx_rsrc_bytes(kp, nk * 384);
+        V = bx_rsrc_bytes(kp + rows * 384, nk * 384);
+    } else {
+        K = bx_rsrc_bytes(a.k + (long)y * a.bstride + (long)head * a.hstride + (long)k0 * 64, nk * 256);
+        V = bx_rsrc_bytes(a.v + (long)y * a.bstride + (long)head * a.hstride + (long)k0 * 64, nk * 256);
+    }
 
     // Q planes: lane (c, hh) keeps Q[qrow][16 s + 8 hh + j], j = 0..7, of d-chunk s; the softmax scale and log2 e folded in before the cut
     u32x4 qh[4], qm[4], ql[4];
@@ -188,48 +221,77 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bx_kernel(AttnArgs a) {
     float m_run = -INFINITY, l_run = 0.f;
     const int nt = (nk + BKT - 1) / BKT;
 
-    // staging offsets of this thread inside a plane; fragment read offsets of this lane
-    const int st_k = (tid >> 4) * BKS + (tid & 15) * 8, st_v = (tid >> 4) * BVS + (tid & 15) * 8;
+    // LDS: K ring (2 x 3 planes), V ring (2 x 3 planes); K runs one step ahead of V
+    unsigned char* const kring = bsm;
+    unsigned char* const vring = bsm + 2 * 3 * BK_PLANE;
     const int rd_k = c * BKS + hh * 16;                                                                // + plane, + 32 s
     const int rd_v = (4 * hh + ((lane & 15) >> 2)) * BVS + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;    // + plane, + (16 s + 8 half) rows, + 64 dt
 
-    float4 rk0, rk1, rv0, rv1;
-#define BX_LOAD(tile)                                                       \
-    {                                                                       \
-        const unsigned so_ = (unsigned)(tile) * (BKT * 256u);               \
-        rk0 = bx_load4(K, voff, so_); rk1 = bx_load4(K, voff, so_ + 16 * 256u); \
-        rv0 = bx_load4(V, voff, so_); rv1 = bx_load4(V, voff, so_ + 16 * 256u); \
-    }
-#define BX_STAGE(stage)                                                     \
-    {                                                                       \
-        unsigned char* const kp_ = bsm + (stage) * B_STAGE;                 \
-        unsigned char* const vp_ = kp_ + 3 * BK_PLANE;                      \
-        stage4(kp_, BK_PLANE, st_k, rk0); stage4(kp_, BK_PLANE, st_k + 16 * BKS, rk1); \
-        stage4(vp_, BV_PLANE, st_v, rv0); stage4(vp_, BV_PLANE, st_v + 16 * BVS, rv1); \
-    }
-    BX_LOAD(0)
-    BX_STAGE(0)
-    BX_LOAD(1)
-    __syncthreads();
-
-    for (int t = 0; t < nt; ++t) {
-        const bool tail = t == nt - 1;
-        const unsigned char* const kp = bsm + (t & 1) * B_STAGE;
-        const unsigned char* const vp = kp + 3 * BK_PLANE;
-        if (!tail) {
-            BX_STAGE((t + 1) & 1)
-            BX_LOAD(t + 2)
-        }
-        // ---- S^T = K . Q^T: two accumulators (even / odd d-chunks), small products first
-        f32x16 sa, sb;
+    // staging. PRE: a tile is 32 rows x 384 bytes = 768 16-byte pieces, contiguous in memory: piece id = tid + 256 i sits at byte 16 id,
+    // row id / 24, plane (id % 24) >> 3, 16-byte column id & 7. !PRE: rows tid >> 4 and + 16, floats 4 (tid & 15) .. + 3.
+    u32x4 pk[3], pv[3];
+    float4 fk[2], fv[2];
+    int lk[3], lv[3];
+    if constexpr (PRE) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { sa[r] = 0.f; sb[r] = 0.f; }
+        for (int i = 0; i < 3; ++i) {
+            const int id = tid + 256 * i, row = id / 24, rem = id - 24 * row;
+            lk[i] = (rem >> 3) * BK_PLANE + row * BKS + (rem & 7) * 16;
+            lv[i] = (rem >> 3) * BV_PLANE + row * BVS + (rem & 7) * 16;
+        }
+    }
+    const unsigned voff = PRE ? tid * 16u : ((tid >> 4) * 64 + (tid & 15) * 4) * 4u;
+    const int st_k = (tid >> 4) * BKS + (tid & 15) * 8, st_v = (tid >> 4) * BVS + (tid & 15) * 8;
+    auto load_k = [&](int tile) {
+        if constexpr (PRE) {
+            const unsigned so = (unsigned)tile * (BKT * 384u);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) pk[i] = __builtin_amdgcn_raw_buffer_load_b128(K, voff, so + 4096u * i, 0);
+        } else {
+            const unsigned so = (unsigned)tile * (BKT * 256u);
+            fk[0] = bx_load4(K, voff, so); fk[1] = bx_load4(K, voff, so + 16 * 256u);
+        }
+    };
+    auto load_v = [&](int tile) {
+        if constexpr (PRE) {
+            const unsigned so = (unsigned)tile * (BKT * 384u);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) pv[i] = __builtin_amdgcn_raw_buffer_load_b128(V, voff, so + 4096u * i, 0);
+        } else {
+            const unsigned so = (unsigned)tile * (BKT * 256u);
+            fv[0] = bx_load4(V, voff, so); fv[1] = bx_load4(V, voff, so + 16 * 256u);
+        }
+    };
+    auto store_k = [&](int stage) {
+        unsigned char* const kp = kring + stage * 3 * BK_PLANE;
+        if constexpr (PRE) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) *reinterpret_cast<u32x4*>(kp + lk[i]) = pk[i];
+        } else {
+            stage4(kp, BK_PLANE, st_k, fk[0]); stage4(kp, BK_PLANE, st_k + 16 * BKS, fk[1]);
+        }
+    };
+    auto store_v = [&](int stage) {
+        unsigned char* const vp = vring + stage * 3 * BV_PLANE;
+        if constexpr (PRE) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) *reinterpret_cast<u32x4*>(vp + lv[i]) = pv[i];
+        } else {
+            stage4(vp, BV_PLANE, st_v, fv[0]); stage4(vp, BV_PLANE, st_v + 16 * BVS, fv[1]);
+        }
+    };
+    // S^T = K . Q^T of one tile: two accumulators (even / odd d-chunks), the small products first
+    auto qk = [&](int stage, f32x16& out) {
+        const unsigned char* const kp = kring + stage * 3 * BK_PLANE + rd_k;
+        f32x16 xa, xb;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { xa[r] = 0.f; xb[r] = 0.f; }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const u32x4 kh = *reinterpret_cast<const u32x4*>(kp + rd_k + 32 * s);
-            const u32x4 km = *reinterpret_cast<const u32x4*>(kp + BK_PLANE + rd_k + 32 * s);
-            const u32x4 kl = *reinterpret_cast<const u32x4*>(kp + 2 * BK_PLANE + rd_k + 32 * s);
-            f32x16& x = (s & 1) ? sb : sa;
+            const u32x4 kh = *reinterpret_cast<const u32x4*>(kp + 32 * s);
+            const u32x4 km = *reinterpret_cast<const u32x4*>(kp + BK_PLANE + 32 * s);
+            const u32x4 kl = *reinterpret_cast<const u32x4*>(kp + 2 * BK_PLANE + 32 * s);
+            f32x16& x = (s & 1) ? xb : xa;
             x = mfma_bf(kh, ql[s], x);
             x = mfma_bf(kl, qh[s], x);
             x = mfma_bf(km, qm[s], x);
@@ -237,39 +299,162 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bx_kernel(AttnArgs a) {
             x = mfma_bf(km, qh[s], x);
             x = mfma_bf(kh, qh[s], x);
         }
-        sa += sb;
-        if (tail) softmax32<true>(sa, t * BKT, nk, hh, m_run, l_run, o0, o1);
-        else softmax32<false>(sa, 0, nk, hh, m_run, l_run, o0, o1);
-        // ---- P planes: registers 8 s .. 8 s + 7 are the eight k slots of key chunk s
-        u32x4 ph[2], pm[2], pl[2];
+        out = xa + xb;
+    };
+    // O^T += V^T . P^T: registers 8 s .. 8 s + 7 of P are the eight k slots of key chunk s
+    auto pv_mul = [&](int stage, const f32x16& p) {
+        const unsigned char* const vp = vring + stage * 3 * BV_PLANE + rd_v;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            const Planes p = split8(sa[8 * s + 0], sa[8 * s + 1], sa[8 * s + 2], sa[8 * s + 3], sa[8 * s + 4], sa[8 * s + 5], sa[8 * s + 6], sa[8 * s + 7]);
-            ph[s] = p.h; pm[s] = p.m; pl[s] = p.l;
-        }
-        // ---- O^T += V^T . P^T
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
+            const Planes pp = split8(p[8 * s + 0], p[8 * s + 1], p[8 * s + 2], p[8 * s + 3], p[8 * s + 4], p[8 * s + 5], p[8 * s + 6], p[8 * s + 7]);
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
-                const unsigned char* vb = vp + rd_v + (16 * s) * BVS + 64 * dt;
+                const unsigned char* vb = vp + (16 * s) * BVS + 64 * dt;
                 const u32x2 h0 = tr_read(vb), h1 = tr_read(vb + 8 * BVS);
                 const u32x2 m0 = tr_read(vb + BV_PLANE), m1 = tr_read(vb + BV_PLANE + 8 * BVS);
                 const u32x2 l0 = tr_read(vb + 2 * BV_PLANE), l1 = tr_read(vb + 2 * BV_PLANE + 8 * BVS);
                 const u32x4 vh = {h0.x, h0.y, h1.x, h1.y}, vm = {m0.x, m0.y, m1.x, m1.y}, vl = {l0.x, l0.y, l1.x, l1.y};
                 f32x16& o = dt ? o1 : o0;
-                o = mfma_bf(vh, pl[s], o);
-                o = mfma_bf(vl, ph[s], o);
-                o = mfma_bf(vm, pm[s], o);
-                o = mfma_bf(vh, pm[s], o);
-                o = mfma_bf(vm, ph[s], o);
-                o = mfma_bf(vh, ph[s], o);
+                o = mfma_bf(vh, pp.l, o);
+                o = mfma_bf(vl, pp.h, o);
+                o = mfma_bf(vm, pp.m, o);
+                o = mfma_bf(vh, pp.m, o);
+                o = mfma_bf(vm, pp.h, o);
+                o = mfma_bf(vh, pp.h, o);
             }
         }
-        if (!tail) __syncthreads();
+    };
+
+    // ---- prologue: K0 -> LDS, S(0); K1, V0 -> LDS; K2, V1 in registers
+    f32x16 sc, sn;
+    load_k(0);
+    store_k(0);
+    load_k(1);
+    load_v(0);
+    __syncthreads();
+    qk(0, sc);
+    store_k(1);
+    store_v(0);
+    load_k(2);
+    load_v(1);
+    __syncthreads();
+
+    // step t: stage K(t+2), V(t+1); request K(t+3), V(t+2); reference of tile t; then 48 MFMA slots - S(t+1) = 24, O += P(t) V(t) = 24 -
+    // with the vector work of tile t dealt over them BY HAND, a few instructions behind each MFMA and a scheduling fence behind each slot:
+    // the bf16 MFMA holds the issue port for 8 of its 32 cycles, so ~5 vector instructions per slot are free, but only if they sit
+    // between the MFMAs in program order (left to itself the compiler emits the MFMAs in runs of six and the vector work in runs of 60).
+    //   slots  0..23 (S(t+1), d-chunk s = slot / 6):  exp2 + row sum of P registers 0..7 | cut of key chunk 0 | exp2 + row sum of 8..15
+    //   slots 24..35 (O += V P, key chunk 0):          cut of key chunk 1
+    //   slots 36..47 (key chunk 1):                    nothing left
+    // LDS reads run one group ahead: K fragments of d-chunk s + 1 during chunk s, the six transposed V reads of (chunk, d-tile) group g + 1
+    // during group g.
+    static constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};   // the six products, small ones first: A plane, B plane
+    for (int t = 0; t < nt - 1; ++t) {
+        const unsigned char* const kp = kring + ((t + 1) & 1) * 3 * BK_PLANE + rd_k;
+        const unsigned char* const vp = vring + (t & 1) * 3 * BV_PLANE + rd_v;
+        u32x4 kf[2][3];
+        u32x2 vr[2][6];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) kf[0][pl] = *reinterpret_cast<const u32x4*>(kp + pl * BK_PLANE);
+        store_k(t & 1);
+        store_v((t + 1) & 1);
+        load_k(t + 3);
+        load_v(t + 2);
+        const float m_use = softmax_ref<false>(sc, 0, nk, hh, m_run, l_run, o0, o1);
+        __builtin_amdgcn_sched_barrier(0);
+
+        float ra[8], rb[8], rsum0 = 0.f, rsum1 = 0.f;
+        unsigned ch[8], cm[8], cl[8];
+        // An empty asm with the values as read-write operands in front of and behind every piece: the pieces cannot leave their slot (the
+        // scheduling fences alone hold the MFMAs in place, but instruction selection had moved the cuts behind the last MFMA of the phase).
+        // No instruction is emitted, so nothing is hidden from the hazard recogniser.
+#define BX_PIN(x) asm volatile("" : "+v"(x))
+        auto expo = [&](int r) {                       // 3 instructions
+            float x = sc[r];
+            BX_PIN(x);
+            x = __builtin_amdgcn_exp2f(x - m_use);
+            BX_PIN(x);
+            sc[r] = x;
+            if (r & 1) rsum1 += x; else rsum0 += x;
+        };
+        auto cut_a = [&](int i) {                      // pair i = registers 2 i, 2 i + 1: 4-5 instructions
+            float x = sc[2 * i], y = sc[2 * i + 1];
+            BX_PIN(x); BX_PIN(y);
+            ch[i] = cvt_pk(x, y);
+            ra[i] = x - __uint_as_float(ch[i] << 16);
+            rb[i] = y - __uint_as_float(ch[i] & 0xffff0000u);
+            BX_PIN(ra[i]); BX_PIN(rb[i]);
+        };
+        auto cut_b = [&](int i) {
+            BX_PIN(ra[i]); BX_PIN(rb[i]);
+            cm[i] = cvt_pk(ra[i], rb[i]);
+            ra[i] -= __uint_as_float(cm[i] << 16);
+            rb[i] -= __uint_as_float(cm[i] & 0xffff0000u);
+            BX_PIN(ra[i]); BX_PIN(rb[i]);
+        };
+        auto cut_l = [&](int i) {
+            BX_PIN(ra[i]);
+            cl[i] = cvt_pk(ra[i], rb[i]);
+            BX_PIN(cl[i]);
+        };
+
+        // ---- slots 0..23: S(t+1) = K(t+1) . Q^T
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sn[r] = 0.f;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            if (s4 < 3) {
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) kf[(s4 + 1) & 1][pl] = *reinterpret_cast<const u32x4*>(kp + pl * BK_PLANE + 32 * (s4 + 1));
+            }
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int slot = 6 * s4 + j;
+                const u32x4 qb = PB[j] == 0 ? qh[s4] : (PB[j] == 1 ? qm[s4] : ql[s4]);
+                sn = mfma_bf(kf[s4 & 1][PA[j]], qb, sn);
+                if (slot < 8) expo(slot);
+                else if (slot < 16) { if (slot & 1) cut_b((slot - 8) >> 1); else cut_a((slot - 8) >> 1); }
+                else { expo(slot - 8); if (slot < 20) cut_l(slot - 16); }
+                if (slot >= 18) vr[0][slot - 18] = tr_read(vp + ((slot - 18) >> 1) * BV_PLANE + ((slot - 18) & 1) * 8 * BVS);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // ---- slots 24..47: O^T += V(t)^T . P(t)^T, groups g = (key chunk g >> 1, d-tile g & 1)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int ks = g >> 1;
+            const u32x4 pp[3] = {u32x4{ch[4 * ks], ch[4 * ks + 1], ch[4 * ks + 2], ch[4 * ks + 3]},
+                                 u32x4{cm[4 * ks], cm[4 * ks + 1], cm[4 * ks + 2], cm[4 * ks + 3]},
+                                 u32x4{cl[4 * ks], cl[4 * ks + 1], cl[4 * ks + 2], cl[4 * ks + 3]}};
+            const u32x4 vf[3] = {u32x4{vr[g & 1][0].x, vr[g & 1][0].y, vr[g & 1][1].x, vr[g & 1][1].y},
+                                 u32x4{vr[g & 1][2].x, vr[g & 1][2].y, vr[g & 1][3].x, vr[g & 1][3].y},
+                                 u32x4{vr[g & 1][4].x, vr[g & 1][4].y, vr[g & 1][5].x, vr[g & 1][5].y}};
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int slot = 6 * g + j;
+                if (g & 1) o1 = mfma_bf(vf[PA[j]], pp[PB[j]], o1);
+                else o0 = mfma_bf(vf[PA[j]], pp[PB[j]], o0);
+                if (slot < 8) { if (slot & 1) cut_b(4 + (slot >> 1)); else cut_a(4 + (slot >> 1)); }
+                else if (slot < 12) cut_l(4 + slot - 8);
+                if (g < 3) {
+                    const int gn = g + 1;
+                    vr[gn & 1][j] = tr_read(vp + (16 * (gn >> 1)) * BVS + 64 * (gn & 1) + (j >> 1) * BV_PLANE + (j & 1) * 8 * BVS);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        float rs = rsum0 + rsum1;
+        rs += __shfl_xor(rs, 32);
+        l_run += rs;
+        sc = sn;
+        __syncthreads();
     }
-#undef BX_LOAD
-#undef BX_STAGE
+    {
+        const int t = nt - 1;
+        const float m_use = softmax_ref<true>(sc, t * BKT, nk, hh, m_run, l_run, o0, o1);
+        softmax_exp(sc, m_use, l_run);
+        pv_mul(t & 1, sc);
+    }
 
     // ---- split-KV: park the partial (O, m, l); the last block of this query block merges all of them in split order (attention.hip)
     if (n_split > 1) {
@@ -332,10 +517,17 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bx_kernel(AttnArgs a) {
 }
 
 hipError_t launch_flash_attn_bx(const AttnArgs& a, hipStream_t s) {
-    static size_t lds_optin[IM_MAX_DEVICES] = {0};
-    if (hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(&flash_attn_bx_kernel), B_LDS, lds_optin); e != hipSuccess) return e;
+    static size_t lds_pre[IM_MAX_DEVICES] = {0}, lds_cut[IM_MAX_DEVICES] = {0};
     dim3 grid(((a.n_max + 127) / 128) * a.heads * a.batch * (a.part ? ATTN_MAX_SPLIT : 1)), block(256);
-    hipLaunchKernelGGL(flash_attn_bx_kernel, grid, block, B_LDS, s, a);
+    if (a.planes) {
+        if (hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(&flash_attn_bx_kernel<true>), B_LDS, lds_pre); e != hipSuccess) return e;
+        const long rows = (long)a.batch * a.heads * a.n_max;
+        hipLaunchKernelGGL(kv_planes_kernel, dim3((unsigned)((rows + 31) / 32), 2), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(flash_attn_bx_kernel<true>, grid, block, B_LDS, s, a);
+    } else {
+        if (hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(&flash_attn_bx_kernel<false>), B_LDS, lds_cut); e != hipSuccess) return e;
+        hipLaunchKernelGGL(flash_attn_bx_kernel<false>, grid, block, B_LDS, s, a);
+    }
     return hipGetLastError();
 }
 

@@ -145,7 +145,15 @@ int im_flash_attn(im_ctx* ctx, const float* d_q, const float* d_k, const float* 
         ctx->dfree(ctx->stage_attn_cnt);
         ctx->stage_attn_part = p; ctx->stage_attn_cnt = c; ctx->stage_attn_floats = nf; ctx->stage_attn_ints = ni;
     }
-    a.part = ctx->stage_attn_part; a.counters = ctx->stage_attn_cnt;
+    const size_t nb = attn_planes_bytes(n_max, batch, heads);
+    if (nb > ctx->stage_attn_plane_bytes) {
+        IM_HIP(ctx, hipDeviceSynchronize());
+        unsigned char* p = ctx->dalloc<unsigned char>(nb, "stage_attn_planes");
+        if (!p) return ctx->fail(-11, "im_flash_attn: out of device memory");
+        ctx->dfree(ctx->stage_attn_planes);
+        ctx->stage_attn_planes = p; ctx->stage_attn_plane_bytes = nb;
+    }
+    a.part = ctx->stage_attn_part; a.counters = ctx->stage_attn_cnt; a.planes = ctx->stage_attn_planes;
     IM_HIP(ctx, launch_flash_attn(a, (hipStream_t)stream));
     IM_GUARD_CHECK(ctx, (hipStream_t)stream, "im_flash_attn");
     return 0;

@@ -94,6 +94,7 @@ struct im_ctx {
     int max_h = 0, max_w = 0, max_images = 0, max_kpts = 0;
     struct Workspace* ws = nullptr;
     float* stage_attn_part = nullptr; int* stage_attn_cnt = nullptr; size_t stage_attn_floats = 0, stage_attn_ints = 0;  // im_flash_attn
+    unsigned char* stage_attn_planes = nullptr; size_t stage_attn_plane_bytes = 0;                                       // im_flash_attn (attention_bx.hip)
     im::MergeScratch* merge = nullptr;   // scratch of im_merge_tile_matches (tile_merge.hip), grown on demand
     int dbg_cur = 0;  // which ping-pong descriptor buffer the last LightGlue forward ended in (im_debug_read)
 

@@ -78,9 +78,13 @@ struct AttnArgs {
     // ATTN_MAX_SPLIT key ranges on separate blocks; the last block to finish merges the partials (fixed order)
     float* part = nullptr;       // [ATTN_MAX_SPLIT][batch][heads][n_max][66]  (64 x O, m, l)
     int* counters = nullptr;     // [batch * heads * ceil(n_max / 128)], zero before the first launch, self-resetting
+    // attention_bx.hip (optional): K and V of the launch as bf16 triples, written by its own first kernel: [K | V][batch][heads][n_max][3][64] bf16.
+    // Without it the attention kernel cuts the fp32 tiles itself, once per 128-query block
+    void* planes = nullptr;
 };
 static constexpr int ATTN_MAX_SPLIT = 4;
 inline size_t attn_part_floats(int n_max, int batch, int heads) { return (size_t)ATTN_MAX_SPLIT * batch * heads * n_max * 66; }
+inline size_t attn_planes_bytes(int n_max, int batch, int heads) { return (size_t)2 * batch * heads * n_max * 384; }
 inline size_t attn_counter_ints(int n_max, int batch, int heads) { return (size_t)batch * heads * ((n_max + 127) / 128); }
 hipError_t launch_flash_attn(const AttnArgs& a, hipStream_t s);      // attention_bx.hip unless IM_ATTN_F32=1 (attention.hip: the f32-input MFMA form)
 hipError_t launch_flash_attn_bx(const AttnArgs& a, hipStream_t s);   // fp32 accuracy from six bf16 products per fp32 product on the bf16 matrix cores

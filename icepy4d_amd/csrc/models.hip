@@ -342,6 +342,7 @@ int im_ctx_reserve(im_ctx* ctx, int max_h, int max_w, int max_images, int max_kp
     A(ws->q, NI * K * 256); A(ws->k, NI * K * 256); A(ws->v, NI * K * 256);
     A(ws->att, NI * K * 256); A(ws->msg, NI * K * 256); A(ws->h, NI * K * 512);
     A(ws->attn_part, attn_part_floats((int)K, (int)NI, 4)); A(ws->attn_cnt, attn_counter_ints((int)K, (int)NI, 4));
+    A(ws->attn_planes, attn_planes_bytes((int)K, (int)NI, 4));
     A(ws->conf, NI * K); A(ws->msc, NI * K); A(ws->keep_idx, NI * K); A(ws->prune, NI * K);
     A(ws->md, NI * K * 256); A(ws->z, NI * K); A(ws->lz, NI * K);
     ws->sim_ps = (((size_t)K * K + (size_t)K + 4) + 3) & ~(size_t)3;     // floats between the score matrices of consecutive pairs
@@ -465,7 +466,7 @@ static int lg_block(im_ctx* ctx, hipStream_t s, int NI, int layer, bool cross, f
     AttnArgs at;
     at.q = ws->q; at.k = cross ? ws->q : ws->k; at.v = ws->v; at.hstride = (long)K * 64; at.bstride = (long)K * 256;
     at.out = ws->att; at.out_bstride = xb; at.ldo = 256; at.n_ptr = n_ptr; at.pstride = ST_INTS; at.n_max = K; at.batch = NI; at.heads = 4;
-    at.cross = cross ? 1 : 0; at.active = active; at.part = ws->attn_part; at.counters = ws->attn_cnt;
+    at.cross = cross ? 1 : 0; at.active = active; at.part = ws->attn_part; at.counters = ws->attn_cnt; at.planes = ws->attn_planes;
     if (!cross) {
         GemmArgs g = base;
         g.A = x; g.a_bstride = xb; g.lda = 256; g.W = W.qkv_w + (long)layer * 768 * 256; g.ldw = 256;

@@ -24,6 +24,7 @@ struct Workspace {
     float* q = nullptr; float* k = nullptr; float* v = nullptr;
     float* att = nullptr; float* msg = nullptr; float* h = nullptr;
     float* attn_part = nullptr; int* attn_cnt = nullptr;   // split-KV partials and block counters (attention.hip)
+    unsigned char* attn_planes = nullptr;                  // K / V of one attention launch as bf16 triples (attention_bx.hip)
     float* conf = nullptr; float* msc = nullptr; int* keep_idx = nullptr; int* prune = nullptr;
     float* md = nullptr; float* z = nullptr; float* lz = nullptr;
     float* sim = nullptr; float* sim2 = nullptr;
