@@ -349,7 +349,9 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bx_kernel(AttnArgs a) {
     // LDS reads run one group ahead: K fragments of d-chunk s + 1 during chunk s, the six transposed V reads of (chunk, d-tile) group g + 1
     // during group g.
     static constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};   // the six products, small ones first: A plane, B plane
-    for (int t = 0; t < nt - 1; ++t) {
+    float m_use = 0.f;
+    if (nt >= 2) m_use = softmax_ref<false>(sc, 0, nk, hh, m_run, l_run, o0, o1);     // tile 0 lies inside the keys
+    for (int t = 0; t < nt - 2; ++t) {       // tiles t and t + 1 lie inside the keys: no masks anywhere
         const unsigned char* const kp = kring + ((t + 1) & 1) * 3 * BK_PLANE + rd_k;
         const unsigned char* const vp = vring + (t & 1) * 3 * BV_PLANE + rd_v;
         u32x4 kf[2][3];
@@ -360,7 +362,6 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bx_kernel(AttnArgs a) {
         store_v((t + 1) & 1);
         load_k(t + 3);
         load_v(t + 2);
-        const float m_use = softmax_ref<false>(sc, 0, nk, hh, m_run, l_run, o0, o1);
         __builtin_amdgcn_sched_barrier(0);
 
         float ra[8], rb[8], rsum0 = 0.f, rsum1 = 0.f;
@@ -399,8 +400,9 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bx_kernel(AttnArgs a) {
         };
 
         // ---- slots 0..23: S(t+1) = K(t+1) . Q^T
+        f32x16 xa, xb;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sn[r] = 0.f;
+        for (int r = 0; r < 16; ++r) { xa[r] = 0.f; xb[r] = 0.f; }
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
             if (s4 < 3) {
@@ -411,7 +413,8 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bx_kernel(AttnArgs a) {
             for (int j = 0; j < 6; ++j) {
                 const int slot = 6 * s4 + j;
                 const u32x4 qb = PB[j] == 0 ? qh[s4] : (PB[j] == 1 ? qm[s4] : ql[s4]);
-                sn = mfma_bf(kf[s4 & 1][PA[j]], qb, sn);
+                if (j & 1) xb = mfma_bf(kf[s4 & 1][PA[j]], qb, xb);
+                else xa = mfma_bf(kf[s4 & 1][PA[j]], qb, xa);
                 if (slot < 8) expo(slot);
                 else if (slot < 16) { if (slot & 1) cut_b((slot - 8) >> 1); else cut_a((slot - 8) >> 1); }
                 else { expo(slot - 8); if (slot < 20) cut_l(slot - 16); }
@@ -420,6 +423,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bx_kernel(AttnArgs a) {
             }
         }
         // ---- slots 24..47: O^T += V(t)^T . P(t)^T, groups g = (key chunk g >> 1, d-tile g & 1)
+        float mxn = 0.f;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int ks = g >> 1;
@@ -436,6 +440,17 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bx_kernel(AttnArgs a) {
                 else o0 = mfma_bf(vf[PA[j]], pp[PB[j]], o0);
                 if (slot < 8) { if (slot & 1) cut_b(4 + (slot >> 1)); else cut_a(4 + (slot >> 1)); }
                 else if (slot < 12) cut_l(4 + slot - 8);
+                if (slot >= 8 && slot < 16) {                     // S(t+1) = the two accumulators, two registers per slot
+                    float u0 = xa[2 * (slot - 8)] + xb[2 * (slot - 8)], u1 = xa[2 * (slot - 8) + 1] + xb[2 * (slot - 8) + 1];
+                    BX_PIN(u0); BX_PIN(u1);
+                    sn[2 * (slot - 8)] = u0; sn[2 * (slot - 8) + 1] = u1;
+                }
+                if (slot >= 16 && slot < 24) {                    // its row maximum, one v_max3 per slot
+                    const int i = slot - 16;
+                    float u = i == 0 ? bmax3(sn[0], sn[1], sn[2]) : (i == 7 ? fmaxf(mxn, sn[15]) : bmax3(mxn, sn[2 * i + 1], sn[2 * i + 2]));
+                    BX_PIN(u);
+                    mxn = u;
+                }
                 if (g < 3) {
                     const int gn = g + 1;
                     vr[gn & 1][j] = tr_read(vp + (16 * (gn >> 1)) * BVS + 64 * (gn & 1) + (j >> 1) * BV_PLANE + (j & 1) * 8 * BVS);
@@ -446,12 +461,35 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bx_kernel(AttnArgs a) {
         float rs = rsum0 + rsum1;
         rs += __shfl_xor(rs, 32);
         l_run += rs;
+        // the reference of tile t + 1, behind the last MFMA that accumulates into O with the old one
+        mxn = fmaxf(mxn, __shfl_xor(mxn, 32));
+        if (__builtin_amdgcn_ballot_w64(mxn > m_run + BX_SLACK) != 0) {
+            asm volatile("" ::: "memory");
+            const float m_new = fmaxf(m_run, mxn);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            l_run *= alpha;
+            o0 *= alpha;
+            o1 *= alpha;
+            m_run = m_new;
+        }
+        m_use = m_run;
+        sc = sn;
+        __syncthreads();
+    }
+#undef BX_PIN
+    if (nt >= 2) {                           // step nt - 2 in plain form: its look-ahead tile is the last one, whose reference needs the mask
+        const int t = nt - 2;
+        store_k(t & 1);
+        store_v((t + 1) & 1);
+        qk((t + 1) & 1, sn);
+        softmax_exp(sc, m_use, l_run);
+        pv_mul(t & 1, sc);
         sc = sn;
         __syncthreads();
     }
     {
         const int t = nt - 1;
-        const float m_use = softmax_ref<true>(sc, t * BKT, nk, hh, m_run, l_run, o0, o1);
+        m_use = softmax_ref<true>(sc, t * BKT, nk, hh, m_run, l_run, o0, o1);
         softmax_exp(sc, m_use, l_run);
         pv_mul(t & 1, sc);
     }
