@@ -33,6 +33,17 @@ sys.path.insert(0, ROOT)
 H, W, KPTS = 1080, 1920, 4096
 H5, W5, KPTS5 = 3000, 4000, 16384
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0 # same guide: dense bf16 matrix peak (the 5 PFLOP/s headline includes 2:1 sparsity)
+# The attention kernel (csrc/attention_bx.hip) computes every fp32 product as SIX bf16 products on the bf16 matrix cores (fp32 operands cut
+# into three bf16 values, fp32 accumulation: error at or below the f32-input MFMA chain's, profiles/r05_bf16x_probe.txt). Its roofline is
+# the bf16 peak divided by the six products an algorithmic fp32 FLOP costs.
+ATTN_BF16_PRODUCTS = 6
+PEAK_ATTN_F32_EQUIVALENT_TFLOPS = PEAK_BF16_MFMA_TFLOPS / ATTN_BF16_PRODUCTS
+ATTN_F32_FORM = os.environ.get("IM_ATTN_F32", "0") not in ("", "0")   # the f32-input MFMA kernel of rounds 1-5 (csrc/attention.hip), for A/B
+ATTN_KERNEL = "im::flash_attn_f32_kernel" if ATTN_F32_FORM else "im::flash_attn_bx_kernel"
+PEAK_ATTN_TFLOPS = PEAK_F32_MFMA_TFLOPS if ATTN_F32_FORM else PEAK_ATTN_F32_EQUIVALENT_TFLOPS
+DTYPE_NOTE = ("fp32 end to end, as the reference: convolutions, GEMMs and the feed-forward on the f32-input MFMA; the attention's fp32 products as six "
+              "bf16 products each on the bf16 matrix cores with fp32 accumulation (error at or below the f32 MFMA chain's)")
 PEAK_HBM_GBS = 8000.0          # same guide: HBM3E spec peak (6.3 TB/s is what a copy kernel reaches)
 # Pairs per launch of the timed region (`--batch`): the batch dimension over pairs inside the kernels. Measured on one MI355X with two
 # launch groups in flight (round 3, three boxes): 2 -> 105.8, 4 -> 107.3, 5 -> 107.5, 8 -> 108.1, 10 -> 107.0-108 (the maximum on every box),
@@ -355,7 +366,7 @@ def main():
     result = {
         "metric": metric, "value": n_pairs / dt, "unit": "pairs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "dtype_note": DTYPE_NOTE, "data": "synthetic",
         "config": {"workload": workload, "height": h, "width": w, "max_keypoints": kpts, "pairs_per_step": 1,
                    "pair_synthesis": args.pairs if not cfg5 else "translated", "hip_graph": not args.no_graph,
                    "launch_groups_in_flight": n_streams, "pairs_per_launch": args.batch,
@@ -448,9 +459,9 @@ def main():
                "per-launch durations are not kernel properties); rocprofv3 --stats of `bench.py --streams 1` in profiles/ agrees")
         # group the launch classes by kernel symbol, as rocprofv3 --stats does, and take the symbol with the largest time
         if cfg5:
-            groups = {"im::flash_attn_f32_kernel": ["flash_attn_self", "flash_attn_cross"]}
+            groups = {ATTN_KERNEL: ["flash_attn_self", "flash_attn_cross"]}
         else:
-            groups = {"im::flash_attn_f32_kernel": ["flash_attn_self", "flash_attn_cross"],
+            groups = {ATTN_KERNEL: ["flash_attn_self", "flash_attn_cross"],
                       "im::conv3x3_wino_kernel<POOL, FUSE1A, UREG> (all instantiations)": ["conv1b", "conv2a", "conv2b", "conv3a", "conv3b", "conv4a",
                                                                                              "conv4b", "convPa", "convDa"]}
         gstat = {}
@@ -463,22 +474,38 @@ def main():
         dom = max(gstat, key=lambda k: gstat[k][0])
         ms, cnt, fl = gstat[dom]
         ach = fl / (ms * 1e-3) / 1e12
-        result["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                              "frac": ach / PEAK_F32_MFMA_TFLOPS,
-                              "traffic": traffic_db.get(dom + "<2>" + ("@16384" if cfg5 else ""), {}).get("traffic_bytes"),
+        peak = PEAK_ATTN_TFLOPS if dom == ATTN_KERNEL else PEAK_F32_MFMA_TFLOPS
+        tkey = dom + ("<2>" if dom == "im::flash_attn_f32_kernel" else "<true>" if dom == ATTN_KERNEL else "")
+        result["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                              "frac": ach / peak,
+                              "traffic": traffic_db.get(tkey + ("@16384" if cfg5 else ""), {}).get("traffic_bytes"),
                               "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of a builder run, "
                                                 "FETCH_SIZE doubled per the gfx950 correction; NOT measured by this run)",
                               "avg_launch_ms": ms / cnt,
                               "launches_per_pair": cnt / prof_steps, "algorithmic_gflop_per_launch": fl / cnt / 1e9,
                               "share_of_pair_time": ms / tot, "event_pair_overhead_us": round(1e3 * ev_overhead_ms, 2),
                               "measured": how}
-        if dom == "im::flash_attn_f32_kernel":
+        if dom == ATTN_KERNEL and not ATTN_F32_FORM:
+            result["roofline"].update({
+                "peak_is": f"{PEAK_BF16_MFMA_TFLOPS:.0f} TFLOP/s dense bf16 MFMA (MI355X_MICROARCH.md) / {ATTN_BF16_PRODUCTS}: the kernel computes every "
+                           "algorithmic fp32 FLOP as six bf16 products on the bf16 matrix cores (fp32 operands as exact sums of three bf16 "
+                           "values, fp32 accumulation; accuracy at or below the f32-input MFMA chain's error: profiles/r05_bf16x_probe.txt). "
+                           "`achieved` counts ALGORITHMIC fp32 FLOPs, as in every earlier round",
+                "executed_bf16_tflops": ach * ATTN_BF16_PRODUCTS * (4.0 * 256 * (n0 * n0 + n1 * n1) * prof.get("flash_attn_self", {}).get("count", 0)
+                                                                   + 8.0 * 256 * n0 * n1 * prof.get("flash_attn_cross", {}).get("count", 0)) / fl,
+                "vs_f32_input_mfma_peak": ach / PEAK_F32_MFMA_TFLOPS,
+                "vs_f32_input_mfma_peak_is": "the same algorithmic rate against the 157.3 TFLOP/s of the f32-input MFMA, the roofline of rounds 1-5's "
+                                             "kernel (csrc/attention.hip, IM_ATTN_F32=1: 0.745 there). A ratio, not a utilisation: this kernel does "
+                                             "not run on that pipe",
+                "sustained_clock_note": "bf16 MFMA loops on random data hold 1.5-1.95 GHz on this part, not 2.4 (guide, DVFS give-back): the "
+                                        "guide's own dense bf16 GEMM example sustains 1,247 TFLOP/s = 0.50 of the spec peak used here"})
+        if dom == ATTN_KERNEL:
             # the two launch kinds of the class apart: self-attention (4 . 256 . n^2 per image) and the cross block, whose two
             # launches execute 8 . 256 . n^2 for an algorithmic 6 . 256 . n^2 (S = Q0 Q1^T is computed once per direction)
             for kname in ("flash_attn_self", "flash_attn_cross"):
                 if kname in prof and prof[kname]["count"]:
                     f1 = kernel_flops(kname, 2, n0, n1, h, w, cfg5)
-                    result["roofline"]["frac_" + kname.split("_")[-1]] = f1 / (prof[kname]["total_ms"] / prof[kname]["count"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS
+                    result["roofline"]["frac_" + kname.split("_")[-1]] = f1 / (prof[kname]["total_ms"] / prof[kname]["count"] * 1e-3) / 1e12 / PEAK_ATTN_TFLOPS
         if cfg5 and "sinkhorn" in prof:
             # Sinkhorn: (2 x iterations) sweeps over the (M+1)(N+1) fp32 couplings, one "launch" here = the whole 20-iteration
             # solve of one pair (41 kernel launches of three symbols; rocprofv3 lists them separately)
@@ -500,13 +527,22 @@ def main():
         pair_flops = (2 * 2035e9 + 10818e9) if cfg5 else (2 * 351.7e9 + 734.4e9)  # algorithmic FLOPs per pair
         # speed of light by ALGORITHMIC FLOPs (direct-form convolutions): the 3x3 layers run as Winograd F(2x2, 3x3), which executes
         # 1 / 2.25 of those multiplies, so this figure is not a utilisation and may exceed 1; the executed-FLOP figure is next to it
-        result["pair_algorithmic_speed_of_light_frac"] = pair_flops * (n_pairs / dt) / world / (PEAK_F32_MFMA_TFLOPS * 1e12)
+        result["pair_algorithmic_tflops"] = pair_flops * (n_pairs / dt) / world / 1e12
+        result["pair_algorithmic_tflops_is"] = ("SURVEY 8d's algorithmic fp32 FLOPs per pair x pairs/s. Not a utilisation of anything: the 3x3 convolutions run as "
+                                                "Winograd F(2x2, 3x3) (1 / 2.25 of the multiplies) on the f32-input MFMA (157.3 TFLOP/s), the attention on the "
+                                                "bf16 matrix cores at six products per fp32 product; `pair_matrix_pipe_time_at_peak_frac` is the utilisation figure")
         if not cfg5:
             conv3 = 2 * sum(conv_flops(*d) for d in ((h, w, 64, 64), (h // 2, w // 2, 64, 64), (h // 2, w // 2, 64, 64), (h // 4, w // 4, 64, 128),
                                                      (h // 4, w // 4, 128, 128), (h // 8, w // 8, 128, 128), (h // 8, w // 8, 128, 128),
                                                      (h // 8, w // 8, 128, 256), (h // 8, w // 8, 128, 256)))
-            executed = pair_flops - conv3 * (1 - 1 / 2.25) + 2.0 * 256 * n0 * n1 * 9   # Winograd multiplies; S computed once per direction
-            result["pair_executed_mfma_utilisation"] = executed * (n_pairs / dt) / world / (PEAK_F32_MFMA_TFLOPS * 1e12)
+            attn_exec = 9 * (4.0 * 256 * (n0 * n0 + n1 * n1) + 8.0 * 256 * n0 * n1)   # executed fp32-equivalent FLOPs of the 18 attention launches
+            attn_alg = 9 * (4.0 * 256 * (n0 * n0 + n1 * n1) + 6.0 * 256 * n0 * n1)
+            rest_exec = pair_flops - attn_alg - conv3 * (1 - 1 / 2.25)                  # everything else, Winograd multiplies counted as executed
+            pipe_s = rest_exec / (PEAK_F32_MFMA_TFLOPS * 1e12) + attn_exec / (PEAK_ATTN_TFLOPS * 1e12)
+            # seconds the matrix pipes need for the executed work of one pair at their peaks (f32-input MFMA for convolutions / GEMMs / feed-forward,
+            # bf16 cores at six products per fp32 product for the attention) / seconds a pair takes
+            result["pair_matrix_pipe_time_at_peak_frac"] = pipe_s * (n_pairs / dt) / world
+            result["pair_executed_mfma_utilisation"] = result["pair_matrix_pipe_time_at_peak_frac"]     # the name of rounds 3-5, same meaning
 
         # ---- CPU baseline: the oracle (torch-CPU fp32 restatement of the reference path) on this box's host cores
         if world == 1 and not args.no_cpu_baseline and not cfg5:
@@ -638,8 +674,10 @@ def config5_side(args, local_rank, sp_sd, host_pair):
     cnt = sum(prof[k]["count"] for k in ("flash_attn_self", "flash_attn_cross") if k in prof)
     fl = sum(kernel_flops(k, 2, n0, n1, H5, W5, True) * prof[k]["count"] for k in ("flash_attn_self", "flash_attn_cross") if k in prof)
     if cnt:
-        out["attention"] = {"avg_launch_ms": ms / cnt, "achieved_tflops": fl / (ms * 1e-3) / 1e12,
-                            "frac_of_fp32_mfma_peak": fl / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}
+        out["attention"] = {"avg_launch_ms": ms / cnt, "achieved_tflops": fl / (ms * 1e-3) / 1e12, "peak_tflops": PEAK_ATTN_TFLOPS,
+                            "frac_of_peak": fl / (ms * 1e-3) / 1e12 / PEAK_ATTN_TFLOPS,
+                            "vs_f32_input_mfma_peak": fl / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                            "peak_is": "see roofline.peak_is: bf16 dense MFMA peak / 6 products per fp32 product (157.3 with IM_ATTN_F32=1)"}
     if "sinkhorn" in prof and prof["sinkhorn"]["count"]:
         sk = prof["sinkhorn"]
         solve_ms = sk["total_ms"] / sk["count"]
@@ -811,7 +849,7 @@ def dry_run(args, rank, world, epochs, kpts, dist):
     if rank == 0:
         emit(json.dumps({"ranks": ranks, "metric": "matched stereo image-pairs/sec (4096 kpts, 1080p)", "value": n_pairs / dt, "unit": "pairs/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "dtype_note": DTYPE_NOTE, "data": "synthetic",
                           "config": {"workload": "DRY RUN: fabricated records, no GPU work"}, "dry_run": True,
                           "failed_epochs": sorted(int(e) for e in full[full[:, 3] < 0, 0].tolist()),
                           "roofline": None, "cpu_baseline": None}))

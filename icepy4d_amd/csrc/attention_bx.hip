@@ -25,6 +25,8 @@
 #include "kernels.h"
 #include "sp_post.h"
 
+#include <cstdlib>
+
 namespace im {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -554,13 +556,20 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bx_kernel(AttnArgs a) {
     }
 }
 
+// K / V of the launch as bf16 triples (a.planes); a launch of its own so that event profiles and rocprofv3 name the two kernels apart
+hipError_t launch_attn_planes(const AttnArgs& a, hipStream_t s) {
+    static const bool f32_form = [] { const char* e = getenv("IM_ATTN_F32"); return e && atoi(e) != 0; }();
+    if (!a.planes || a.n_max <= 0 || f32_form) return hipSuccess;
+    const long rows = (long)a.batch * a.heads * a.n_max;
+    hipLaunchKernelGGL(kv_planes_kernel, dim3((unsigned)((rows + 31) / 32), 2), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_flash_attn_bx(const AttnArgs& a, hipStream_t s) {
     static size_t lds_pre[IM_MAX_DEVICES] = {0}, lds_cut[IM_MAX_DEVICES] = {0};
     dim3 grid(((a.n_max + 127) / 128) * a.heads * a.batch * (a.part ? ATTN_MAX_SPLIT : 1)), block(256);
-    if (a.planes) {
+    if (a.planes) {     // filled by launch_attn_planes on the same stream
         if (hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(&flash_attn_bx_kernel<true>), B_LDS, lds_pre); e != hipSuccess) return e;
-        const long rows = (long)a.batch * a.heads * a.n_max;
-        hipLaunchKernelGGL(kv_planes_kernel, dim3((unsigned)((rows + 31) / 32), 2), dim3(256), 0, s, a);
         hipLaunchKernelGGL(flash_attn_bx_kernel<true>, grid, block, B_LDS, s, a);
     } else {
         if (hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(&flash_attn_bx_kernel<false>), B_LDS, lds_cut); e != hipSuccess) return e;

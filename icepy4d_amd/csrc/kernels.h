@@ -87,6 +87,7 @@ inline size_t attn_part_floats(int n_max, int batch, int heads) { return (size_t
 inline size_t attn_planes_bytes(int n_max, int batch, int heads) { return (size_t)2 * batch * heads * n_max * 384; }
 inline size_t attn_counter_ints(int n_max, int batch, int heads) { return (size_t)batch * heads * ((n_max + 127) / 128); }
 hipError_t launch_flash_attn(const AttnArgs& a, hipStream_t s);      // attention_bx.hip unless IM_ATTN_F32=1 (attention.hip: the f32-input MFMA form)
+hipError_t launch_attn_planes(const AttnArgs& a, hipStream_t s);     // a.planes <- K / V as bf16 triples; call before launch_flash_attn when a.planes is set
 hipError_t launch_flash_attn_bx(const AttnArgs& a, hipStream_t s);   // fp32 accuracy from six bf16 products per fp32 product on the bf16 matrix cores
 
 // ------------------------------------------------------------------ conv.hip

@@ -484,6 +484,7 @@ static int lg_block(im_ctx* ctx, hipStream_t s, int NI, int layer, bool cross, f
         IM_LAUNCH(ctx, "lg_proj_gemm", s, launch_gemm(g, s));
         at.scale = 1.f;
     }
+    IM_LAUNCH(ctx, "attn_kv_planes", s, launch_attn_planes(at, s));
     IM_LAUNCH(ctx, cross ? "flash_attn_cross" : "flash_attn_self", s, launch_flash_attn(at, s));
     // A/B switch: IM_FFN_UNFUSED=1 keeps the three-launch form (ffn.0 GEMM, LayerNorm + GELU, ffn.3 GEMM + residual)
     static const bool unfused = getenv("IM_FFN_UNFUSED") && getenv("IM_FFN_UNFUSED")[0] == '1';

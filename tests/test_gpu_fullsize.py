@@ -181,7 +181,7 @@ def test_bench_line_with_odd_step_counts(flags):
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["steps"] == int(flags[1]) and d["warmup"] == int(flags[3]) and d["unit"] == "pairs/s"
-    assert d["config"]["mean_keypoints"] == 4096 and d["roofline"]["bound"] == "mfma" and 0.5 < d["roofline"]["frac"] < 1.0
+    assert d["config"]["mean_keypoints"] == 4096 and d["roofline"]["bound"] == "mfma" and 0.2 < d["roofline"]["frac"] < 1.0
     assert d["value"] > 5.0, d["value"]      # a sanity bound, not a performance threshold (a cold or shared device is slower)
     assert "all_gather_ms" in d and "traffic_source" in d["roofline"] and "pair_executed_mfma_utilisation" in d
     if side:
@@ -189,7 +189,7 @@ def test_bench_line_with_odd_step_counts(flags):
         c3, c5, mc = sm["config3_distinct_epochs"], sm["config5"], sm["match_call_ms"]
         assert c3["pairs"] >= 60 and c3["epochs_distinct_and_in_order"] and c3["pairs_per_s"] > 5.0
         assert c5["pairs"] == 3 and c5["mean_keypoints"] == 16384 and c5["pairs_per_s"] > 0.5
-        assert 0.5 < c5["attention"]["frac_of_fp32_mfma_peak"] < 1.0 and 1.0 < c5["sinkhorn"]["solve_ms"] < 50.0
+        assert 0.2 < c5["attention"]["frac_of_peak"] < 1.0 and 1.0 < c5["sinkhorn"]["solve_ms"] < 50.0
         assert 1.0 < mc["median"] < 500.0 and mc["keypoints"] == 4096
         assert sm["other_launch_mode"]["pairs_per_s"] > 5.0 and sm["host_inputs_pairs_per_s"]["pairs_per_s"] > 5.0
     if "--config" in flags:                 # configs[3] on one rank: 98 KB records (keypoints of both images ride along)
