@@ -5,19 +5,25 @@
 // It replaces three launches (ffn.0 GEMM, LayerNorm + GELU, ffn.3 GEMM + residual) and the two HBM round trips of the 512-wide
 // hidden rows (3 x 16.8 MB per launch at 2 x 4096 keypoints).
 //
-// A block owns 32 rows of one image and holds them in LDS for the whole kernel: first [x | att] (32 x 512 floats), then - in
-// the same buffer - the hidden rows. 8 waves: in the first GEMM a wave owns 64 of the 512 hidden columns (two 32 x 32 MFMA
-// tiles), in the second 32 of the 256 output columns (one tile). With a single row tile per block nothing of W is shared
-// between the waves of a block, so W never goes through LDS: the weights are packed at load time in MFMA-fragment order
-// ([column tile][k group of 8][lane][4 floats]: a wave's 16-byte-per-lane load is one contiguous KiB) and stream from L2
-// straight into registers, double-buffered one 32-deep k chunk (32 MFMAs per wave) ahead. Between the four block barriers
-// (inputs staged / first GEMM done / hidden rows normalised / - ) the waves run free of each other.
+// Round 5: both products run on the bf16 matrix cores with fp32 accuracy, as the attention does (attention_bx.hip: an fp32 value is the
+// exact sum of three bf16 values, six bf16 products per fp32 product, fp32 accumulation; error at or below the f32-input MFMA chain's,
+// profiles/r05_bf16x_probe.txt). The weights are cut into their three planes on the host, once per weight set; the rows are cut when
+// they are written to LDS - the inputs by the staging pass, the hidden rows by the LayerNorm / GELU pass - so every value is cut once.
+//
+// A block owns 32 rows of one image and holds them in LDS for the whole kernel: first [x | att] as three bf16 planes (32 x 512 each),
+// then - over the same bytes - the hidden rows in fp32 for the normalisation, then their planes. 8 waves: in the first GEMM a wave owns 64
+// of the 512 hidden columns (two 32 x 32 MFMA tiles), in the second 32 of the 256 output columns (one tile). With a single row tile
+// per block nothing of W is shared between the waves of a block, so W never goes through LDS: the planes are packed in MFMA-fragment
+// order ([column tile][k chunk of 16][plane][lane][8 bf16]: a wave's 16-byte-per-lane load is one contiguous KiB) and stream from L2
+// straight into registers, double-buffered one 32-deep k chunk (24 / 12 MFMAs per wave) ahead.
 //
 // LayerNorm is the two-pass form of lg_misc.hip's layernorm_gelu_kernel (mean, then centred sum of squares, eps 1e-5, erf GELU).
 #include "common.h"
 #include "kernels.h"
 #include "sp_post.h"
 
+#include <cstdint>
+#include <cstring>
 #include <vector>
 
 namespace im {
@@ -25,31 +31,89 @@ namespace im {
 namespace ff {
 constexpr int BM = 32;              // rows per block
 constexpr int NT = 512;             // threads per block (8 waves)
-constexpr int LD = 516;             // LDS row stride in floats: 516 = 4 (mod 32), 16-byte fragment reads are conflict free
-constexpr int LDS_BYTES = BM * LD * 4;
-constexpr unsigned TILE_BYTES = (512 / 8) * 64 * 16;   // one packed 32-column tile at K = 512
+constexpr int LD = 516;             // fp32 row stride of the hidden rows (floats)
+constexpr int PS = 1040;            // bytes per row of a bf16 plane: 512 x 2 + 16 (conflict-free 16-byte row reads)
+constexpr int PLANE = BM * PS;      // 33,280 bytes
+constexpr int LDS_BYTES = 3 * PLANE;                    // 99,840 (>= BM * LD * 4 = 66,048)
+constexpr unsigned TILE_BYTES = (512 / 16) * 3 * 1024;  // one packed 32-column tile at K = 512: 32 k chunks x 3 planes x 1 KiB
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 }  // namespace ff
 
-// Fragment-order packing of a row-major W[N][K] (host side, once per weight set):
-//   out[tile = n / 32][G = k / 8][lane = hh * 32 + c][i] = W[tile * 32 + c][8 G + 4 hh + i]
-// MFMA step i of group G multiplies the k pair (8 G + i, 8 G + 4 + i); the A fragments are read with the same mapping.
+// host: fp32 -> bf16, round to nearest even (what v_cvt_pk_bf16_f32 does); the weights are finite
+static inline uint16_t host_bf16(float x) {
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static inline float host_bf16_to_float(uint16_t h) {
+    const uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+// Fragment-order packing of a row-major W[N][K] as three bf16 planes (host side, once per weight set):
+//   out[tile = n / 32][chunk = k / 16][plane][lane = hh * 32 + c][j] = plane of W[tile * 32 + c][16 chunk + 8 hh + j],  j = 0..7
+// (the B operand of v_mfma_f32_32x32x16_bf16: lane (c, hh) holds k = 8 hh + j of column c). 6 bytes per weight: the vector holds
+// n k 3 / 2 floats' worth of bytes.
 std::vector<float> pack_frag_weights(const float* w, int n, int k) {
-    std::vector<float> out((size_t)n * k);
-    const int groups = k / 8;
+    std::vector<float> out((size_t)n * k * 3 / 2);
+    uint16_t* o = reinterpret_cast<uint16_t*>(out.data());
+    const int chunks = k / 16;
     for (int t = 0; t < n / 32; ++t)
-        for (int g = 0; g < groups; ++g)
+        for (int ch = 0; ch < chunks; ++ch)
             for (int lane = 0; lane < 64; ++lane)
-                for (int i = 0; i < 4; ++i)
-                    out[(((size_t)t * groups + g) * 64 + lane) * 4 + i] = w[(size_t)(t * 32 + (lane & 31)) * k + 8 * g + 4 * (lane >> 5) + i];
+                for (int j = 0; j < 8; ++j) {
+                    const float x = w[(size_t)(t * 32 + (lane & 31)) * k + 16 * ch + 8 * (lane >> 5) + j];
+                    const uint16_t h = host_bf16(x);
+                    const float r1 = x - host_bf16_to_float(h);
+                    const uint16_t m = host_bf16(r1);
+                    const float r2 = r1 - host_bf16_to_float(m);
+                    const uint16_t l = host_bf16(r2);
+                    const size_t base = (((size_t)t * chunks + ch) * 3) * 512 + (size_t)lane * 8 + j;     // in bf16 elements; a plane block = 64 x 8
+                    o[base] = h; o[base + 512] = m; o[base + 1024] = l;
+                }
     return out;
 }
+
+namespace ff {
+__device__ __forceinline__ f32x16 mfma_bf(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ unsigned cvt_pk(float a, float b) {
+    const bf16x2 v = __builtin_convertvector(f32x2{a, b}, bf16x2);
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ void split2(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
+    h = cvt_pk(a, b);
+    float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
+    m = cvt_pk(ra, rb);
+    ra -= __uint_as_float(m << 16);
+    rb -= __uint_as_float(m & 0xffff0000u);
+    l = cvt_pk(ra, rb);
+}
+// four consecutive row values -> 8 bytes in each plane
+__device__ __forceinline__ void put4(unsigned char* plane0, int off, float4 x) {
+    unsigned h0, m0, l0, h1, m1, l1;
+    split2(x.x, x.y, h0, m0, l0);
+    split2(x.z, x.w, h1, m1, l1);
+    *reinterpret_cast<u32x2*>(plane0 + off) = u32x2{h0, h1};
+    *reinterpret_cast<u32x2*>(plane0 + PLANE + off) = u32x2{m0, m1};
+    *reinterpret_cast<u32x2*>(plane0 + 2 * PLANE + off) = u32x2{l0, l1};
+}
+}  // namespace ff
 
 // ACT 0: LayerNorm(512) + GELU between the two products (LightGlue); ACT 1: ReLU (SuperGlue's MLP with its BatchNorm folded into
 // W0 / b0, `SuperGlue/models/superglue.py:51-61, 104-116`)
 template <int ACT>
-__global__ __launch_bounds__(ff::NT, 4) void ffn_fused_kernel(FfnArgs a) {
+__global__ __launch_bounds__(ff::NT, 2) void ffn_fused_kernel(FfnArgs a) {
     using namespace ff;
-    extern __shared__ __attribute__((aligned(16))) float sA[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char sB[];
+    float* const sA = reinterpret_cast<float*>(sB);
     const int z = blockIdx.y, pair = z >> 1;
     if (a.active && a.active[pair * a.pstride] == 0) return;
     const int M = a.m_ptr ? a.m_ptr[pair * a.pstride + (z & 1)] : a.m_max;
@@ -61,28 +125,36 @@ __global__ __launch_bounds__(ff::NT, 4) void ffn_fused_kernel(FfnArgs a) {
 
     const __amdgpu_buffer_rsrc_t rX = gmake_rsrc(a.x + (long)z * a.x_bstride, (unsigned)M * 1024u);
     const __amdgpu_buffer_rsrc_t rAtt = gmake_rsrc(a.att + (long)z * a.att_bstride, (unsigned)M * 1024u);
-    const __amdgpu_buffer_rsrc_t rW0 = gmake_rsrc(a.w0p, 512u * 512u * 4u);
-    const __amdgpu_buffer_rsrc_t rW3 = gmake_rsrc(a.w3p, 256u * 512u * 4u);
+    const __amdgpu_buffer_rsrc_t rW0 = gmake_rsrc(a.w0p, 512u * 512u * 6u);
+    const __amdgpu_buffer_rsrc_t rW3 = gmake_rsrc(a.w3p, 256u * 512u * 6u);
 
-    // ---- first weight chunk in flight while the input rows are staged
+    // a weight chunk = 32 k = two MFMA k chunks x three planes (x two column tiles in the first product): 16-byte loads, 1 KiB per wave each
     const unsigned vb0 = (unsigned)(2 * wave) * TILE_BYTES + lane * 16u;
-    float4 p0[4], p1[4], q0[4], q1[4];
-#define FF_LOAD2(b0_, b1_, ch_)                                                     \
-    _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                 \
-        b0_[g] = gbuf_load4(rW0, vb0, (unsigned)((ch_) * 4 + g) * 1024u);            \
-        b1_[g] = gbuf_load4(rW0, vb0 + TILE_BYTES, (unsigned)((ch_) * 4 + g) * 1024u); \
+    u32x4 p0[6], p1[6], q0[6], q1[6];
+#define FF_LOAD2(b0_, b1_, ch_)                                                                                  \
+    _Pragma("unroll") for (int g = 0; g < 6; ++g) {                                                              \
+        b0_[g] = __builtin_amdgcn_raw_buffer_load_b128(rW0, vb0, (unsigned)((ch_) * 6 + g) * 1024u, 0);              \
+        b1_[g] = __builtin_amdgcn_raw_buffer_load_b128(rW0, vb0 + TILE_BYTES, (unsigned)((ch_) * 6 + g) * 1024u, 0); \
     }
-#define FF_MMA2(b0_, b1_, ch_)                                                                                  \
-    _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                             \
-        const float4 fa = *reinterpret_cast<const float4*>(sA + c * LD + ((ch_) * 4 + g) * 8 + hh * 4);         \
-        acc0 = mfma32(fa.x, b0_[g].x, acc0); acc1 = mfma32(fa.x, b1_[g].x, acc1);                               \
-        acc0 = mfma32(fa.y, b0_[g].y, acc0); acc1 = mfma32(fa.y, b1_[g].y, acc1);                               \
-        acc0 = mfma32(fa.z, b0_[g].z, acc0); acc1 = mfma32(fa.z, b1_[g].z, acc1);                               \
-        acc0 = mfma32(fa.w, b0_[g].w, acc0); acc1 = mfma32(fa.w, b1_[g].w, acc1);                               \
+    // the six products of one 16-deep k chunk, small ones first: A planes (h, m, l) from LDS, B planes b[3 kc + (0, 1, 2)]
+#define FF_SIX(acc_, ah_, am_, al_, b_, kc_)              \
+    acc_ = mfma_bf(ah_, b_[3 * (kc_) + 2], acc_);         \
+    acc_ = mfma_bf(al_, b_[3 * (kc_) + 0], acc_);         \
+    acc_ = mfma_bf(am_, b_[3 * (kc_) + 1], acc_);         \
+    acc_ = mfma_bf(ah_, b_[3 * (kc_) + 1], acc_);         \
+    acc_ = mfma_bf(am_, b_[3 * (kc_) + 0], acc_);         \
+    acc_ = mfma_bf(ah_, b_[3 * (kc_) + 0], acc_);
+#define FF_MMA2(b0_, b1_, ch_)                                                                                   \
+    _Pragma("unroll") for (int kc = 0; kc < 2; ++kc) {                                                           \
+        const unsigned char* ap = sB + c * PS + ((ch_) * 32 + kc * 16 + hh * 8) * 2;                             \
+        const u32x4 ah = *reinterpret_cast<const u32x4*>(ap), am = *reinterpret_cast<const u32x4*>(ap + PLANE),  \
+                    al = *reinterpret_cast<const u32x4*>(ap + 2 * PLANE);                                        \
+        FF_SIX(acc0, ah, am, al, b0_, kc)                                                                        \
+        FF_SIX(acc1, ah, am, al, b1_, kc)                                                                        \
     }
     FF_LOAD2(p0, p1, 0)
     {
-        // [x | att] rows -> LDS. idx & 127 < 64 <=> even wave: the source is wave-uniform.
+        // [x | att] rows -> planes in LDS. idx & 127 < 64 <=> even wave: the source is wave-uniform.
         const bool second = (wave & 1) != 0;
         float4 v[8];
 #pragma unroll
@@ -93,7 +165,7 @@ __global__ __launch_bounds__(ff::NT, 4) void ffn_fused_kernel(FfnArgs a) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int idx = tid + i * NT, row = idx >> 7, c4 = idx & 127;
-            *reinterpret_cast<float4*>(sA + row * LD + c4 * 4) = v[i];
+            put4(sB, row * PS + c4 * 8, v[i]);
         }
     }
     __syncthreads();
@@ -114,9 +186,9 @@ __global__ __launch_bounds__(ff::NT, 4) void ffn_fused_kernel(FfnArgs a) {
 
     // first chunk of W3 and the residual rows in flight behind the normalisation
     const unsigned vb3 = (unsigned)wave * TILE_BYTES + lane * 16u;
-    float4 s0[4], s1[4];
+    u32x4 s0[6], s1[6];
 #define FF_LOAD1(b_, ch_) \
-    _Pragma("unroll") for (int g = 0; g < 4; ++g) b_[g] = gbuf_load4(rW3, vb3, (unsigned)((ch_) * 4 + g) * 1024u);
+    _Pragma("unroll") for (int g = 0; g < 6; ++g) b_[g] = __builtin_amdgcn_raw_buffer_load_b128(rW3, vb3, (unsigned)((ch_) * 6 + g) * 1024u, 0);
     FF_LOAD1(s0, 0)
     const int ocol = wave * 32 + c;
     const unsigned vres = (unsigned)((m0 + 4 * hh) * 256 + ocol) * 4u;
@@ -125,7 +197,7 @@ __global__ __launch_bounds__(ff::NT, 4) void ffn_fused_kernel(FfnArgs a) {
     for (int r = 0; r < 16; ++r)
         resid[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rX, vres, (unsigned)((r & 3) + 8 * (r >> 2)) * 1024u, 0));
 
-    __syncthreads();   // every wave is done reading the input rows
+    __syncthreads();   // every wave is done reading the input planes: the hidden rows go over them, in fp32
     {
         const int col0 = wave * 64 + c;
         const float bv0 = a.b0[col0], bv1 = a.b0[col0 + 32];
@@ -139,55 +211,58 @@ __global__ __launch_bounds__(ff::NT, 4) void ffn_fused_kernel(FfnArgs a) {
         }
     }
     __syncthreads();
-    if constexpr (ACT == 0) {
-        // LayerNorm(512) + GELU in place: 16 threads per row, thread `part` holds columns part * 4 + 64 i + {0..3}
+    {
+        // 16 threads per row, thread `part` holds columns part * 4 + 64 i + {0..3}: LayerNorm(512) + GELU (ACT 0), then the cut into planes
         const int row = tid >> 4, part = tid & 15;
-        float* rp = sA + row * LD + part * 4;
+        const float* rp = sA + row * LD + part * 4;
         float4 v[8];
-        float sum = 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            v[i] = *reinterpret_cast<const float4*>(rp + 64 * i);
-            sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const float4*>(rp + 64 * i);
+        if constexpr (ACT == 0) {
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+            const float mean = sum * (1.f / 512.f);
+            float ss = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+                ss += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+            }
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+            const float rstd = rsqrtf(ss * (1.f / 512.f) + 1e-5f);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float4 gg = *reinterpret_cast<const float4*>(a.ln_g + part * 4 + 64 * i);
+                const float4 bb = *reinterpret_cast<const float4*>(a.ln_b + part * 4 + 64 * i);
+                float4 y;
+                y.x = v[i].x * rstd * gg.x + bb.x; y.y = v[i].y * rstd * gg.y + bb.y;
+                y.z = v[i].z * rstd * gg.z + bb.z; y.w = v[i].w * rstd * gg.w + bb.w;
+                y.x = 0.5f * y.x * (1.f + erff(y.x * 0.70710678118654752440f));
+                y.y = 0.5f * y.y * (1.f + erff(y.y * 0.70710678118654752440f));
+                y.z = 0.5f * y.z * (1.f + erff(y.z * 0.70710678118654752440f));
+                y.w = 0.5f * y.w * (1.f + erff(y.w * 0.70710678118654752440f));
+                v[i] = y;
+            }
         }
+        __syncthreads();   // every fp32 row is in registers: the planes go over them
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-        const float mean = sum * (1.f / 512.f);
-        float ss = 0.f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
-            ss += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
-        }
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
-        const float rstd = rsqrtf(ss * (1.f / 512.f) + 1e-5f);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float4 gg = *reinterpret_cast<const float4*>(a.ln_g + part * 4 + 64 * i);
-            const float4 bb = *reinterpret_cast<const float4*>(a.ln_b + part * 4 + 64 * i);
-            float4 y;
-            y.x = v[i].x * rstd * gg.x + bb.x; y.y = v[i].y * rstd * gg.y + bb.y;
-            y.z = v[i].z * rstd * gg.z + bb.z; y.w = v[i].w * rstd * gg.w + bb.w;
-            y.x = 0.5f * y.x * (1.f + erff(y.x * 0.70710678118654752440f));
-            y.y = 0.5f * y.y * (1.f + erff(y.y * 0.70710678118654752440f));
-            y.z = 0.5f * y.z * (1.f + erff(y.z * 0.70710678118654752440f));
-            y.w = 0.5f * y.w * (1.f + erff(y.w * 0.70710678118654752440f));
-            *reinterpret_cast<float4*>(rp + 64 * i) = y;
-        }
-        __syncthreads();
+        for (int i = 0; i < 8; ++i) put4(sB, row * PS + (part * 4 + 64 * i) * 2, v[i]);
     }
+    __syncthreads();
 
     // ---- x += h . W3^T + b3 : wave owns output columns [32 wave, 32 wave + 32)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc0[r] = 0.f;
-#define FF_MMA1(b_, ch_)                                                                                        \
-    _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                             \
-        const float4 fa = *reinterpret_cast<const float4*>(sA + c * LD + ((ch_) * 4 + g) * 8 + hh * 4);         \
-        acc0 = mfma32(fa.x, b_[g].x, acc0);                                                                     \
-        acc0 = mfma32(fa.y, b_[g].y, acc0);                                                                     \
-        acc0 = mfma32(fa.z, b_[g].z, acc0);                                                                     \
-        acc0 = mfma32(fa.w, b_[g].w, acc0);                                                                     \
+#define FF_MMA1(b_, ch_)                                                                                         \
+    _Pragma("unroll") for (int kc = 0; kc < 2; ++kc) {                                                           \
+        const unsigned char* ap = sB + c * PS + ((ch_) * 32 + kc * 16 + hh * 8) * 2;                             \
+        const u32x4 ah = *reinterpret_cast<const u32x4*>(ap), am = *reinterpret_cast<const u32x4*>(ap + PLANE),  \
+                    al = *reinterpret_cast<const u32x4*>(ap + 2 * PLANE);                                        \
+        FF_SIX(acc0, ah, am, al, b_, kc)                                                                         \
     }
 #pragma unroll 1
     for (int ch = 0; ch < 16; ch += 2) {
@@ -198,6 +273,7 @@ __global__ __launch_bounds__(ff::NT, 4) void ffn_fused_kernel(FfnArgs a) {
     }
 #undef FF_LOAD1
 #undef FF_MMA1
+#undef FF_SIX
     const float bv = a.b3[ocol];
 #pragma unroll
     for (int r = 0; r < 16; ++r)

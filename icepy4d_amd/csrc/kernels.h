@@ -52,7 +52,7 @@ struct FfnArgs {
     int act = 0;                                       // 0: gelu(layernorm(.)) (LightGlue), 1: relu(.) (SuperGlue, BatchNorm folded)
     float* x = nullptr; long x_bstride = 0;            // [z][row][256], updated in place
     const float* att = nullptr; long att_bstride = 0;  // [z][row][256]
-    const float* w0p = nullptr; const float* b0 = nullptr;      // W0 [512][512] packed by pack_frag_weights, bias [512]
+    const float* w0p = nullptr; const float* b0 = nullptr;      // W0 [512][512] as bf16 planes packed by pack_frag_weights (6 bytes per weight), bias [512]
     const float* ln_g = nullptr; const float* ln_b = nullptr;   // LayerNorm(512) weight / bias
     const float* w3p = nullptr; const float* b3 = nullptr;      // W3 [256][512] packed, bias [256]
     int m_max = 0; int batch = 1;
@@ -61,7 +61,7 @@ struct FfnArgs {
     int pstride = 2;
 };
 hipError_t launch_ffn_fused(const FfnArgs& a, hipStream_t s);
-std::vector<float> pack_frag_weights(const float* w, int n, int k);   // host: row-major W[n][k] -> MFMA-fragment order
+std::vector<float> pack_frag_weights(const float* w, int n, int k);   // host: row-major W[n][k] -> three bf16 planes in MFMA-fragment order (n k 3 / 2 floats of bytes)
 
 // ------------------------------------------------------------------ attention.hip
 struct AttnArgs {

@@ -491,9 +491,9 @@ static int lg_block(im_ctx* ctx, hipStream_t s, int NI, int layer, bool cross, f
     if (!unfused) {   // ffn.0 on cat([x, att]) (out_proj folded into the weights), LayerNorm, GELU, ffn.3, residual: one kernel
         FfnArgs f;
         f.x = x; f.x_bstride = xb; f.att = ws->att; f.att_bstride = xb;
-        f.w0p = (cross ? W.cf0_wp : W.sf0_wp) + (long)layer * 512 * 512; f.b0 = (cross ? W.cf0_b : W.sf0_b) + (long)layer * 512;
+        f.w0p = (cross ? W.cf0_wp : W.sf0_wp) + (long)layer * 512 * 512 * 3 / 2; f.b0 = (cross ? W.cf0_b : W.sf0_b) + (long)layer * 512;
         f.ln_g = (cross ? W.cln_g : W.sln_g) + (long)layer * 512; f.ln_b = (cross ? W.cln_b : W.sln_b) + (long)layer * 512;
-        f.w3p = (cross ? W.cf3_wp : W.sf3_wp) + (long)layer * 256 * 512; f.b3 = (cross ? W.cf3_b : W.sf3_b) + (long)layer * 256;
+        f.w3p = (cross ? W.cf3_wp : W.sf3_wp) + (long)layer * 256 * 512 * 3 / 2; f.b3 = (cross ? W.cf3_b : W.sf3_b) + (long)layer * 256;
         f.m_max = K; f.batch = NI; f.m_ptr = n_ptr; f.active = active; f.pstride = ST_INTS;
         IM_LAUNCH(ctx, "lg_ffn_fused", s, launch_ffn_fused(f, s));
         return 0;

@@ -650,8 +650,8 @@ int im_superglue_forward(im_ctx* ctx, const float* d_kpts, const float* d_scores
         if (!unfused) {   // x += mlp.3(relu(bn(mlp.0([x | att])))) with merge and BatchNorm folded into mlp.0: one kernel (ffn_fused.hip)
             FfnArgs f;
             f.act = 1; f.x = x; f.x_bstride = xb; f.att = ws->att; f.att_bstride = xb;
-            f.w0p = W.mlp0_wp + (long)l * 512 * 512; f.b0 = W.mlp0_b + (long)l * 512;
-            f.w3p = W.mlp3_wp + (long)l * 256 * 512; f.b3 = W.mlp3_b + (long)l * 256;
+            f.w0p = W.mlp0_wp + (long)l * 512 * 512 * 3 / 2; f.b0 = W.mlp0_b + (long)l * 512;
+            f.w3p = W.mlp3_wp + (long)l * 256 * 512 * 3 / 2; f.b3 = W.mlp3_b + (long)l * 256;
             f.m_max = base.m_max; f.batch = base.batch; f.m_ptr = base.m_ptr; f.active = base.active; f.pstride = base.pstride;
             IM_LAUNCH(ctx, "sg_mlp_fused", s, launch_ffn_fused(f, s));
             continue;
