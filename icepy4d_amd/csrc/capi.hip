@@ -39,7 +39,7 @@ int im_gemm_nt(im_ctx* ctx, const float* d_a, const float* d_w, const float* d_b
     IM_CHECK_CTX(ctx);
     GemmArgs g;
     g.A = d_a; g.lda = k; g.W = d_w; g.ldw = k; g.bias = d_bias; g.N = n; g.K = k; g.m_max = m;
-    g.C = d_c; g.ldc = n; g.alpha = alpha; g.epi = EPI_BIAS; g.big_tile = big_tile;
+    g.C = d_c; g.ldc = n; g.alpha = alpha; g.epi = EPI_BIAS; g.big_tile = big_tile & 1; g.bx = (big_tile >> 1) & 1;
     IM_HIP(ctx, launch_gemm(g, (hipStream_t)stream));
     return 0;
 }

@@ -18,16 +18,42 @@
 
 namespace im {
 
-template <int BM, int BN, int BK, int EPI>
+typedef unsigned int gu32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int gu32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 gbf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 gbf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x16 gmfma_bf(gu32x4 a, gu32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gbf16x8, a), __builtin_bit_cast(gbf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ unsigned gcvt_pk(float a, float b) {
+    const gbf16x2 v = __builtin_convertvector(f32x2{a, b}, gbf16x2);
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ void gsplit2(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
+    h = gcvt_pk(a, b);
+    float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
+    m = gcvt_pk(ra, rb);
+    ra -= __uint_as_float(m << 16);
+    rb -= __uint_as_float(m & 0xffff0000u);
+    l = gcvt_pk(ra, rb);
+}
+
+// BX (round 5, GemmArgs::bx): the product on the bf16 matrix cores with fp32 accuracy, as attention_bx.hip - the fp32 tiles are cut into three
+// bf16 planes as they are written to LDS (row stride 80 bytes: conflict-free 16-byte fragment reads), six v_mfma_f32_32x32x16_bf16 per 16 k
+// and tile pair, small products first; everything around the slab loop (block map, staging loads, epilogues) is shared with the f32 form.
+template <int BM, int BN, int BK, int EPI, bool BX>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
     constexpr int LDS_LD = BK + 4;
     constexpr int WM = BM / 2, WN = BN / 2;
     constexpr int MB = WM / 32, NB = WN / 32;
     constexpr int F4 = BK / 4;                                 // float4 per row of a slab
     constexpr int A_IT = BM * F4 / 256, B_IT = BN * F4 / 256;  // float4 loads per thread per slab
-    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDS_LD];
+    constexpr int XS = BK * 2 + 16, XPA = BM * XS, XPB = BN * XS;   // BX: plane row stride, plane sizes (bytes)
+    __shared__ __attribute__((aligned(16))) float smem[BX ? 3 * (XPA + XPB) / 4 : (BM + BN) * LDS_LD];
     float* sA = smem;
     float* sB = smem + BM * LDS_LD;
+    unsigned char* const xA = reinterpret_cast<unsigned char*>(smem);
+    unsigned char* const xB = xA + 3 * XPA;
 
     // XCD-aware block -> tile map: the row-tile index is the fastest-varying part of the linear block id, so (with
     // a multiple of 8 row tiles) all column tiles of one row tile run on the same XCD and the A rows are fetched
@@ -92,7 +118,21 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
         if constexpr (B_IT > 1) rb1 = IM_LD_B(1, k0_);                                     \
         if constexpr (B_IT > 2) { rb2 = IM_LD_B(2, k0_); rb3 = IM_LD_B(3, k0_); }          \
     }
-#define IM_ST(buf, i, r) *reinterpret_cast<float4*>(buf + ((tid + (i) * 256) / F4) * LDS_LD + ((tid + (i) * 256) % F4) * 4) = r
+#define IM_ST_F32(buf, i, r) *reinterpret_cast<float4*>(buf + ((tid + (i) * 256) / F4) * LDS_LD + ((tid + (i) * 256) % F4) * 4) = r
+    auto st_bx = [&](unsigned char* plane0, int plane_bytes, int i, float4 x) {
+        unsigned h0, m0, l0, h1, m1, l1;
+        gsplit2(x.x, x.y, h0, m0, l0);
+        gsplit2(x.z, x.w, h1, m1, l1);
+        unsigned char* d = plane0 + ((tid + i * 256) / F4) * XS + ((tid + i * 256) % F4) * 8;
+        *reinterpret_cast<gu32x2*>(d) = gu32x2{h0, h1};
+        *reinterpret_cast<gu32x2*>(d + plane_bytes) = gu32x2{m0, m1};
+        *reinterpret_cast<gu32x2*>(d + 2 * plane_bytes) = gu32x2{l0, l1};
+    };
+#define IM_ST(buf, i, r)                                                              \
+    {                                                                                 \
+        if constexpr (BX) st_bx(buf == sA ? xA : xB, buf == sA ? XPA : XPB, i, r);    \
+        else IM_ST_F32(buf, i, r);                                                    \
+    }
 
     IM_LOAD_SLAB(0)
     for (int k0 = 0; k0 < a.K; k0 += BK) {
@@ -104,6 +144,33 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
         if constexpr (B_IT > 2) { IM_ST(sB, 2, rb2); IM_ST(sB, 3, rb3); }
         __syncthreads();
         if (k0 + BK < a.K) IM_LOAD_SLAB(k0 + BK)
+        if constexpr (BX) {
+#pragma unroll
+            for (int kc = 0; kc < BK / 16; ++kc) {
+                gu32x4 fa[MB][3], fb[NB][3];
+#pragma unroll
+                for (int i = 0; i < MB; ++i)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        fa[i][pl] = *reinterpret_cast<const gu32x4*>(xA + pl * XPA + (wm0 + i * 32 + c) * XS + kc * 32 + hh * 16);
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        fb[j][pl] = *reinterpret_cast<const gu32x4*>(xB + pl * XPB + (wn0 + j * 32 + c) * XS + kc * 32 + hh * 16);
+#pragma unroll
+                for (int i = 0; i < MB; ++i)
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) {
+                        acc[i][j] = gmfma_bf(fa[i][0], fb[j][2], acc[i][j]);
+                        acc[i][j] = gmfma_bf(fa[i][2], fb[j][0], acc[i][j]);
+                        acc[i][j] = gmfma_bf(fa[i][1], fb[j][1], acc[i][j]);
+                        acc[i][j] = gmfma_bf(fa[i][0], fb[j][1], acc[i][j]);
+                        acc[i][j] = gmfma_bf(fa[i][1], fb[j][0], acc[i][j]);
+                        acc[i][j] = gmfma_bf(fa[i][0], fb[j][0], acc[i][j]);
+                    }
+            }
+        } else
 #pragma unroll
         for (int t = 0; t < BK / 8; ++t) {
             float4 fa[MB], fb[NB];
@@ -129,6 +196,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
 #undef IM_LD_A
 #undef IM_LD_B
 #undef IM_ST
+#undef IM_ST_F32
 
     // ---- epilogue: lane holds column n = .. + c, rows row0 + 4 hh + (r & 3) + 8 (r >> 2). Buffer stores: the descriptor
     // covers the live rows only, so rows past them are dropped by the range check; a dead column gets an out-of-range
@@ -209,8 +277,13 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
     if (grid.x == 0) return hipSuccess;
 #define IM_GEMM_CASE(E)                                                                  \
     case E:                                                                              \
-        if (a.big_tile) hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 32, E>), grid, block, 0, s, a);   \
-        else hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 32, E>), grid, block, 0, s, a);               \
+        if (a.bx) {                                                                      \
+            if (a.big_tile) hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 32, E, true>), grid, block, 0, s, a);   \
+            else hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 32, E, true>), grid, block, 0, s, a);               \
+        } else {                                                                         \
+            if (a.big_tile) hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 32, E, false>), grid, block, 0, s, a);  \
+            else hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 32, E, false>), grid, block, 0, s, a);              \
+        }                                                                                \
         break;
     switch (a.epi) {
         IM_GEMM_CASE(EPI_BIAS)

@@ -43,6 +43,8 @@ struct GemmArgs {
     const float* cs = nullptr; const float* sn = nullptr; long enc_bstride = 0;    // rotary tables [rows][32]
     int epi = EPI_BIAS;
     int big_tile = 0;              // 128x128 block tile (score GEMM) instead of 64x64
+    int bx = 0;                    // the product on the bf16 matrix cores, six bf16 products per fp32 product (gemm.hip BX; the matchers' GEMMs;
+                                   // SuperPoint's stay on the f32-input MFMA: its outputs are bit-identical to round 4's)
 };
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
 

@@ -462,7 +462,7 @@ static int lg_block(im_ctx* ctx, hipStream_t s, int NI, int layer, bool cross, f
     const int* n_ptr = ws->st->n;
     const int* active = &ws->st->active;
     GemmArgs base;
-    base.m_max = K; base.m_ptr = n_ptr; base.active = active; base.pstride = ST_INTS; base.batch = NI;
+    base.m_max = K; base.m_ptr = n_ptr; base.active = active; base.pstride = ST_INTS; base.batch = NI; base.bx = 1;
     AttnArgs at;
     at.q = ws->q; at.k = cross ? ws->q : ws->k; at.v = ws->v; at.hstride = (long)K * 64; at.bstride = (long)K * 256;
     at.out = ws->att; at.out_bstride = xb; at.ldo = 256; at.n_ptr = n_ptr; at.pstride = ST_INTS; at.n_max = K; at.batch = NI; at.heads = 4;
@@ -568,7 +568,7 @@ static int lightglue_forward(im_ctx* ctx, int n_pairs, const float* d_kpts, cons
     IM_HIP(ctx, launch_lg_select_layer(st, NP, L, ws->sel, d_info, s));
     {
         GemmArgs g;
-        g.m_max = K; g.m_ptr = st->n; g.pstride = ST_INTS; g.batch = NI;
+        g.m_max = K; g.m_ptr = st->n; g.pstride = ST_INTS; g.batch = NI; g.bx = 1;
         g.A = ws->x[cur]; g.a_bstride = xb; g.lda = 256; g.W = W.fp_w; g.ldw = 256; g.bias = W.fp_b;
         g.sel = ws->sel; g.w_sel_stride = 65536; g.bias_sel_stride = 256; g.N = 256; g.K = 256;
         g.C = ws->md; g.c_bstride = xb; g.ldc = 256; g.alpha = 0.25f;  // / 256**0.25 (`lightglue.py:279`)
@@ -579,7 +579,7 @@ static int lightglue_forward(im_ctx* ctx, int n_pairs, const float* d_kpts, cons
     IM_HIP(ctx, launch_logsig(ws->z, K, st, NI, K, ws->lz, s));
     {   // one score matrix per pair: md of image 2p against md of image 2p + 1
         GemmArgs g;
-        g.m_max = K; g.m_ptr = &st->n[0]; g.n_ptr = &st->n[1]; g.pstride = ST_INTS; g.pair_batched = 1; g.batch = NP;
+        g.m_max = K; g.m_ptr = &st->n[0]; g.n_ptr = &st->n[1]; g.pstride = ST_INTS; g.pair_batched = 1; g.batch = NP; g.bx = 1;
         g.A = ws->md; g.a_bstride = 2 * xb; g.lda = 256; g.W = ws->md + xb; g.w_bstride = 2 * xb; g.ldw = 256; g.N = K; g.K = 256;
         g.C = ws->sim; g.c_bstride = (long)ws->sim_ps; g.ldc = K; g.epi = EPI_BIAS; g.big_tile = 1;
         IM_LAUNCH(ctx, "score_gemm", s, launch_gemm(g, s));

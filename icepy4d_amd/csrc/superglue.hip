@@ -607,7 +607,7 @@ int im_superglue_forward(im_ctx* ctx, const float* d_kpts, const float* d_scores
     IM_HIP(ctx, launch_lg_init(st, 2, d_n, ws->ind[0], ws->prune, K, K, d_matches, d_mscores, K, s));
     float* x = ws->x[0];
     GemmArgs base;
-    base.m_max = K; base.m_ptr = st->n; base.batch = 2;   // one pair: pstride is irrelevant for z < 2
+    base.m_max = K; base.m_ptr = st->n; base.batch = 2; base.bx = 1;   // one pair: pstride is irrelevant for z < 2
     {   // keypoint encoder; the last layer adds the visual descriptors: x = desc + kenc(kpts, scores) (`superglue.py:269-270`)
         float* inp = ws->h;  // [2][K][32]
         const float4 shapes = make_float4(h_shape[0], h_shape[1], h_shape[2], h_shape[3]);
@@ -677,7 +677,7 @@ int im_superglue_forward(im_ctx* ctx, const float* d_kpts, const float* d_scores
         g.C = ws->md; g.c_bstride = xb; g.ldc = 256; g.epi = EPI_BIAS;
         IM_LAUNCH(ctx, "sg_proj_gemm", s, launch_gemm(g, s));
         GemmArgs sgm;
-        sgm.m_max = K; sgm.m_ptr = &st->n[0]; sgm.n_ptr = &st->n[1]; sgm.batch = 1; sgm.pair_batched = 1;
+        sgm.m_max = K; sgm.m_ptr = &st->n[0]; sgm.n_ptr = &st->n[1]; sgm.batch = 1; sgm.pair_batched = 1; sgm.bx = 1;
         sgm.A = ws->md; sgm.lda = 256; sgm.W = ws->md + xb; sgm.ldw = 256; sgm.N = K; sgm.K = 256;
         sgm.C = ws->sim; sgm.ldc = K; sgm.alpha = 0.0625f;  // / 256 ** .5 (`superglue.py:280`)
         sgm.epi = EPI_BIAS; sgm.big_tile = 1;

@@ -141,7 +141,8 @@ int im_debug_guard_selftest(im_ctx* ctx, void* stream);
 int im_debug_guards_check(im_ctx* ctx, void* stream);
 
 /* ---- stage entry points (what the stage-isolated parity tests call; also usable on their own) ----------- */
-/* C[m][n] = alpha * (sum_k A[m][k] W[n][k] + bias[n]); fp32 MFMA GEMM. bias may be NULL. big_tile: 128x128 tiles. */
+/* C[m][n] = alpha * (sum_k A[m][k] W[n][k] + bias[n]); fp32 GEMM. bias may be NULL. big_tile bit 0: 128x128 tiles; bit 1: the product on
+ * the bf16 matrix cores with fp32 accuracy (operands cut into three bf16 values, six products per fp32 product) instead of the f32-input MFMA. */
 int im_gemm_nt(im_ctx* ctx, const float* d_a, const float* d_w, const float* d_bias, float* d_c,
                int m, int n, int k, float alpha, int big_tile, void* stream);
 /* The feed-forward tail of a transformer block / GNN layer in one kernel:

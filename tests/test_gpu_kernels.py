@@ -22,8 +22,10 @@ def dev(a):
     return torch.as_tensor(a).cuda().contiguous()
 
 
-@pytest.mark.parametrize("m,n,k,big", [(64, 64, 32, 0), (100, 65, 256, 0), (4096, 256, 512, 0), (300, 257, 256, 1), (1024, 768, 256, 1)])
+@pytest.mark.parametrize("m,n,k,big", [(64, 64, 32, 0), (100, 65, 256, 0), (4096, 256, 512, 0), (300, 257, 256, 1), (1024, 768, 256, 1),
+                                       (64, 64, 32, 2), (100, 65, 256, 2), (4096, 256, 512, 2), (300, 257, 256, 3), (1024, 768, 256, 3)])
 def test_gemm_nt(ctx, m, n, k, big):
+    """big: bit 0 = 128 x 128 tiles, bit 1 = the product on the bf16 matrix cores (six bf16 products per fp32 product; same tolerance)."""
     from icepy4d_amd._lib import ptr, stream_ptr
     g = torch.Generator().manual_seed(m + n)
     a = torch.randn(m, k, generator=g)
@@ -80,9 +82,11 @@ def test_gemm_asymmetric_layout(ctx):
     w = torch.arange(n * n, dtype=torch.float32).reshape(n, n)
     dc = torch.zeros(n, n, device="cuda")
     da, dw = dev(a), dev(w)  # keep alive: a temporary would be freed and its address reused
-    ctx.call("im_gemm_nt", ptr(da), ptr(dw), None, ptr(dc), n, n, n, 1.0, 0, stream_ptr())
-    torch.cuda.synchronize()
-    assert torch.equal(dc.cpu(), w.t())
+    for mode in (0, 2):      # f32-input MFMA; bf16 planes (integers up to 4095 are exact in three bf16 values)
+        dc.zero_()
+        ctx.call("im_gemm_nt", ptr(da), ptr(dw), None, ptr(dc), n, n, n, 1.0, mode, stream_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(dc.cpu(), w.t()), mode
 
 
 @pytest.mark.parametrize("relu", [1, 0])
