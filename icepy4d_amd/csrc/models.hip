@@ -472,7 +472,7 @@ static int lg_block(im_ctx* ctx, hipStream_t s, int NI, int layer, bool cross, f
         g.A = x; g.a_bstride = xb; g.lda = 256; g.W = W.qkv_w + (long)layer * 768 * 256; g.ldw = 256;
         g.bias = W.qkv_b + (long)layer * 768; g.N = 768; g.K = 256; g.epi = EPI_QKV_ROPE;
         g.q = ws->q; g.k = ws->k; g.v = ws->v; g.head_bstride = (long)K * 256; g.head_stride = (long)K * 64;
-        g.cs = cs; g.sn = sn; g.enc_bstride = (long)K * 32;
+        g.cs = cs; g.sn = sn; g.enc_bstride = (long)K * 32; g.big_tile = NI >= 4;
         IM_LAUNCH(ctx, "lg_qkv_rope_gemm", s, launch_gemm(g, s));
         at.scale = 0.125f;  // SDPA default 1/sqrt(64) (`lightglue.py:120-123`)
     } else {
@@ -481,6 +481,7 @@ static int lg_block(im_ctx* ctx, hipStream_t s, int NI, int layer, bool cross, f
         g.bias = W.cqv_b + (long)layer * 512; g.N = 512; g.K = 256; g.epi = EPI_HEADS_QV;
         g.q = ws->q; g.v = ws->v; g.head_bstride = (long)K * 256; g.head_stride = (long)K * 64;
         g.alpha = (float)0.35355339059327373;  // scale**0.5 = 64**-0.25 on to_qk (`lightglue.py:201`); to_v unscaled
+        g.big_tile = NI >= 4;
         IM_LAUNCH(ctx, "lg_proj_gemm", s, launch_gemm(g, s));
         at.scale = 1.f;
     }
