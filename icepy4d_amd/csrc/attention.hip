@@ -452,7 +452,7 @@ static hipError_t launch_g(const AttnArgs& a, hipStream_t s) {
 hipError_t launch_flash_attn(const AttnArgs& a, hipStream_t s) {
     if (a.n_max <= 0) return hipSuccess;
     static const bool f32_form = [] { const char* e = getenv("IM_ATTN_F32"); return e && atoi(e) != 0; }();
-    if (!f32_form) return launch_flash_attn_bx(a, s);
+    if (!f32_form && !a.f32_form) return launch_flash_attn_bx(a, s);
     static const int force = [] { const char* e = getenv("IM_ATTN_GROUPS"); return e ? atoi(e) : 0; }();
     const int g = force ? force : 2;
     return g == 2 ? launch_g<2>(a, s) : launch_g<1>(a, s);

@@ -559,7 +559,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bx_kernel(AttnArgs a) {
 // K / V of the launch as bf16 triples (a.planes); a launch of its own so that event profiles and rocprofv3 name the two kernels apart
 hipError_t launch_attn_planes(const AttnArgs& a, hipStream_t s) {
     static const bool f32_form = [] { const char* e = getenv("IM_ATTN_F32"); return e && atoi(e) != 0; }();
-    if (!a.planes || a.n_max <= 0 || f32_form) return hipSuccess;
+    if (!a.planes || a.n_max <= 0 || f32_form || a.f32_form) return hipSuccess;
     const long rows = (long)a.batch * a.heads * a.n_max;
     hipLaunchKernelGGL(kv_planes_kernel, dim3((unsigned)((rows + 31) / 32), 2), dim3(256), 0, s, a);
     return hipGetLastError();

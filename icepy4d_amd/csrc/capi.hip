@@ -132,7 +132,7 @@ int im_flash_attn(im_ctx* ctx, const float* d_q, const float* d_k, const float* 
     AttnArgs a;
     a.q = d_q; a.k = d_k; a.v = d_v; a.hstride = (long)n_max * 64; a.bstride = a.hstride * heads;
     a.out = d_out; a.ldo = heads * 64; a.out_bstride = (long)n_max * a.ldo;
-    a.n_ptr = d_n; a.n_max = n_max; a.batch = batch; a.heads = heads; a.cross = cross; a.scale = scale;
+    a.n_ptr = d_n; a.n_max = n_max; a.batch = batch; a.heads = heads; a.cross = cross & 1; a.f32_form = (cross >> 1) & 1; a.scale = scale;
     // split-KV scratch of the stage entry point (the model paths use the reserved workspace): grown on demand
     const size_t nf = attn_part_floats(n_max, batch, heads), ni = attn_counter_ints(n_max, batch, heads);
     if (nf > ctx->stage_attn_floats || ni > ctx->stage_attn_ints) {

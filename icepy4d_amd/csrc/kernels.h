@@ -83,6 +83,7 @@ struct AttnArgs {
     // attention_bx.hip (optional): K and V of the launch as bf16 triples, written by its own first kernel: [K | V][batch][heads][n_max][3][64] bf16.
     // Without it the attention kernel cuts the fp32 tiles itself, once per 128-query block
     void* planes = nullptr;
+    int f32_form = 0;            // 1: attention.hip's kernel on the f32-input MFMA (rounds 1-5) for this launch; IM_ATTN_F32=1 sets it for all
 };
 static constexpr int ATTN_MAX_SPLIT = 4;
 inline size_t attn_part_floats(int n_max, int batch, int heads) { return (size_t)ATTN_MAX_SPLIT * batch * heads * n_max * 66; }

@@ -170,6 +170,39 @@ def test_flash_attn(ctx, n0, n1, cross):
         assert torch.isnan(out[z, ns[z]:]).all()  # rows beyond the live count are untouched
 
 
+@pytest.mark.parametrize("n", [1024, 4096])
+def test_flash_attn_bf16_form_is_as_accurate_as_the_f32_mfma_form(ctx, n):
+    """The product path (csrc/attention_bx.hip: fp32 operands as three bf16 values, six bf16 products per fp32 product on the bf16
+    matrix cores) against the f32-input MFMA kernel of rounds 1-5 (csrc/attention.hip, `cross` bit 1 of the stage entry) on the same
+    inputs, both against a float64 softmax: the two errors must be of one size - the bf16 form's maximum and mean within 1.25 x the f32
+    form's. Measured at 4096 keys: maximum 2.9e-7 against 4.5e-7, mean 1.87e-8 against 1.68e-8 (the matrix core adds 16 products before
+    it rounds once, which lowers the spread and leaves a slightly larger bias: profiles/r05_bf16x_probe.txt); at 1024 both are lower."""
+    from icepy4d_amd._lib import ptr, stream_ptr
+    heads = 4
+    g = torch.Generator().manual_seed(n)
+    q = torch.randn(2, heads, n, 64, generator=g)
+    k = torch.randn(2, heads, n, 64, generator=g)
+    v = torch.randn(2, heads, n, 64, generator=g)
+    dn = torch.tensor([n, n], dtype=torch.int32, device="cuda")
+    dq, dk, dv = dev(q), dev(k), dev(v)
+    for cross in (0, 1):
+        refs = []
+        for z in range(2):
+            y = z ^ 1 if cross else z
+            att = torch.softmax(q[z].double().cuda() @ k[y].double().cuda().transpose(-1, -2) * 0.125, -1) @ v[y].double().cuda()
+            refs.append(att.transpose(0, 1).reshape(n, heads * 64).cpu())
+        errs = {}
+        for form in (0, 1):      # 0: bf16 planes (the product), 1: f32-input MFMA
+            dout = torch.empty(2, n, heads * 64, device="cuda")
+            ctx.call("im_flash_attn", ptr(dq), ptr(dk), ptr(dv), ptr(dout), ptr(dn), n, 2, heads, cross | (form << 1), 0.125, stream_ptr())
+            torch.cuda.synchronize()
+            e = torch.stack([(dout[z].cpu().double() - refs[z]).abs() for z in range(2)])
+            errs[form] = (e.max().item(), e.mean().item())
+        print(f"n={n} cross={cross}: bf16 form max {errs[0][0]:.3e} mean {errs[0][1]:.3e} | f32 form max {errs[1][0]:.3e} mean {errs[1][1]:.3e}")
+        assert errs[0][0] < 2e-5 and errs[1][0] < 2e-5
+        assert errs[0][0] <= 1.25 * errs[1][0] and errs[0][1] <= 1.25 * errs[1][1], errs
+
+
 @pytest.mark.parametrize("n0,n1", [(1, 63), (64, 65), (127, 129), (191, 193), (130, 1), (257, 256)])
 def test_flash_attn_key_group_edges(ctx, n0, n1):
     """Key counts around the 64-key tile / 128-key step boundaries of the two-key-group kernel, self and cross; the
