@@ -37,7 +37,9 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_lg_$c -- python3 $root/tools/run_pair_once.py lightglue 2 > /dev/null 2>&1
   [ "$mode" = full ] && rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_sg_$c -- python3 $root/tools/run_pair_once.py superglue 1 > /dev/null 2>&1
 done
-[ "$mode" = full ] && rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $out/pmc_attn_sq -- python3 $root/tools/run_attn_once.py > /dev/null 2>&1
+python3 $root/tools/bench_attn_batch.py 4096 > $out/attn_batch.txt 2>&1          # the attention stage entry, 1 .. 10 pairs per launch, both forms
+python3 $root/tools/bench_attn_batch.py 4096 zeros >> $out/attn_batch.txt 2>&1   # the same on all-zero operands: the clock without data toggling
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $out/pmc_attn_sq -- python3 $root/tools/run_attn_once.py > /dev/null 2>&1
 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $out/pmc_sq_all -- python3 $root/tools/run_pair_once.py lightglue 2 > /dev/null 2>&1
 cd $root
 python3 tests/parity_report.py --epochs 30 --superglue --out $out/parity_winograd.json > $out/parity_winograd.log 2>&1

@@ -97,7 +97,7 @@ for fn in newest(glob.glob(f"{src}/pmc_sq_all/**/*counter_collection.csv", recur
 for name in ("bench.json", "bench_streams1_under_rocprof.json", "bench_default_under_rocprof.json", "bench_config5.json", "bench_config3.json", "bench_steps20_warmup5.json",
              "bench_config5_under_rocprof.json", "parity_winograd.json", "parity_direct_conv.json", "bench_config4_1gpu_256epochs.json",
              "bench_config4_nccl_world1.json", "bench_2ranks_one_device_gloo.json", "bench_config4_8ranks_one_device_gloo.json",
-             "match_call_phases.txt", "sinkhorn.txt", "nms.txt", "assign.txt", "parity_adaptive_10epochs.json"):
+             "match_call_phases.txt", "sinkhorn.txt", "nms.txt", "assign.txt", "parity_adaptive_10epochs.json", "attn_batch.txt"):
     p = os.path.join(src, name)
     if os.path.exists(p) and os.path.getsize(p):
         open(os.path.join(dst, f"{tag}_{name}"), "w").write(open(p).read())
