@@ -42,8 +42,9 @@ PEAK_ATTN_F32_EQUIVALENT_TFLOPS = PEAK_BF16_MFMA_TFLOPS / ATTN_BF16_PRODUCTS
 ATTN_F32_FORM = os.environ.get("IM_ATTN_F32", "0") not in ("", "0")   # the f32-input MFMA kernel of rounds 1-5 (csrc/attention.hip), for A/B
 ATTN_KERNEL = "im::flash_attn_f32_kernel" if ATTN_F32_FORM else "im::flash_attn_bx_kernel"
 PEAK_ATTN_TFLOPS = PEAK_F32_MFMA_TFLOPS if ATTN_F32_FORM else PEAK_ATTN_F32_EQUIVALENT_TFLOPS
-DTYPE_NOTE = ("fp32 end to end, as the reference: convolutions, GEMMs and the feed-forward on the f32-input MFMA; the attention's fp32 products as six "
-              "bf16 products each on the bf16 matrix cores with fp32 accumulation (error at or below the f32 MFMA chain's)")
+DTYPE_NOTE = ("fp32 end to end, as the reference: SuperPoint (convolutions, its 1 x 1 heads) on the f32-input MFMA; the matchers' fp32 products (attention, "
+              "feed-forward, their GEMMs) as six bf16 products each on the bf16 matrix cores with fp32 accumulation - every fp32 operand is the exact sum of "
+              "three bf16 values; error at or below the f32 MFMA chain's (profiles/r05_bf16x_probe.txt, tests/test_gpu_kernels.py)")
 PEAK_HBM_GBS = 8000.0          # same guide: HBM3E spec peak (6.3 TB/s is what a copy kernel reaches)
 # Pairs per launch of the timed region (`--batch`): the batch dimension over pairs inside the kernels. Measured on one MI355X with two
 # launch groups in flight (round 3, three boxes): 2 -> 105.8, 4 -> 107.3, 5 -> 107.5, 8 -> 108.1, 10 -> 107.0-108 (the maximum on every box),

@@ -153,7 +153,7 @@ int im_flash_attn(im_ctx* ctx, const float* d_q, const float* d_k, const float* 
         ctx->dfree(ctx->stage_attn_planes);
         ctx->stage_attn_planes = p; ctx->stage_attn_plane_bytes = nb;
     }
-    a.part = ctx->stage_attn_part; a.counters = ctx->stage_attn_cnt; a.planes = ctx->stage_attn_planes;
+    a.part = ctx->stage_attn_part; a.counters = ctx->stage_attn_cnt; a.planes = (cross & 4) ? nullptr : ctx->stage_attn_planes;   // bit 2: K / V cut inside the attention kernel
     IM_HIP(ctx, launch_attn_planes(a, (hipStream_t)stream));
     IM_HIP(ctx, launch_flash_attn(a, (hipStream_t)stream));
     IM_GUARD_CHECK(ctx, (hipStream_t)stream, "im_flash_attn");

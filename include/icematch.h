@@ -160,7 +160,8 @@ int im_conv3x3(im_ctx* ctx, const float* d_in, const float* h_weight, const floa
 int im_conv3x3_winograd(im_ctx* ctx, const float* d_in, const float* h_weight, const float* h_bias, float* d_out,
                         int b, int h, int w, int cin, int cout, int relu, int pool, void* stream);
 /* fp32 flash attention: q, k, v [batch][heads][n_max][64]; out [batch][n_max][heads*64]; cross bit 0: kv of image z^1; bit 1: the kernel on the
- * f32-input MFMA (rounds 1-5) instead of the bf16-plane kernel, for A/B */
+ * f32-input MFMA (rounds 1-5) instead of the bf16-plane kernel, for A/B; bit 2: the bf16-plane kernel cuts K / V itself while it stages them
+ * (the form for callers without the plane workspace) instead of reading the planes of its first launch */
 int im_flash_attn(im_ctx* ctx, const float* d_q, const float* d_k, const float* d_v, float* d_out,
                   const int32_t* d_n, int n_max, int batch, int heads, int cross, float scale, void* stream);
 /* `simple_nms` (`lightglue/superpoint.py:50-65`): d_scores, d_out [n_images][h][w] */

@@ -192,12 +192,15 @@ def test_flash_attn_bf16_form_is_as_accurate_as_the_f32_mfma_form(ctx, n):
             att = torch.softmax(q[z].double().cuda() @ k[y].double().cuda().transpose(-1, -2) * 0.125, -1) @ v[y].double().cuda()
             refs.append(att.transpose(0, 1).reshape(n, heads * 64).cpu())
         errs = {}
-        for form in (0, 1):      # 0: bf16 planes (the product), 1: f32-input MFMA
+        outs = {}
+        for form in (0, 1, 2):   # 0: bf16 planes cut by the first launch (the product), 1: f32-input MFMA, 2: bf16 planes cut inside the kernel
             dout = torch.empty(2, n, heads * 64, device="cuda")
             ctx.call("im_flash_attn", ptr(dq), ptr(dk), ptr(dv), ptr(dout), ptr(dn), n, 2, heads, cross | (form << 1), 0.125, stream_ptr())
             torch.cuda.synchronize()
-            e = torch.stack([(dout[z].cpu().double() - refs[z]).abs() for z in range(2)])
+            outs[form] = dout.cpu()
+            e = torch.stack([(outs[form][z].double() - refs[z]).abs() for z in range(2)])
             errs[form] = (e.max().item(), e.mean().item())
+        assert errs[2][0] <= 1.25 * errs[1][0] and errs[2][1] <= 1.25 * errs[1][1], errs
         print(f"n={n} cross={cross}: bf16 form max {errs[0][0]:.3e} mean {errs[0][1]:.3e} | f32 form max {errs[1][0]:.3e} mean {errs[1][1]:.3e}")
         assert errs[0][0] < 2e-5 and errs[1][0] < 2e-5
         assert errs[0][0] <= 1.25 * errs[1][0] and errs[0][1] <= 1.25 * errs[1][1], errs
