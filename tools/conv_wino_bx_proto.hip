@@ -36,8 +36,14 @@ static constexpr int MS = 33;                     // floats per (position, tile)
 static constexpr int M_BYTES = 16 * 32 * NG * MS * 4;  // 67,584 at NG = 1: two blocks per CU
 static constexpr int LDS_BYTES = M_BYTES > PATCH_BYTES ? M_BYTES : PATCH_BYTES;
 
+// Timing-only ablations (wrong results by construction), -DABL_NO_MFMA / -DABL_NO_CUT / -DABL_NO_READ / -DABL_NO_EPI: what each part of a block costs
 __device__ __forceinline__ f32x16 mfma_bf(u32x4 a, u32x4 b, f32x16 c) {
+#ifdef ABL_NO_MFMA
+    c[0] += __uint_as_float(a.x ^ b.x);      // keeps the operands alive: one vector instruction instead of the MFMA
+    return c;
+#else
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+#endif
 }
 __device__ __forceinline__ unsigned cvt_pk(float a, float b) {
     const bf16x2 v = __builtin_convertvector(f32x2{a, b}, bf16x2);
@@ -128,8 +134,13 @@ __global__ __launch_bounds__(512, NG == 1 ? 4 : 2) void conv_wino_bx(const float
         float t[4][8];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+#ifdef ABL_NO_READ
+            const float fz = (float)(chunk + j + g);
+            const float4 a0 = make_float4(fz, sgn, fz, sgn), a1 = a0, b0 = make_float4(sgn, fz, fz, fz), b1 = b0;
+#else
             const float4 a0 = *reinterpret_cast<const float4*>(pa + 8 * g * PROW + j * PIX + 16 * chunk), a1 = *reinterpret_cast<const float4*>(pa + 8 * g * PROW + j * PIX + 16 * chunk + 4);
             const float4 b0 = *reinterpret_cast<const float4*>(pb + 8 * g * PROW + j * PIX + 16 * chunk), b1 = *reinterpret_cast<const float4*>(pb + 8 * g * PROW + j * PIX + 16 * chunk + 4);
+#endif
             t[j][0] = a0.x + sgn * b0.x; t[j][1] = a0.y + sgn * b0.y; t[j][2] = a0.z + sgn * b0.z; t[j][3] = a0.w + sgn * b0.w;
             t[j][4] = a1.x + sgn * b1.x; t[j][5] = a1.y + sgn * b1.y; t[j][6] = a1.z + sgn * b1.z; t[j][7] = a1.w + sgn * b1.w;
         }
@@ -141,7 +152,12 @@ __global__ __launch_bounds__(512, NG == 1 ? 4 : 2) void conv_wino_bx(const float
                 if (pp == 0) v[i] = q == 0 ? t[0][i] - t[2][i] : t[1][i] + t[2][i];
                 else v[i] = q == 0 ? t[2][i] - t[1][i] : t[1][i] - t[3][i];
             }
+#ifdef ABL_NO_CUT
+            const P3 a = P3{u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])},
+                            u32x4{__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])}, u32x4{1u, 2u, 3u, 4u}};
+#else
             const P3 a = split8(v);
+#endif
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct) {
                 const u32x4 bh = ub[chunk & 1][q][ct][0], bm = ub[chunk & 1][q][ct][1], bl = ub[chunk & 1][q][ct][2];
@@ -158,6 +174,21 @@ __global__ __launch_bounds__(512, NG == 1 ? 4 : 2) void conv_wino_bx(const float
     }
     // ---- Y = A^T M A per (tile, cout), A^T = [1 1 1 0; 0 1 -1 -1], one 32-channel half at a time through the exchange image M[position][tile][32]
     float* img_out = out + (long)b * H * W * C;
+#ifdef ABL_NO_EPI
+    {
+        float sum = 0.f;
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sum += acc[g][q][ct][r];
+        if (sum == 12345.678f) img_out[tid] = sum;
+        return;
+    }
+#endif
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
         __syncthreads();       // the patch (ct = 0) / the first half (ct = 1) is dead
