@@ -144,6 +144,53 @@ static void rate(int blocks_per_cu, float* out) {
            NACC, NV, KIND ? "split steps (cvt_pk, sub, fma)" : "v_fma_f32", blocks_per_cu, bf, bf / 6, bf / 6 / 157.3);
 }
 
+// the two bf16 MFMA shapes on RANDOM operands (the clock the chip holds depends on the data: guide, DVFS give-back): same FLOPs per wave and iteration
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+template <int SHAPE>   // 0: 32x32x16 (four accumulators of 16), 1: 16x16x32 (eight accumulators of 4: the same 32 x 32 x 64 of work per eight / sixteen MFMAs)
+__global__ __launch_bounds__(256) void shape_kernel(float* out, int iters, unsigned seed) {
+    unsigned h = (threadIdx.x + 1) * 2654435761u ^ (blockIdx.x * 40503u) ^ seed;
+    bf16x8 a[4], b[4];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 8; ++j) {
+            h = h * 1664525u + 1013904223u; a[i][j] = (__bf16)(((int)(h >> 8) & 0xffff) * (1.f / 32768.f) - 1.f);
+            h = h * 1664525u + 1013904223u; b[i][j] = (__bf16)(((int)(h >> 8) & 0xffff) * (1.f / 32768.f) - 1.f);
+        }
+    float s = 0;
+    if (SHAPE == 0) {
+        f32x16 acc[4];
+        for (int i = 0; i < 4; ++i) acc[i] = f32x16{};
+        for (int it = 0; it < iters; ++it)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u & 3], b[(u >> 1) & 3], acc[u & 3], 0, 0, 0);
+        for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) s += acc[i][r];
+    } else {
+        f32x4v acc[8];
+        for (int i = 0; i < 8; ++i) acc[i] = f32x4v{};
+        for (int it = 0; it < iters; ++it)
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc[u & 7] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u & 3], b[(u >> 2) & 3], acc[u & 7], 0, 0, 0);
+        for (int i = 0; i < 8; ++i) for (int r = 0; r < 4; ++r) s += acc[i][r];
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+template <int SHAPE>
+static void shape_rate(int blocks_per_cu, float* out) {
+    const int iters = 4000, grid = 256 * blocks_per_cu;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    float ms = 0;
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(e0);
+        for (int j = 0; j < 25; ++j) hipLaunchKernelGGL((shape_kernel<SHAPE>), dim3(grid), dim3(256), 0, 0, out, iters, 77u + rep);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1);
+    }
+    const double fl = 25.0 * grid * 4 * iters * 8.0 * 2 * 32 * 32 * 16;
+    printf("  %s on random operands, %d waves/SIMD: %7.1f TFLOP/s bf16 (%.0f ms of back-to-back launches)\n", SHAPE ? "v_mfma_f32_16x16x32_bf16" : "v_mfma_f32_32x32x16_bf16",
+           blocks_per_cu, fl / ms / 1e9, ms);
+}
+
 int main() {
     float *dA, *dB, *dC, *out;
     hipMalloc(&dA, 32 * 4096 * 4); hipMalloc(&dB, 32 * 4096 * 4); hipMalloc(&dC, 32 * 32 * 4); hipMalloc(&out, 256 * 8 * 256 * 4);
@@ -163,5 +210,7 @@ int main() {
     rate<4, 2, 0>(1, out); rate<4, 4, 0>(1, out); rate<4, 5, 0>(1, out); rate<4, 6, 0>(1, out); rate<4, 8, 0>(1, out);
     rate<4, 4, 0>(2, out); rate<4, 6, 0>(2, out); rate<4, 8, 0>(2, out);
     rate<4, 1, 1>(1, out); rate<4, 2, 1>(1, out); rate<4, 2, 1>(2, out);
+    printf("the two bf16 shapes on random operands (same FLOPs per iteration):\n");
+    shape_rate<0>(1, out); shape_rate<1>(1, out); shape_rate<0>(2, out); shape_rate<1>(2, out);
     return 0;
 }
