@@ -41,6 +41,31 @@ static constexpr int BVS = 192;                   // bytes per key row of a V pl
 static constexpr int BK_PLANE = BKT * BKS, BV_PLANE = BKT * BVS;
 static constexpr int B_STAGE = 3 * BK_PLANE + 3 * BV_PLANE;     // 32,256 bytes
 static constexpr int B_LDS = 2 * B_STAGE;
+// DMA form: unpadded 128-byte rows (a plane of a tile = 4 KB = four 1 KB transfers that land lane-linear), the 16-byte pieces of a row permuted
+// instead (the transfer fetches piece `pc ^ swz(row)` into place pc: swz = (row >> 1) & 7 for K - conflict-free 16-byte row reads of 16 rows -,
+// ((row >> 1) & 1) << 2 for V - the four rows of a transposed read fall on disjoint bank windows), rings of THREE stages (72 KB: two blocks per CU)
+static constexpr int DPL = BKT * 128;                           // bytes per plane of a tile
+static constexpr int D_LDS = 3 * 3 * (DPL + DPL);
+
+typedef unsigned int du32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* dlds_ptr_t;
+__device__ __forceinline__ du32x4 dma_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long b = reinterpret_cast<unsigned long long>(base);
+    du32x4 r;
+    r.x = __builtin_amdgcn_readfirstlane((unsigned)b);
+    r.y = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32)) & 0xFFFFu;
+    r.z = __builtin_amdgcn_readfirstlane(bytes);
+    r.w = 0x00020000u;
+    return r;
+}
+// one LDS-DMA piece as inline asm (conv_wino.hip: the compiler's wait-count pass must not see it, or it orders every later LDS read behind it)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ void bx_dma16(du32x4 rsrc, unsigned lds_byte_addr, unsigned voff, unsigned soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :: "s"(lds_byte_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory", "m0");
+}
+#pragma clang diagnostic pop
 
 __device__ __forceinline__ f32x16 mfma_bf(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
@@ -158,9 +183,13 @@ __global__ __launch_bounds__(256) void kv_planes_kernel(AttnArgs a) {
 }
 
 // PRE: K / V arrive as planes (kv_planes_kernel; staging is a copy). !PRE: fp32 K / V cut while they are staged (no workspace).
-template <bool PRE>
+template <bool PRE, bool DMA>
 __global__ __launch_bounds__(256, 2) void flash_attn_bx_kernel(AttnArgs a) {
+    static_assert(PRE || !DMA, "the DMA form stages planes");
     extern __shared__ __attribute__((aligned(16))) unsigned char bsm[];
+    constexpr int RD = DMA ? 3 : 2;                                  // ring depth
+    constexpr int KS = DMA ? 128 : BKS, VS = DMA ? 128 : BVS;        // row strides
+    constexpr int KPL = BKT * KS, VPL = BKT * VS;                    // plane sizes
 
     // block -> (pair, image, head, query block, key split): attention.hip's XCD-aware map
     const int gsz = (a.batch % 2 == 0) ? 2 : a.batch;
@@ -194,11 +223,13 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bx_kernel(AttnArgs a) {
 
     const float* Q = a.q + (long)z * a.bstride + (long)head * a.hstride;
     __amdgpu_buffer_rsrc_t K, V;
+    du32x4 Kd = {}, Vd = {};
     if constexpr (PRE) {
         const long rows = (long)a.heads * a.n_max * a.batch;
         const unsigned char* kp = reinterpret_cast<const unsigned char*>(a.planes) + (((long)y * a.heads + head) * a.n_max + k0) * 384;
         K = bx_rsrc_bytes(kp, nk * 384);
         V = bx_rsrc_bytes(kp + rows * 384, nk * 384);
+        if constexpr (DMA) { Kd = dma_rsrc(kp, nk * 384); Vd = dma_rsrc(kp + rows * 384, nk * 384); }
     } else {
         K = bx_rsrc_bytes(a.k + (long)y * a.bstride + (long)head * a.hstride + (long)k0 * 64, nk * 256);
         V = bx_rsrc_bytes(a.v + (long)y * a.bstride + (long)head * a.hstride + (long)k0 * 64, nk * 256);
@@ -225,9 +256,21 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bx_kernel(AttnArgs a) {
 
     // LDS: K ring (2 x 3 planes), V ring (2 x 3 planes); K runs one step ahead of V
     unsigned char* const kring = bsm;
-    unsigned char* const vring = bsm + 2 * 3 * BK_PLANE;
-    const int rd_k = c * BKS + hh * 16;                                                                // + plane, + 32 s
-    const int rd_v = (4 * hh + ((lane & 15) >> 2)) * BVS + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;    // + plane, + (16 s + 8 half) rows, + 64 dt
+    unsigned char* const vring = bsm + RD * 3 * KPL;
+    // fragment reads. K: row c, d-chunk s, pieces 2 s + hh of the row. V (transposed read): row 16 s + 8 half + 4 hh + q, bytes 64 dt + 32 dgrp + 8 pp
+    int kq[4], dv[2];
+    const int vq = (lane & 15) >> 2;
+    if constexpr (DMA) {
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) kq[s4] = c * 128 + (((2 * s4 + hh) ^ ((c >> 1) & 7)) << 4);
+        const int base = (4 * hh + vq) * 128 + (((lane >> 4) & 1) * 2 + ((lane & 3) >> 1)) * 16 + (lane & 1) * 8, sv = (vq >> 1) & 1;
+        dv[0] = base + sv * 64; dv[1] = base + (1 - sv) * 64;
+    } else {
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) kq[s4] = c * BKS + hh * 16 + 32 * s4;
+        const int base = (4 * hh + vq) * BVS + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
+        dv[0] = base; dv[1] = base + 64;
+    }
 
     // staging. PRE: a tile is 32 rows x 384 bytes = 768 16-byte pieces, contiguous in memory: piece id = tid + 256 i sits at byte 16 id,
     // row id / 24, plane (id % 24) >> 3, 16-byte column id & 7. !PRE: rows tid >> 4 and + 16, floats 4 (tid & 15) .. + 3.
@@ -282,17 +325,32 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bx_kernel(AttnArgs a) {
             stage4(vp, BV_PLANE, st_v, fv[0]); stage4(vp, BV_PLANE, st_v + 16 * BVS, fv[1]);
         }
     };
+    // DMA form: wave w transfers rows 8 w .. 8 w + 7 of the three planes of a tile (three 1 KB pieces per tensor), lane (row, place pc) fetching piece
+    // pc ^ swz(row) of its row
+    const int drow = 8 * wave + (lane >> 3), dpc = lane & 7;
+    const unsigned dvoff_k = drow * 384u + ((dpc ^ ((drow >> 1) & 7)) << 4), dvoff_v = drow * 384u + ((dpc ^ (((drow >> 1) & 1) << 2)) << 4);
+    const unsigned wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);          // in an SGPR: the transfer's LDS address goes through M0
+    const unsigned lds_k = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(dlds_ptr_t)kring) + wave_u * 1024u;
+    const unsigned lds_v = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(dlds_ptr_t)vring) + wave_u * 1024u;
+    auto dma_k = [&](int tile, int stage) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) bx_dma16(Kd, __builtin_amdgcn_readfirstlane(lds_k + (unsigned)stage * (3u * DPL) + i * DPL), dvoff_k, __builtin_amdgcn_readfirstlane((unsigned)tile * (BKT * 384u) + i * 128u));
+    };
+    auto dma_v = [&](int tile, int stage) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) bx_dma16(Vd, __builtin_amdgcn_readfirstlane(lds_v + (unsigned)stage * (3u * DPL) + i * DPL), dvoff_v, __builtin_amdgcn_readfirstlane((unsigned)tile * (BKT * 384u) + i * 128u));
+    };
     // S^T = K . Q^T of one tile: two accumulators (even / odd d-chunks), the small products first
     auto qk = [&](int stage, f32x16& out) {
-        const unsigned char* const kp = kring + stage * 3 * BK_PLANE + rd_k;
+        const unsigned char* const kp = kring + stage * 3 * KPL;
         f32x16 xa, xb;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { xa[r] = 0.f; xb[r] = 0.f; }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const u32x4 kh = *reinterpret_cast<const u32x4*>(kp + 32 * s);
-            const u32x4 km = *reinterpret_cast<const u32x4*>(kp + BK_PLANE + 32 * s);
-            const u32x4 kl = *reinterpret_cast<const u32x4*>(kp + 2 * BK_PLANE + 32 * s);
+            const u32x4 kh = *reinterpret_cast<const u32x4*>(kp + kq[s]);
+            const u32x4 km = *reinterpret_cast<const u32x4*>(kp + KPL + kq[s]);
+            const u32x4 kl = *reinterpret_cast<const u32x4*>(kp + 2 * KPL + kq[s]);
             f32x16& x = (s & 1) ? xb : xa;
             x = mfma_bf(kh, ql[s], x);
             x = mfma_bf(kl, qh[s], x);
@@ -305,16 +363,16 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bx_kernel(AttnArgs a) {
     };
     // O^T += V^T . P^T: registers 8 s .. 8 s + 7 of P are the eight k slots of key chunk s
     auto pv_mul = [&](int stage, const f32x16& p) {
-        const unsigned char* const vp = vring + stage * 3 * BV_PLANE + rd_v;
+        const unsigned char* const vp = vring + stage * 3 * VPL;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const Planes pp = split8(p[8 * s + 0], p[8 * s + 1], p[8 * s + 2], p[8 * s + 3], p[8 * s + 4], p[8 * s + 5], p[8 * s + 6], p[8 * s + 7]);
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
-                const unsigned char* vb = vp + (16 * s) * BVS + 64 * dt;
-                const u32x2 h0 = tr_read(vb), h1 = tr_read(vb + 8 * BVS);
-                const u32x2 m0 = tr_read(vb + BV_PLANE), m1 = tr_read(vb + BV_PLANE + 8 * BVS);
-                const u32x2 l0 = tr_read(vb + 2 * BV_PLANE), l1 = tr_read(vb + 2 * BV_PLANE + 8 * BVS);
+                const unsigned char* vb = vp + (16 * s) * VS + dv[dt];
+                const u32x2 h0 = tr_read(vb), h1 = tr_read(vb + 8 * VS);
+                const u32x2 m0 = tr_read(vb + VPL), m1 = tr_read(vb + VPL + 8 * VS);
+                const u32x2 l0 = tr_read(vb + 2 * VPL), l1 = tr_read(vb + 2 * VPL + 8 * VS);
                 const u32x4 vh = {h0.x, h0.y, h1.x, h1.y}, vm = {m0.x, m0.y, m1.x, m1.y}, vl = {l0.x, l0.y, l1.x, l1.y};
                 f32x16& o = dt ? o1 : o0;
                 o = mfma_bf(vh, pp.l, o);
@@ -329,17 +387,26 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bx_kernel(AttnArgs a) {
 
     // ---- prologue: K0 -> LDS, S(0); K1, V0 -> LDS; K2, V1 in registers
     f32x16 sc, sn;
-    load_k(0);
-    store_k(0);
-    load_k(1);
-    load_v(0);
-    __syncthreads();
-    qk(0, sc);
-    store_k(1);
-    store_v(0);
-    load_k(2);
-    load_v(1);
-    __syncthreads();
+    if constexpr (DMA) {       // tile j lives in ring stage j % 3
+        dma_k(0, 0); dma_k(1, 1); dma_v(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        dma_k(2, 2); dma_v(1, 1);              // in flight under S(0); waited for at the end of step 0
+        qk(0, sc);
+        __syncthreads();                       // every wave is done with K(0) before step 0 transfers K(3) over it
+    } else {
+        load_k(0);
+        store_k(0);
+        load_k(1);
+        load_v(0);
+        __syncthreads();
+        qk(0, sc);
+        store_k(1);
+        store_v(0);
+        load_k(2);
+        load_v(1);
+        __syncthreads();
+    }
 
     // step t: stage K(t+2), V(t+1); request K(t+3), V(t+2); reference of tile t; then 48 MFMA slots - S(t+1) = 24, O += P(t) V(t) = 24 -
     // with the vector work of tile t dealt over them BY HAND, a few instructions behind each MFMA and a scheduling fence behind each slot:
@@ -353,17 +420,25 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bx_kernel(AttnArgs a) {
     static constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};   // the six products, small ones first: A plane, B plane
     float m_use = 0.f;
     if (nt >= 2) m_use = softmax_ref<false>(sc, 0, nk, hh, m_run, l_run, o0, o1);     // tile 0 lies inside the keys
+    int r0 = 0, r1 = 1 % RD, r2 = 2 % RD;    // t % RD, (t + 1) % RD, (t + 2) % RD
     for (int t = 0; t < nt - 2; ++t) {       // tiles t and t + 1 lie inside the keys: no masks anywhere
-        const unsigned char* const kp = kring + ((t + 1) & 1) * 3 * BK_PLANE + rd_k;
-        const unsigned char* const vp = vring + (t & 1) * 3 * BV_PLANE + rd_v;
+        const unsigned char* const kp = kring + r1 * 3 * KPL;
+        const unsigned char* const vp = vring + r0 * 3 * VPL;
         u32x4 kf[2][3];
         u32x2 vr[2][6];
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) kf[0][pl] = *reinterpret_cast<const u32x4*>(kp + pl * BK_PLANE);
-        store_k(t & 1);
-        store_v((t + 1) & 1);
-        load_k(t + 3);
-        load_v(t + 2);
+        for (int pl = 0; pl < 3; ++pl) kf[0][pl] = *reinterpret_cast<const u32x4*>(kp + pl * KPL + kq[0]);
+#ifndef BX_ABL_NO_STAGE     // -DBX_ABL_*: timing-only ablations of the main loop (wrong results), as IM_ABL_* in attention.hip
+        if constexpr (DMA) {
+            dma_k(t + 3, r0);                // over K(t), last read in step t - 1
+            dma_v(t + 2, r2);                // over V(t - 1)
+        } else {
+            store_k(r0);
+            store_v(r1);
+            load_k(t + 3);
+            load_v(t + 2);
+        }
+#endif
         __builtin_amdgcn_sched_barrier(0);
 
         float ra[8], rb[8], rsum0 = 0.f, rsum1 = 0.f;
@@ -409,7 +484,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bx_kernel(AttnArgs a) {
         for (int s4 = 0; s4 < 4; ++s4) {
             if (s4 < 3) {
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) kf[(s4 + 1) & 1][pl] = *reinterpret_cast<const u32x4*>(kp + pl * BK_PLANE + 32 * (s4 + 1));
+                for (int pl = 0; pl < 3; ++pl) kf[(s4 + 1) & 1][pl] = *reinterpret_cast<const u32x4*>(kp + pl * KPL + kq[s4 + 1]);
             }
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
@@ -420,7 +495,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bx_kernel(AttnArgs a) {
                 if (slot < 8) expo(slot);
                 else if (slot < 16) { if (slot & 1) cut_b((slot - 8) >> 1); else cut_a((slot - 8) >> 1); }
                 else { expo(slot - 8); if (slot < 20) cut_l(slot - 16); }
-                if (slot >= 18) vr[0][slot - 18] = tr_read(vp + ((slot - 18) >> 1) * BV_PLANE + ((slot - 18) & 1) * 8 * BVS);
+                if (slot >= 18) vr[0][slot - 18] = tr_read(vp + dv[0] + ((slot - 18) >> 1) * VPL + ((slot - 18) & 1) * 8 * VS);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -455,7 +530,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bx_kernel(AttnArgs a) {
                 }
                 if (g < 3) {
                     const int gn = g + 1;
-                    vr[gn & 1][j] = tr_read(vp + (16 * (gn >> 1)) * BVS + 64 * (gn & 1) + (j >> 1) * BV_PLANE + (j & 1) * 8 * BVS);
+                    vr[gn & 1][j] = tr_read(vp + (16 * (gn >> 1)) * VS + dv[gn & 1] + (j >> 1) * VPL + (j & 1) * 8 * VS);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -476,24 +551,33 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bx_kernel(AttnArgs a) {
         }
         m_use = m_run;
         sc = sn;
+        { const int rr = r0; r0 = r1; r1 = r2; r2 = RD == 3 ? rr : r0; }
+        if constexpr (DMA) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");    // K(t+2), V(t+1) have landed; this step's six transfers may still fly
+#ifndef BX_ABL_NO_BARRIER
         __syncthreads();
+#endif
     }
 #undef BX_PIN
+    if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // nothing is requested from here on
     if (nt >= 2) {                           // step nt - 2 in plain form: its look-ahead tile is the last one, whose reference needs the mask
-        const int t = nt - 2;
-        store_k(t & 1);
-        store_v((t + 1) & 1);
-        qk((t + 1) & 1, sn);
+        if constexpr (DMA) {
+            __syncthreads();                 // the other waves' transfers too
+        } else {
+            store_k(r0);
+            store_v(r1);
+        }
+        qk(r1, sn);
         softmax_exp(sc, m_use, l_run);
-        pv_mul(t & 1, sc);
+        pv_mul(r0, sc);
         sc = sn;
+        { const int rr = r0; r0 = r1; r1 = r2; r2 = RD == 3 ? rr : r0; }
         __syncthreads();
     }
     {
         const int t = nt - 1;
         m_use = softmax_ref<true>(sc, t * BKT, nk, hh, m_run, l_run, o0, o1);
         softmax_exp(sc, m_use, l_run);
-        pv_mul(t & 1, sc);
+        pv_mul(r0, sc);
     }
 
     // ---- split-KV: park the partial (O, m, l); the last block of this query block merges all of them in split order (attention.hip)
@@ -568,12 +652,17 @@ hipError_t launch_attn_planes(const AttnArgs& a, hipStream_t s) {
 hipError_t launch_flash_attn_bx(const AttnArgs& a, hipStream_t s) {
     static size_t lds_pre[IM_MAX_DEVICES] = {0}, lds_cut[IM_MAX_DEVICES] = {0};
     dim3 grid(((a.n_max + 127) / 128) * a.heads * a.batch * (a.part ? ATTN_MAX_SPLIT : 1)), block(256);
-    if (a.planes) {     // filled by launch_attn_planes on the same stream
-        if (hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(&flash_attn_bx_kernel<true>), B_LDS, lds_pre); e != hipSuccess) return e;
-        hipLaunchKernelGGL(flash_attn_bx_kernel<true>, grid, block, B_LDS, s, a);
+    static size_t lds_dma[IM_MAX_DEVICES] = {0};
+    static const bool reg_staging = [] { const char* e = getenv("IM_ATTN_REG_STAGING"); return e && atoi(e) != 0; }();
+    if (a.planes && !reg_staging) {     // planes filled by launch_attn_planes on the same stream; tiles into LDS by LDS-DMA
+        if (hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(&flash_attn_bx_kernel<true, true>), D_LDS, lds_dma); e != hipSuccess) return e;
+        hipLaunchKernelGGL((flash_attn_bx_kernel<true, true>), grid, block, D_LDS, s, a);
+    } else if (a.planes) {              // tiles through registers (A/B)
+        if (hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(&flash_attn_bx_kernel<true, false>), B_LDS, lds_pre); e != hipSuccess) return e;
+        hipLaunchKernelGGL((flash_attn_bx_kernel<true, false>), grid, block, B_LDS, s, a);
     } else {
-        if (hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(&flash_attn_bx_kernel<false>), B_LDS, lds_cut); e != hipSuccess) return e;
-        hipLaunchKernelGGL(flash_attn_bx_kernel<false>, grid, block, B_LDS, s, a);
+        if (hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(&flash_attn_bx_kernel<false, false>), B_LDS, lds_cut); e != hipSuccess) return e;
+        hipLaunchKernelGGL((flash_attn_bx_kernel<false, false>), grid, block, B_LDS, s, a);
     }
     return hipGetLastError();
 }
