@@ -18,9 +18,12 @@
 //     O^T (64 d x 32 queries)   += V^T . P^T   A = three bf16 planes of a V tile in LDS, read TRANSPOSED by ds_read_b64_tr_b16,
 //                                              B = the planes of P = exp2(S^T - m), cut from the accumulator registers in place
 // (an accumulator tile is the next MFMA's B operand with the k order `16 s + 8 (j >> 2) + 4 h + (j & 3)`; the V reads use the same order).
-// A block is 128 queries of one (image, head): 4 waves x 32 queries, 32 keys per step, K / V tiles loaded as fp32 by range-checked buffer
-// loads one step ahead, cut into planes ONCE per block when they are written to LDS (two stages of 31.5 KB: two blocks per CU, each with
-// its own barrier, so that one block's vector phases sit beside the other's MFMAs).
+// A block is 128 queries of one (image, head): 4 waves x 32 queries, 32 keys per step, two blocks per CU, each with its own barrier, so that one
+// block's vector phases sit beside the other's MFMAs. Three forms of the K / V staging, same products in the same order (bit-identical results):
+//   <PRE, DMA>   the product: K / V arrive as bf16 planes (kv_planes_kernel, one small launch before this one) and go into LDS by LDS-DMA - no
+//                staging registers, no ds_write; unpadded 128-byte rows whose 16-byte pieces are permuted by the transfer, rings of three stages;
+//   <PRE, !DMA>  the same planes through registers (IM_ATTN_REG_STAGING=1, A/B): padded rows, rings of two stages;
+//   <!PRE>       no plane workspace: the fp32 tiles are cut while they are staged, once per block.
 #include "common.h"
 #include "kernels.h"
 #include "sp_post.h"
