@@ -476,7 +476,7 @@ def main():
         ms, cnt, fl = gstat[dom]
         ach = fl / (ms * 1e-3) / 1e12
         peak = PEAK_ATTN_TFLOPS if dom == ATTN_KERNEL else PEAK_F32_MFMA_TFLOPS
-        tkey = dom + ("<2>" if dom == "im::flash_attn_f32_kernel" else "<true>" if dom == ATTN_KERNEL else "")
+        tkey = dom + ("<2>" if dom == "im::flash_attn_f32_kernel" else "<true, true>" if dom == ATTN_KERNEL else "")   # the instantiation rocprofv3 names
         result["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                               "frac": ach / peak,
                               "traffic": traffic_db.get(tkey + ("@16384" if cfg5 else ""), {}).get("traffic_bytes"),
