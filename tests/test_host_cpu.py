@@ -758,6 +758,39 @@ def test_kernels_keep_their_register_budget(tmp_path):
         conv[field2("name")] = (int(field2("vgpr_count")), int(field2("vgpr_spill_count")), int(field2("private_segment_fixed_size")))
     assert len(conv) == 7, sorted(conv)     # pool / plain x fused / plain x U through registers / LDS, minus the unpooled fused register form
     assert all(v <= 256 and sp == 0 and scratch == 0 for v, sp, scratch in conv.values()), conv
+    # the kernels on the bf16 matrix cores (round 5): two waves per SIMD (<= 256 registers), no scratch; the attention's main loop must hold its 48
+    # bf16 MFMAs apart (the vector work of a tile is dealt over the MFMA slots by hand: at most two MFMAs back to back outside the last PV group),
+    # and the product form stages by LDS-DMA (no ds_write in its loop)
+    for name, n_kernels in (("attention_bx.hip", 4), ("ffn_fused.hip", 2), ("gemm.hip", 24)):
+        o = tmp_path / (name + ".s")
+        r = subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only", "-I" + os.path.join(ROOT, "include"),
+                            os.path.join(ROOT, "icepy4d_amd", "csrc", name), "-o", str(o)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        ks = {}
+        for blk in re.split(r"\n  - \.agpr_count:", o.read_text())[1:]:
+            def field3(k):
+                m = re.search(r"\." + k + r":\s+(\S+)", blk)
+                return m.group(1) if m else "0"
+            ks[field3("name")] = (int(field3("vgpr_count")), int(field3("vgpr_spill_count")), int(field3("private_segment_fixed_size")))
+        assert len(ks) == n_kernels, (name, sorted(ks))
+        assert all(v <= 256 and sp == 0 and scratch == 0 for v, sp, scratch in ks.values()), (name, ks)
+        if name == "attention_bx.hip":
+            text = o.read_text()
+            sym = "_ZN2im20flash_attn_bx_kernelILb1ELb1EEEvNS_8AttnArgsE"
+            body = text[text.index(sym + ":"):]
+            body = body[:body.index(".Lfunc_end")]
+            assert body.count("v_mfma_f32_32x32x16_bf16") >= 48 and "v_mfma_f32_32x32x2_f32" not in body
+            assert body.count("buffer_load_dwordx4") >= 6 and " lds" in body
+            # the hand-dealt loop: the basic block with the most bf16 MFMAs holds the 48 of a step; count its longest run of adjacent MFMAs
+            blocks = re.split(r"\n\.LBB\d+_\d+:", body)
+            hot = max(blocks, key=lambda b: b.count("v_mfma_f32_32x32x16_bf16"))
+            assert hot.count("v_mfma_f32_32x32x16_bf16") == 48 and "ds_write" not in hot, hot.count("v_mfma_f32_32x32x16_bf16")
+            ops = [l.split()[0] for l in hot.split("\n") if l.strip() and not l.strip().startswith((";", ".", "s_nop", "s_waitcnt"))]
+            run = best_run = 0
+            for op in ops:
+                run = run + 1 if op.startswith("v_mfma") else 0
+                best_run = max(best_run, run)
+            assert best_run <= 6, best_run         # only the last PV group (nothing left to deal) runs its six back to back
 
 
 # ------------------------------------------------------------------------------------------- failure isolation
