@@ -4,9 +4,10 @@
 //
 // Why: gfx950's f32-input MFMA runs at the VECTOR rate (157 TFLOP/s, 1 / 16 of the bf16 matrix cores) and holds the vector issue port
 // while it runs; the bf16 MFMA does neither. An fp32 value is the exact sum of three bf16 values (8 + 8 + 8 significant bits, each cut
-// rounded to nearest: x = x0 + x1 + x2 with |x1| <= 2^-9 |x|, |x2| <= 2^-18 |x|, remainder <= 2^-27 |x|), a bf16 product is exact in
-// the matrix core's fp32 accumulation, and of the nine products of two such triples the six with i + j <= 2 carry everything above
-// 2^-26 |a b| - less than the rounding of ONE fp32 accumulation. `tools/bf16x_probe.hip` measured it on the part
+// rounded to nearest: x = x0 + x1 + x2 with |x1| <= 2^-8 |x|, |x2| <= 2^-17 |x|, nothing left), a bf16 product is exact in
+// the matrix core's fp32 accumulation, and of the nine products of two such triples the three that are dropped (i + j >= 3) are worth at
+// most 2^-24 |a b| - the rounding of ONE fp32 operation -, 2^-27.4 in the root mean square (tests/test_host_cpu.py pins this arithmetic
+// in numpy). `tools/bf16x_probe.hip` measured the accumulation on the part
 // (`profiles/r05_bf16x_probe.txt`): error against an f64 sum, in units of 2^-24 sum |a b|, rms 0.37-0.39 for six products against
 // 0.45-0.47 for the f32 MFMA chain at K = 64 .. 4096 (the matrix core adds 16 products before it rounds once), nine products no
 // better than six, three 4-30 x worse; and six `v_mfma_f32_32x32x16_bf16` per 16 k run at 2.2-2.35 PFLOP/s = 2.4-2.5 x the f32 MFMA,
@@ -77,7 +78,7 @@ __device__ __forceinline__ unsigned cvt_pk(float a, float b) {            // v_c
     const bf16x2 v = __builtin_convertvector(f32x2{a, b}, bf16x2);
     return __builtin_bit_cast(unsigned, v);
 }
-// (a, b) -> three packed bf16 pairs with a = h.lo + m.lo + l.lo (remainder below 2^-27 |a|): the subtractions are exact
+// (a, b) -> three packed bf16 pairs with a = h.lo + m.lo + l.lo exactly: the subtractions are exact in fp32
 __device__ __forceinline__ void split2(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
     h = cvt_pk(a, b);
     float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);

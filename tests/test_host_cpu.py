@@ -793,6 +793,52 @@ def test_kernels_keep_their_register_budget(tmp_path):
             assert best_run <= 6, best_run         # only the last PV group (nothing left to deal) runs its six back to back
 
 
+
+def test_bf16_triple_arithmetic_behind_the_matchers_products():
+    """The arithmetic of csrc/attention_bx.hip / ffn_fused.hip / gemm.hip (BX), emulated in numpy (bf16 = the upper half of an fp32, round to
+    nearest even, as v_cvt_pk_bf16_f32): an fp32 value IS the sum of its three bf16 cuts (8 + 8 + 8 significant bits: exact, not approximate),
+    with |x1| <= 2^-8 |x| and |x2| <= 2^-17 |x|; the two subtractions of the cut are exact in fp32; every bf16 x bf16 product is exact in fp32;
+    and the six products with i + j <= 2 miss the exact product by at most 2^-24 |a b| - the rounding of ONE fp32 operation - and by 2^-27 in the
+    root mean square, where a rounded fp32 product itself sits at 2^-25.2; three products (i + j <= 1) miss by up to 2^-16. How the matrix core
+    accumulates them is measured on the device (profiles/r05_bf16x_probe.txt, tests/test_gpu_kernels.py); this pins the part that is arithmetic."""
+    rng = np.random.default_rng(5)
+
+    def bf16(x):
+        u = x.astype(np.float32).view(np.uint32).astype(np.uint64)
+        u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+        return u.astype(np.uint32).view(np.float32)
+
+    def cut(x):
+        x = x.astype(np.float32)
+        h = bf16(x)
+        r1 = (x - h).astype(np.float32)
+        assert np.array_equal(r1.astype(np.float64), x.astype(np.float64) - h.astype(np.float64))        # exact
+        m = bf16(r1)
+        r2 = (r1 - m).astype(np.float32)
+        assert np.array_equal(r2.astype(np.float64), r1.astype(np.float64) - m.astype(np.float64))       # exact
+        return h, m, bf16(r2)
+
+    x = np.concatenate([rng.standard_normal(400000), rng.uniform(0, 256, 200000), rng.standard_normal(100000) * 1e-6]).astype(np.float32)
+    y = rng.permutation(x)
+    xh, xm, xl = cut(x)
+    yh, ym, yl = cut(y)
+    x64, y64 = x.astype(np.float64), y.astype(np.float64)
+    assert np.array_equal(xh.astype(np.float64) + xm.astype(np.float64) + xl.astype(np.float64), x64)   # the three cuts ARE the value
+    ax = np.abs(x64)
+    assert (np.abs(xm.astype(np.float64)) <= ax * 2.0 ** -8).all() and (np.abs(xl.astype(np.float64)) <= ax * 2.0 ** -17).all()
+    for a in (xh, xm, xl):
+        for b in (yh, ym, yl):      # 8 x 8 significant bits: exact in fp32
+            assert np.array_equal((a * b).astype(np.float64), a.astype(np.float64) * b.astype(np.float64))
+    exact = x64 * y64
+    scale = np.abs(exact)
+    six = sum(a.astype(np.float64) * b.astype(np.float64) for a, b in ((xh, yl), (xl, yh), (xm, ym), (xh, ym), (xm, yh), (xh, yh)))
+    three = sum(a.astype(np.float64) * b.astype(np.float64) for a, b in ((xh, ym), (xm, yh), (xh, yh)))
+    e6, e3 = np.abs(six - exact) / scale, np.abs(three - exact) / scale
+    e32 = np.abs((x * y).astype(np.float32).astype(np.float64) - exact) / scale            # one rounded fp32 product, for scale
+    assert e6.max() <= 2.0 ** -24 and np.sqrt((e6 ** 2).mean()) <= 2.0 ** -27, (np.log2(e6.max()), np.log2(np.sqrt((e6 ** 2).mean())))
+    assert np.sqrt((e6 ** 2).mean()) < 0.25 * np.sqrt((e32 ** 2).mean())
+    assert e3.max() >= 2.0 ** -17       # what the other three products are for
+
 # ------------------------------------------------------------------------------------------- failure isolation (SURVEY 5)
 FAKE_SEQUENCE = r'''
 import torch
