@@ -84,7 +84,9 @@ __global__ __launch_bounds__(512, NG == 1 ? 4 : 2) void conv_wino_bx(const float
             const int idx = tid + 512 * i, pix = idx >> 4, f4 = idx & 15, py = pix / PW, px = pix - py * PW;
             const int y = y0 - 1 + py, x = x0 - 1 + px;
             v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#ifndef ABL_NO_PATCH
             if (idx < PH * PW * 16 && y >= 0 && y < H && x >= 0 && x < W) v[i] = *reinterpret_cast<const float4*>(img + ((long)y * W + x) * C + f4 * 4);
+#endif
         }
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
@@ -119,7 +121,9 @@ __global__ __launch_bounds__(512, NG == 1 ? 4 : 2) void conv_wino_bx(const float
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-#ifdef ABL_ONE_U   // timing-only ablation (wrong results): every chunk reads the SAME 12 KB of U - what is the L2 stream of the U planes worth?
+#ifdef ABL_NO_U
+                for (int pl = 0; pl < 3; ++pl) ub[buf][q][ct][pl] = u32x4{(unsigned)(lane + chunk), 2u + pl, 3u + q, 4u + ct};
+#elif defined(ABL_ONE_U)   // timing-only ablation (wrong results): every chunk reads the SAME 12 KB of U - what is the L2 stream of the U planes worth?
                 for (int pl = 0; pl < 3; ++pl) ub[buf][q][ct][pl] = upl[((((p0 + q) * 4 + 0 * chunk) * 2 + ct) * 3 + pl) * 64 * (1 + 0 * buf)];
 #else
                 for (int pl = 0; pl < 3; ++pl) ub[buf][q][ct][pl] = upl[((((p0 + q) * 4 + chunk) * 2 + ct) * 3 + pl) * 64];
