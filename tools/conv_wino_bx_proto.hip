@@ -227,6 +227,150 @@ __global__ __launch_bounds__(512, NG == 1 ? 4 : 2) void conv_wino_bx(const float
     }
 }
 
+// ---- version 3 (-DV3): the same layout with the block's parts overlapped: the halo patch in four 16-channel chunks through a double-buffered LDS image, the
+// next chunk's global loads (and U planes) in flight under this chunk's products; the exchange with 8-byte accesses in a [position][cout][tile] image
+static constexpr int P3PIX = 20;                       // floats per pixel of a patch chunk (16 + 4)
+static constexpr int P3ROW = 364;                      // floats per patch row (18 x 20 = 360, + 4)
+static constexpr int P3BUF = 10 * P3ROW;               // floats per buffer
+static constexpr int M3S = 34;                         // floats per (position, cout) row of the exchange image: 32 tiles + 2 (8-byte reads of 32 couts conflict-free)
+static constexpr int M3_BYTES = 16 * 32 * M3S * 4;     // 69,632 for one 32-cout half
+static constexpr int LDS3_BYTES = M3_BYTES > 2 * P3BUF * 4 ? M3_BYTES : 2 * P3BUF * 4;
+
+__global__ __launch_bounds__(512, 2) void conv_wino_bx3(const float* __restrict__ in, const uint16_t* __restrict__ up, const float* __restrict__ bias,
+                                                          float* __restrict__ out, int H, int W, int relu) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int rx = (W + 15) / 16;
+    const int x0 = (blockIdx.x % rx) * 16, y0 = (blockIdx.x / rx) * 8, b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 31, hh = lane >> 5;
+    const float* img = in + (long)b * H * W * C;
+
+    // patch chunk loads: 180 pixels x 4 float4 = 720 pieces, two per thread (the second one for 208 threads)
+    int pofs[2], gofs[2]; bool pin[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = tid + 512 * i, pix = idx >> 2, f4 = idx & 3, py = pix / 18, px = pix - py * 18;
+        const int y = y0 - 1 + py, x = x0 - 1 + px;
+        pin[i] = idx < 720 && y >= 0 && y < H && x >= 0 && x < W;
+        pofs[i] = idx < 720 ? py * P3ROW + px * P3PIX + f4 * 4 : -1;
+        gofs[i] = pin[i] ? (y * W + x) * C + f4 * 4 : 0;
+    }
+    float4 pv[2];
+    auto patch_load = [&](int chunk) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) pv[i] = pin[i] ? *reinterpret_cast<const float4*>(img + gofs[i] + 16 * chunk) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto patch_store = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) if (pofs[i] >= 0) *reinterpret_cast<float4*>(lds + buf * P3BUF + pofs[i]) = pv[i];
+    };
+
+    const int ph = wave >> 1, pp = wave & 1;
+    const int ty = c >> 3, tx = c & 7;
+    const int ra = ph == 0 ? 0 : (ph == 2 ? 2 : 1), rb = ph == 0 ? 2 : (ph == 1 ? 2 : (ph == 2 ? 1 : 3));
+    const float sgn = ph == 1 ? 1.f : -1.f;
+    const int oa = (2 * ty + ra) * P3ROW + (2 * tx) * P3PIX + 8 * hh, ob = (2 * ty + rb) * P3ROW + (2 * tx) * P3PIX + 8 * hh;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[q][ct][r] = 0.f;
+    const u32x4* upl = reinterpret_cast<const u32x4*>(up) + lane;
+    const int p0 = 4 * ph + 2 * pp;
+    u32x4 ub[2][2][2][3];
+    auto load_u = [&](int buf, int chunk) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) ub[buf][q][ct][pl] = upl[((((p0 + q) * 4 + chunk) * 2 + ct) * 3 + pl) * 64];
+    };
+    patch_load(0);
+    load_u(0, 0);
+    patch_store(0);
+    __syncthreads();
+#pragma unroll
+    for (int chunk = 0; chunk < 4; ++chunk) {
+        if (chunk < 3) { patch_load(chunk + 1); load_u((chunk + 1) & 1, chunk + 1); }
+        const float* pa = lds + (chunk & 1) * P3BUF + oa;
+        const float* pb = lds + (chunk & 1) * P3BUF + ob;
+        float t[4][8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float4 a0 = *reinterpret_cast<const float4*>(pa + j * P3PIX), a1 = *reinterpret_cast<const float4*>(pa + j * P3PIX + 4);
+            const float4 b0 = *reinterpret_cast<const float4*>(pb + j * P3PIX), b1 = *reinterpret_cast<const float4*>(pb + j * P3PIX + 4);
+            t[j][0] = a0.x + sgn * b0.x; t[j][1] = a0.y + sgn * b0.y; t[j][2] = a0.z + sgn * b0.z; t[j][3] = a0.w + sgn * b0.w;
+            t[j][4] = a1.x + sgn * b1.x; t[j][5] = a1.y + sgn * b1.y; t[j][6] = a1.z + sgn * b1.z; t[j][7] = a1.w + sgn * b1.w;
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (pp == 0) v[i] = q == 0 ? t[0][i] - t[2][i] : t[1][i] + t[2][i];
+                else v[i] = q == 0 ? t[2][i] - t[1][i] : t[1][i] - t[3][i];
+            }
+            const P3 a = split8(v);
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                const u32x4 bh = ub[chunk & 1][q][ct][0], bm = ub[chunk & 1][q][ct][1], bl = ub[chunk & 1][q][ct][2];
+                f32x16& x = acc[q][ct];
+                x = mfma_bf(a.h, bl, x);
+                x = mfma_bf(a.l, bh, x);
+                x = mfma_bf(a.m, bm, x);
+                x = mfma_bf(a.h, bm, x);
+                x = mfma_bf(a.m, bh, x);
+                x = mfma_bf(a.h, bh, x);
+            }
+        }
+        if (chunk < 3) {
+            patch_store((chunk + 1) & 1);      // the other buffer: last read in chunk - 1, behind the barrier of that step
+            __syncthreads();
+        }
+    }
+    // ---- inverse transform, one 32-cout half at a time through M[position][cout][tile] (8-byte accesses)
+    float* img_out = out + (long)b * H * W * C;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {       // registers 4 g .. 4 g + 3 = tiles 8 g + 4 hh + (0..3)
+                float* dst = lds + ((p0 + q) * 32 + c) * M3S + 8 * g + 4 * hh;
+                *reinterpret_cast<float2*>(dst) = make_float2(acc[q][ct][4 * g], acc[q][ct][4 * g + 1]);
+                *reinterpret_cast<float2*>(dst + 2) = make_float2(acc[q][ct][4 * g + 2], acc[q][ct][4 * g + 3]);
+            }
+        __syncthreads();
+        {
+            const int co = tid & 31, tp = tid >> 5;          // two tiles 2 tp, 2 tp + 1 of cout co
+            float2 m[16];
+#pragma unroll
+            for (int p = 0; p < 16; ++p) m[p] = *reinterpret_cast<const float2*>(lds + (p * 32 + co) * M3S + 2 * tp);
+            const float bv = bias[32 * ct + co];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                float mm[16];
+#pragma unroll
+                for (int p = 0; p < 16; ++p) mm[p] = e ? m[p].y : m[p].x;
+                float s0[4], s1[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { s0[j] = mm[j] + mm[4 + j] + mm[8 + j]; s1[j] = mm[4 + j] - mm[8 + j] - mm[12 + j]; }
+                float y[2][2] = {{s0[0] + s0[1] + s0[2] + bv, s0[1] - s0[2] - s0[3] + bv}, {s1[0] + s1[1] + s1[2] + bv, s1[1] - s1[2] - s1[3] + bv}};
+                const int tile = 2 * tp + e, oy = y0 + 2 * (tile >> 3), ox = x0 + 2 * (tile & 7);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        if (oy + i < H && ox + j < W) img_out[((long)(oy + i) * W + ox + j) * C + 32 * ct + co] = relu ? fmaxf(y[i][j], 0.f) : y[i][j];
+            }
+        }
+    }
+}
+
 static uint16_t host_bf16(float x) {
     uint32_t u;
     memcpy(&u, &x, 4);
@@ -269,7 +413,14 @@ int main() {
     uint16_t* d_up; float *d_bias, *d_in, *d_out;
     hipMalloc(&d_up, up.size() * 2); hipMemcpy(d_up, up.data(), up.size() * 2, hipMemcpyHostToDevice);
     hipMalloc(&d_bias, C * 4); hipMemcpy(d_bias, bias.data(), C * 4, hipMemcpyHostToDevice);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_bx), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+#ifdef V3
+#define KERNEL conv_wino_bx3
+#define KLDS LDS3_BYTES
+#else
+#define KERNEL conv_wino_bx
+#define KLDS LDS_BYTES
+#endif
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, KLDS);
 
     {   // ---- accuracy on a small ragged image against a float64 direct convolution
         const int B = 1, H = 21, W = 37;
@@ -277,7 +428,7 @@ int main() {
         for (auto& v : x) v = nd(rng);
         hipMalloc(&d_in, x.size() * 4); hipMalloc(&d_out, x.size() * 4);
         hipMemcpy(d_in, x.data(), x.size() * 4, hipMemcpyHostToDevice);
-        hipLaunchKernelGGL(conv_wino_bx, dim3(((W + TW - 1) / TW) * ((H + TH - 1) / TH), B), dim3(512), LDS_BYTES, 0, d_in, d_up, d_bias, d_out, H, W, 0);
+        hipLaunchKernelGGL(KERNEL, dim3(((W + TW - 1) / TW) * ((H + TH - 1) / TH), B), dim3(512), KLDS, 0, d_in, d_up, d_bias, d_out, H, W, 0);
         hipMemcpy(y.data(), d_out, y.size() * 4, hipMemcpyDeviceToHost);
         double mx = 0, mxref = 0;
         for (int yy = 0; yy < H; ++yy)
@@ -307,7 +458,7 @@ int main() {
         hipEventCreate(&e0); hipEventCreate(&e1);
         for (int rep = 0; rep < 3; ++rep) {
             hipEventRecord(e0);
-            for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(conv_wino_bx, grid, dim3(512), LDS_BYTES, 0, d_in, d_up, d_bias, d_out, H, W, 1);
+            for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(KERNEL, grid, dim3(512), KLDS, 0, d_in, d_up, d_bias, d_out, H, W, 1);
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
             if (rep == 2) {
