@@ -470,9 +470,16 @@ def main():
             ms = sum(prof[k]["total_ms"] for k in names if k in prof)
             cnt = sum(prof[k]["count"] for k in names if k in prof)
             fl = sum(kernel_flops(k, 2, n0, n1, h, w, cfg5) * prof[k]["count"] for k in names if k in prof)
+            if sym.startswith("im::conv3x3_wino"):
+                fl /= 2.25     # the Winograd F(2x2, 3x3) kernels execute 16 multiplies per 2 x 2 outputs where the direct form has 36: a utilisation prices what runs
             if cnt:
                 gstat[sym] = (ms, cnt, fl)
         dom = max(gstat, key=lambda k: gstat[k][0])
+        # since round 5 the attention class and the Winograd class take the same share of a pair to within a few per cent (2.8 ms each): keep the attention
+        # class as the line's `roofline` while it is within 5 % of the largest, so that the line does not flip between two kernels from box to box; the other
+        # class is always next to it (`roofline_attention` / `roofline_convolutions`)
+        if ATTN_KERNEL in gstat and gstat[ATTN_KERNEL][0] >= 0.95 * gstat[dom][0]:
+            dom = ATTN_KERNEL
         ms, cnt, fl = gstat[dom]
         ach = fl / (ms * 1e-3) / 1e12
         peak = PEAK_ATTN_TFLOPS if dom == ATTN_KERNEL else PEAK_F32_MFMA_TFLOPS
@@ -486,6 +493,20 @@ def main():
                               "launches_per_pair": cnt / prof_steps, "algorithmic_gflop_per_launch": fl / cnt / 1e9,
                               "share_of_pair_time": ms / tot, "event_pair_overhead_us": round(1e3 * ev_overhead_ms, 2),
                               "measured": how}
+        if dom.startswith("im::conv3x3_wino"):
+            result["roofline"]["flops_are"] = ("EXECUTED FLOPs of the Winograd F(2x2, 3x3) form = SURVEY 8d's direct-form count / 2.25 (the direct-form rate is "
+                                               "`achieved` x 2.25 and exceeds the f32-input MFMA peak: not a utilisation). The attention class "
+                                               f"({ATTN_KERNEL}) is within a few per cent of this one in time: its figures are in `roofline_attention`")
+        if dom != ATTN_KERNEL and ATTN_KERNEL in gstat:
+            ms_a, cnt_a, fl_a = gstat[ATTN_KERNEL]
+            result["roofline_attention"] = {"bound": "mfma", "kernel": ATTN_KERNEL, "achieved": fl_a / (ms_a * 1e-3) / 1e12, "peak": PEAK_ATTN_TFLOPS, "unit": "TFLOP/s",
+                                            "frac": fl_a / (ms_a * 1e-3) / 1e12 / PEAK_ATTN_TFLOPS, "avg_launch_ms": ms_a / cnt_a, "share_of_pair_time": ms_a / tot}
+        conv_sym = next((k for k in gstat if k.startswith("im::conv3x3_wino")), None)
+        if dom == ATTN_KERNEL and conv_sym:
+            ms_c, cnt_c, fl_c = gstat[conv_sym]
+            result["roofline_convolutions"] = {"bound": "mfma", "kernel": conv_sym, "achieved": fl_c / (ms_c * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                               "frac": fl_c / (ms_c * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, "share_of_pair_time": ms_c / tot,
+                                               "flops_are": "EXECUTED FLOPs of the Winograd F(2x2, 3x3) form = SURVEY 8d's direct-form count / 2.25, on the f32-input MFMA"}
         if dom == ATTN_KERNEL and not ATTN_F32_FORM:
             result["roofline"].update({
                 "peak_is": f"{PEAK_BF16_MFMA_TFLOPS:.0f} TFLOP/s dense bf16 MFMA (MI355X_MICROARCH.md) / {ATTN_BF16_PRODUCTS}: the kernel computes every "
