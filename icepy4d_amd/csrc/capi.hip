@@ -99,14 +99,18 @@ static int conv3x3_entry(im_ctx* ctx, bool wino, const float* d_in, const float*
     IM_CHECK_CTX(ctx);
     if (cin % 16 || cout % 64) return ctx->fail(-10, "im_conv3x3: cin %% 16 and cout %% 64 must be 0");
     std::vector<float> packed = wino ? pack_conv3x3_wino(h_weight, cout, cin) : pack_conv3x3(h_weight, cout, cin);
-    float *dw = nullptr, *db = nullptr;
+    std::vector<float> planes = wino ? pack_conv3x3_wino_bx(h_weight, cout, cin) : std::vector<float>(1);   // the product form of the Winograd layer (IM_CONV_F32=1: the f32-input form)
+    float *dw = nullptr, *db = nullptr, *dx = nullptr;
     IM_HIP(ctx, hipMalloc(&dw, packed.size() * sizeof(float)));
     IM_HIP(ctx, hipMalloc(&db, cout * sizeof(float)));
+    IM_HIP(ctx, hipMalloc(&dx, planes.size() * sizeof(float)));
     IM_HIP(ctx, hipMemcpy(dw, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
     IM_HIP(ctx, hipMemcpy(db, h_bias, cout * sizeof(float), hipMemcpyHostToDevice));
+    IM_HIP(ctx, hipMemcpy(dx, planes.data(), planes.size() * sizeof(float), hipMemcpyHostToDevice));
     ConvArgs a;
     a.in = d_in; a.w = dw; a.bias = db; a.out = d_out; a.B = b; a.H = h; a.W = w; a.Cin = cin; a.Cout = cout;
     a.relu = relu; a.pool = pool;
+    if (wino) a.wx = dx;
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipSuccess;
     if (ctx->prof_on) {
@@ -121,6 +125,7 @@ static int conv3x3_entry(im_ctx* ctx, bool wino, const float* d_in, const float*
     hipError_t e2 = hipStreamSynchronize(st);
     hipFree(dw);
     hipFree(db);
+    hipFree(dx);
     IM_HIP(ctx, e);
     IM_HIP(ctx, e2);
     return 0;

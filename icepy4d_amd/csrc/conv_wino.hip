@@ -117,6 +117,9 @@ static constexpr int S_MAIN = 2 * S_SP + 2 * W_SU;
 static constexpr int S_IH = S_TH + 4, S_IW = S_TW + 4;
 static constexpr int S_FUSE = S_IH * S_IW;
 static constexpr int S_LDS_FLOATS = S_MAIN;
+static constexpr int X_SP = 4 * S_QUAD * 4;          // BX: floats per patch stage (four channel quads = 16 channels)
+static constexpr int X_LDS_FLOATS = 16384;           // BX: two patch stages (6,400 floats); the 64 KB exchange image of the epilogue aliases them
+static_assert(2 * X_SP <= X_LDS_FLOATS, "the patch stages must fit under the exchange image");
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
@@ -151,8 +154,42 @@ __device__ __forceinline__ void dma16(wu32x4 rsrc, unsigned lds_byte_addr, unsig
 // eight outstanding" means the transfers have landed while the U loads stay in flight across the barrier (round 5)
 #define IM_DMA_WAIT_BEFORE_8_LOADS() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
 
-template <bool POOL, bool FUSE1A, bool UREG>
+// ---- BX (round 6): the sixteen element-wise products on the bf16 matrix cores at fp32 accuracy, as gemm.hip BX / attention_bx.hip: every fp32
+// operand is the exact sum of three bf16 values (x = h + m + l, each rounded to nearest even from the residual), a product is the six bf16
+// products h l, l h, m m, h m, m h, h h accumulated in fp32 in that order (small terms first). U is cut on the host (weights.hip::
+// pack_conv3x3_wino_bx); V = B^T d B is computed in fp32 exactly as in the f32 form and cut AFTER the transform (the planes of a sum are not
+// the sums of the planes), in registers, just before it becomes the A operand of v_mfma_f32_32x32x16_bf16 (lane (c, hh): tile c, channels
+// 8 hh .. 8 hh + 7 of a 16-channel chunk).
+typedef __bf16 wbf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 wbf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x16 mfma_bx(wu32x4 a, wu32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wbf16x8, a), __builtin_bit_cast(wbf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ unsigned wcvt_pk(float a, float b) {
+    const wbf16x2 v = __builtin_convertvector(f32x2{a, b}, wbf16x2);
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ void wsplit2(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
+    h = wcvt_pk(a, b);
+    float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
+    m = wcvt_pk(ra, rb);
+    ra -= __uint_as_float(m << 16);
+    rb -= __uint_as_float(m & 0xffff0000u);
+    l = wcvt_pk(ra, rb);
+}
+struct WPlanes { wu32x4 h, m, l; };
+__device__ __forceinline__ WPlanes wsplit8(const float (&x)[8]) {
+    unsigned h[4], m[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wsplit2(x[2 * i], x[2 * i + 1], h[i], m[i], l[i]);
+    return WPlanes{wu32x4{h[0], h[1], h[2], h[3]}, wu32x4{m[0], m[1], m[2], m[3]}, wu32x4{l[0], l[1], l[2], l[3]}};
+}
+static constexpr int X_RING = 4;                     // register slots of U fragments (one (position, 32 output channels) fragment = 3 planes x 4 registers)
+static constexpr int X_AHEAD = X_RING - 1;           // fragments requested ahead of the one in use
+
+template <bool POOL, bool FUSE1A, bool UREG, bool BX = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
+    static_assert(!BX || UREG, "BX reads its U fragments straight into registers");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sP = smem;                   // [2][S_SP]
     float* sU = smem + 2 * S_SP;        // [2][16][64][8]
@@ -160,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
     // the matrix pipe, into a resident LDS image [16 quads][S_QUAD] float4 (51 KB); the slab loop then has no producer, no transfer
     // and NO BARRIER - patch read-only, U per wave in registers. The exchange buffer of the epilogue (64 KB) aliases the patch.
     constexpr bool RESIDENT = FUSE1A && UREG;
-    float* sImg = smem + (RESIDENT ? 16384 : S_LDS_FLOATS);  // FUSE1A only
+    float* sImg = smem + (RESIDENT || BX ? 16384 : S_LDS_FLOATS);  // FUSE1A only
 
     const int nslices = a.Cout / 64;
     const int tx = (a.W + S_TW - 1) / S_TW, ty = (a.H + S_TH - 1) / S_TH;
@@ -350,6 +387,95 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
 
     const int nslab = a.Cin / WCC;
     const f32x2 m1 = minus_one();
+    if constexpr (BX) {
+        // ---- BX main loop: 16-channel chunks. Per chunk and wave: 16 patch reads, the transform of its V row (64 packed-pair adds), four cuts
+        // (one per position: 8 values -> 12 registers of planes), 8 steps of six MFMAs (position j = s >> 1, output channels 32 (s & 1) ..), and
+        // 8 x 3 fragment loads (1 KB each, lane-linear) requested X_AHEAD steps ahead into a ring of X_RING register slots. The patch of the
+        // next chunk travels by LDS-DMA under this chunk's products (plain layers; the fused first layer reads its resident image).
+        const int nchunk = a.Cin / 16;
+        const unsigned ux_pos = (unsigned)(a.Cout / 32) * 3072u, ux_chunk = 16u * ux_pos;
+        const __amdgpu_buffer_rsrc_t rux = wmake_rsrc(a.wx, (unsigned)nchunk * ux_chunk);
+        const unsigned ux_voff = (unsigned)lane * 16u;
+        const unsigned ux_base = (unsigned)(4 * ph) * ux_pos + (unsigned)(co0 / 32) * 3072u;
+        const int x_slotA = 2 * hh * S_QUAD + (2 * t_ty + rowA) * S_ROW + t_tx, x_slotB = 2 * hh * S_QUAD + (2 * t_ty + rowB) * S_ROW + t_tx;
+        wu32x4 ur[X_RING][3];
+#define IM_XULOAD(slot, chunk, s)                                                                        \
+        {                                                                                                \
+            const unsigned so_ = (unsigned)((chunk) + ((s) >> 3)) * ux_chunk + ux_base + (unsigned)(((s) >> 1) & 3) * ux_pos + (unsigned)((s) & 1) * 3072u; \
+            _Pragma("unroll") for (int pl_ = 0; pl_ < 3; ++pl_)                                            \
+                ur[slot][pl_] = __builtin_amdgcn_raw_buffer_load_b128(rux, ux_voff + pl_ * 1024u, so_, 0); \
+        }
+        auto xstage = [&](int chunk) {       // the patch of `chunk` (four channel quads) into stage chunk & 1
+            if (tid < S_QUAD) {
+                const unsigned pb_ = lds_sP + ((chunk & 1) * X_SP + wave * 256) * 4u;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dma16(rin, pb_ + q * (S_QUAD * 16u), pv, chunk * 64u + q * 16u);
+            }
+        };
+        auto xchunk = [&](int chunk, auto FIRST_) {
+            constexpr bool FIRST = decltype(FIRST_)::value;
+            const bool more = chunk + 1 < nchunk;                                   // uniform
+            if constexpr (!RESIDENT) { if (more) xstage(chunk + 1); }
+            const float4* pa = RESIDENT ? reinterpret_cast<const float4*>(smem) + chunk * (4 * S_QUAD)
+                                        : reinterpret_cast<const float4*>(sP + (chunk & 1) * X_SP);
+            float v[4][8];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const float4* pq = pa + q * S_QUAD;
+                float4 t[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) t[j] = sub4(pq[x_slotA + (j & 1) * S_PAR + (j >> 1)], pq[x_slotB + (j & 1) * S_PAR + (j >> 1)], rsgn);
+                const float4 w0 = sub4(t[0], t[2], m1), w1 = add4(t[1], t[2]), w2 = sub4(t[2], t[1], m1), w3 = sub4(t[1], t[3], m1);
+                v[0][4 * q] = w0.x; v[0][4 * q + 1] = w0.y; v[0][4 * q + 2] = w0.z; v[0][4 * q + 3] = w0.w;
+                v[1][4 * q] = w1.x; v[1][4 * q + 1] = w1.y; v[1][4 * q + 2] = w1.z; v[1][4 * q + 3] = w1.w;
+                v[2][4 * q] = w2.x; v[2][4 * q + 1] = w2.y; v[2][4 * q + 2] = w2.z; v[2][4 * q + 3] = w2.w;
+                v[3][4 * q] = w3.x; v[3][4 * q + 1] = w3.y; v[3][4 * q + 2] = w3.z; v[3][4 * q + 3] = w3.w;
+            }
+            // the cut of position j + 1 rides in the two steps of position j (pairs 0, 1 beside the first 32 output channels' MFMAs, pairs 2, 3 beside
+            // the second's); a scheduling fence per step keeps every step's fragment loads X_AHEAD steps in front of their use (the machine
+            // scheduler otherwise sinks each load to its use, wait and all)
+            unsigned ph_[2][4], pm_[2][4], pl_[2][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wsplit2(v[0][2 * i], v[0][2 * i + 1], ph_[0][i], pm_[0][i], pl_[0][i]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const int j = s >> 1, n = s & 1, cur = j & 1;
+                const wu32x4 ah = {ph_[cur][0], ph_[cur][1], ph_[cur][2], ph_[cur][3]}, am = {pm_[cur][0], pm_[cur][1], pm_[cur][2], pm_[cur][3]},
+                             al = {pl_[cur][0], pl_[cur][1], pl_[cur][2], pl_[cur][3]};
+                const wu32x4 bh = ur[s % X_RING][0], bm = ur[s % X_RING][1], bl = ur[s % X_RING][2];
+                f32x16 x = mfma_bx(ah, bl, FIRST ? f32x16{} : acc[s]);
+                x = mfma_bx(al, bh, x);
+                x = mfma_bx(am, bm, x);
+                x = mfma_bx(ah, bm, x);
+                x = mfma_bx(am, bh, x);
+                acc[s] = mfma_bx(ah, bh, x);
+                if (j < 3) {
+#pragma unroll
+                    for (int i = 2 * n; i < 2 * n + 2; ++i) wsplit2(v[j + 1][2 * i], v[j + 1][2 * i + 1], ph_[cur ^ 1][i], pm_[cur ^ 1][i], pl_[cur ^ 1][i]);
+                }
+                IM_XULOAD((s + X_AHEAD) % X_RING, chunk, s + X_AHEAD)      // past the last chunk: beyond the descriptor's range, i.e. zeros and no traffic
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (!RESIDENT) {
+                __builtin_amdgcn_sched_barrier(0);
+                // the transfers of the next patch were issued before this chunk's 24 fragment loads: "at most the X_AHEAD fragments in flight" means
+                // they have landed (loads and transfers complete in issue order); the barrier covers the other waves' transfers and reads
+                if (more) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * X_AHEAD) : "memory");
+                __syncthreads();
+            }
+        };
+#pragma unroll
+        for (int s = 0; s < X_AHEAD; ++s) IM_XULOAD(s, 0, s)
+        if constexpr (!RESIDENT) {
+            xstage(0);
+            IM_DMA_WAIT();
+            __syncthreads();
+        }
+        xchunk(0, std::true_type{});
+        for (int chunk = 1; chunk < nchunk; ++chunk) xchunk(chunk, std::false_type{});
+#undef IM_XULOAD
+    } else {
     if constexpr (UREG) { IM_ULOAD(uA, 0) }
     if constexpr (!RESIDENT) {
         IM_SSTAGE(0)
@@ -396,6 +522,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
         IM_SSTEP(0, true)
         for (int slab = 1; slab < nslab; ++slab) IM_SSTEP(slab, false)
     }
+    }   // !BX
 #undef IM_USTEP
 #undef IM_SSTEP
 #undef IM_SSTAGE
@@ -522,20 +649,32 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
 }
 
 
-// a.w must be the Winograd-packed weights [Cin/8][16][Cout][8] (pack_conv3x3_wino)
-template <bool POOL, bool FUSE, bool UREG>
+// a.w must be the Winograd-packed weights [Cin/8][16][Cout][8] (pack_conv3x3_wino); BX: a.wx the bf16 planes (pack_conv3x3_wino_bx)
+template <bool POOL, bool FUSE, bool UREG, bool BX = false>
 static hipError_t launch_wino(const ConvArgs& a, hipStream_t s) {
     const int ntile = ((a.W + S_TW - 1) / S_TW) * ((a.H + S_TH - 1) / S_TH) * a.B;
     dim3 grid(((ntile + 7) / 8) * 8 * (a.Cout / 64)), block(256);
-    const size_t lds = ((FUSE && UREG ? 16384 : S_LDS_FLOATS) + (FUSE ? S_FUSE : 0)) * sizeof(float);
+    const size_t lds = ((BX ? X_LDS_FLOATS : FUSE && UREG ? 16384 : S_LDS_FLOATS) + (FUSE ? S_FUSE : 0)) * sizeof(float);
     static size_t lds_optin[IM_MAX_DEVICES] = {0};   // per device: a process may hold contexts on several GPUs
-    if (hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(&conv3x3_wino_kernel<POOL, FUSE, UREG>), lds, lds_optin); e != hipSuccess) return e;
-    hipLaunchKernelGGL((conv3x3_wino_kernel<POOL, FUSE, UREG>), grid, block, lds, s, a);
+    if (hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(&conv3x3_wino_kernel<POOL, FUSE, UREG, BX>), lds, lds_optin); e != hipSuccess) return e;
+    hipLaunchKernelGGL((conv3x3_wino_kernel<POOL, FUSE, UREG, BX>), grid, block, lds, s, a);
     return hipGetLastError();
 }
 
 hipError_t launch_conv3x3_wino(const ConvArgs& a, hipStream_t s) {
     if (a.Cin < WCC || a.Cin % WCC != 0 || a.Cout % 64 != 0) return hipErrorInvalidValue;
+    // BX (round 6): the products on the bf16 matrix cores whenever the bf16 planes of U are there; IM_CONV_F32=1 (read per call: the parity tests
+    // run both forms in one process) or a.f32_form keeps the f32-input form of rounds 2-5, which needs a.w
+    const char* const f32_env = getenv("IM_CONV_F32");
+    const bool bx = a.wx && a.Cin % 16 == 0 && !(a.f32_form || (f32_env && f32_env[0] == '1'));
+    if (bx) {
+        if (a.img) {
+            if (a.Cin != 64 || !a.pool || !a.w1 || !a.b1 || !a.w1q) return hipErrorInvalidValue;     // the model's conv1b: fused first layer, pooled
+            return launch_wino<true, true, true, true>(a, s);
+        }
+        return a.pool ? launch_wino<true, false, true, true>(a, s) : launch_wino<false, false, true, true>(a, s);
+    }
+    if (!a.w) return hipErrorInvalidValue;
     // U through registers where one slice covers all output channels (the 64 -> 64 layers), through LDS otherwise; the register form
     // walks the slabs in pairs
     const bool ureg = a.Cout == 64 && (a.Cin / WCC) % 2 == 0;

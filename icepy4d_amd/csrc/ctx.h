@@ -22,6 +22,7 @@ struct MergeScratch {                     // im_merge_tile_matches (tile_merge.h
 };
 std::vector<float> pack_conv3x3(const float* w, int cout, int cin);       // [cout][cin][3][3] -> [cin/16][9][cout][16]
 std::vector<float> pack_conv3x3_wino(const float* w, int cout, int cin);  // -> G g G^T as [cin/8][16][cout][8]
+std::vector<float> pack_conv3x3_wino_bx(const float* w, int cout, int cin);  // -> the same values as three bf16 planes in MFMA-fragment order (bytes in floats)
 
 struct SuperPointW {
     bool ready = false;
@@ -29,6 +30,7 @@ struct SuperPointW {
     float* c1a_wq = nullptr;                                 // [64][2][8]: conv1a weights + bias in the k order of the resident-patch form (conv_wino.hip)
     float* cw[10] = {nullptr}; float* cb[10] = {nullptr};     // conv1b..conv4b, convPa, convDa (packed slabs)
     float* cww[10] = {nullptr};                               // the same layers, Winograd-transformed weights
+    float* cwx[10] = {nullptr};                               // the same again as bf16 planes (conv_wino.hip BX)
     float* pb_w = nullptr; float* pb_b = nullptr;             // convPb [65][256], [65]
     float* db_w = nullptr; float* db_b = nullptr;             // convDb [256][256], [256]
 };

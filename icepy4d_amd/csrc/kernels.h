@@ -109,9 +109,15 @@ struct ConvArgs {
     const float* w1 = nullptr;    // conv1a weights [9][64]
     const float* b1 = nullptr;    // conv1a bias [64]
     const float* w1q = nullptr;   // conv1a as MFMA A operand: [64 channels][2 lane halves][8] = {bias, tap 1, 3, 5, 7, -, -, -} / {tap 0, 2, 4, 6, 8, -, -, -}
+    // Winograd form on the bf16 matrix cores (conv_wino.hip BX, round 6): the same U = G g G^T cut into three bf16 planes per value in
+    // MFMA-fragment order (pack_conv3x3_wino_bx). When set, launch_conv3x3_wino runs the six-bf16-products form; a.w may then be null
+    // unless the f32-input form is asked for (IM_CONV_F32=1 / f32_form)
+    const void* wx = nullptr;
+    int f32_form = 0;             // 1: the f32-input MFMA Winograd kernel (rounds 2-5) although wx is set
 };
 hipError_t launch_conv3x3(const ConvArgs& a, hipStream_t s);
-// Winograd F(2x2, 3x3) variant (conv_wino.hip); a.w = weights packed by pack_conv3x3_wino: [Cin / 8][16][Cout][8]
+// Winograd F(2x2, 3x3) variant (conv_wino.hip); a.w = weights packed by pack_conv3x3_wino: [Cin / 8][16][Cout][8] and / or
+// a.wx = the same as bf16 planes (pack_conv3x3_wino_bx): [Cin / 16][16][Cout / 32][3][64][8] bf16
 hipError_t launch_conv3x3_wino(const ConvArgs& a, hipStream_t s);
 // conv1a: u8 gray [B][H][W] -> (x / 255) * w + b, ReLU -> NHWC [B][H][W][64]; w packed [9][64]
 hipError_t launch_conv1a(const uint8_t* img, int channels, int gray_mode, const float* w, const float* bias, float* out, int B, int H,

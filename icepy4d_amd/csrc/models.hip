@@ -55,8 +55,9 @@ static int finalize_superpoint(im_ctx* ctx) {
         GETW(cb, "superpoint", nm + ".bias", (size_t)SP_COUT[i]);
         w.cw[i] = ctx->upload(pack_conv3x3(cw->data(), SP_COUT[i], SP_CIN[i]));
         w.cww[i] = ctx->upload(pack_conv3x3_wino(cw->data(), SP_COUT[i], SP_CIN[i]));
+        w.cwx[i] = ctx->upload(pack_conv3x3_wino_bx(cw->data(), SP_COUT[i], SP_CIN[i]));
         w.cb[i] = ctx->upload(*cb);
-        if (!w.cw[i] || !w.cww[i] || !w.cb[i]) return ctx->fail(-22, "weights: upload failed");
+        if (!w.cw[i] || !w.cww[i] || !w.cwx[i] || !w.cb[i]) return ctx->fail(-22, "weights: upload failed");
     }
     GETW(pbw, "superpoint", "convPb.weight", 65 * 256);
     GETW(pbb, "superpoint", "convPb.bias", 65);
@@ -390,11 +391,16 @@ int im_superpoint_forward(im_ctx* ctx, const uint8_t* d_img, int n_images, int h
     hipStream_t s = (hipStream_t)stream;
     const SuperPointW& W = ctx->sp;
     const int B = n_images, K = ctx->max_kpts;
-    // 3x3 layers run in Winograd F(2x2,3x3) form (conv_wino.hip); IM_CONV_DIRECT=1 selects the direct implicit GEMM
-    // (read per call, not cached: the parity tests run both forms in one process; a captured graph keeps the form it was captured with)
+    // 3x3 layers run in Winograd F(2x2,3x3) form with the products on the bf16 matrix cores (conv_wino.hip BX, six bf16 products per fp32
+    // product); IM_CONV_F32=1 selects the same form on the f32-input MFMA (rounds 2-5; read by launch_conv3x3_wino), IM_CONV_DIRECT=1 the direct
+    // implicit GEMM (read per call, not cached: the parity tests run all forms in one process; a captured graph keeps the form it was captured with)
     const char* const direct_env = getenv("IM_CONV_DIRECT");
     const bool direct = direct_env && direct_env[0] == '1';
-    auto conv = [&](ConvArgs& a, int layer) { a.w = direct ? W.cw[layer] : W.cww[layer]; return direct ? launch_conv3x3(a, s) : launch_conv3x3_wino(a, s); };
+    auto conv = [&](ConvArgs& a, int layer) {
+        a.w = direct ? W.cw[layer] : W.cww[layer];
+        a.wx = W.cwx[layer];
+        return direct ? launch_conv3x3(a, s) : launch_conv3x3_wino(a, s);
+    };
     // conv1a is fused into conv1b's patch producer: the full-resolution 64-channel activation never touches HBM
     float* src = nullptr;
     float* dst = ws->act1;

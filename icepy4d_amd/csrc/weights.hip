@@ -37,6 +37,43 @@ std::vector<float> pack_conv3x3_wino(const float* w, int cout, int cin) {
     return p;
 }
 
+// The same U values (pack_conv3x3_wino's: evaluated in double, rounded once to fp32) cut into three bf16 planes, x = h + m + l with
+// h = bf16(x), m = bf16(x - h), l = bf16(x - h - m) (round to nearest even each), in the fragment order of v_mfma_f32_32x32x16_bf16's B
+// operand: [cin / 16][pos][cout / 32][plane][lane = (cin % 16 / 8) * 32 + cout % 32][cin % 8] bf16 - one plane of one (position, 32 output
+// channels, 16 input channels) fragment is 1 KB, lane-linear 16 bytes per lane. Returned as floats holding the bytes (for im_ctx::upload).
+static uint16_t wx_bf16(float x) {
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static float wx_f32(uint16_t h) {
+    const uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+std::vector<float> pack_conv3x3_wino_bx(const float* w, int cout, int cin) {
+    const std::vector<float> u = pack_conv3x3_wino(w, cout, cin);      // [cin/8][16][cout][8]
+    const size_t n16 = (size_t)cin * 16 * cout * 3;
+    std::vector<float> out((n16 + 1) / 2);
+    uint16_t* p = reinterpret_cast<uint16_t*>(out.data());
+    const int nct = cout / 32;
+    for (int ci = 0; ci < cin; ++ci)
+        for (int pos = 0; pos < 16; ++pos)
+            for (int co = 0; co < cout; ++co) {
+                const float x = u[(((size_t)(ci / 8) * 16 + pos) * cout + co) * 8 + (ci % 8)];
+                const uint16_t h = wx_bf16(x);
+                const float r1 = x - wx_f32(h);
+                const uint16_t m = wx_bf16(r1);
+                const uint16_t l = wx_bf16(r1 - wx_f32(m));
+                const int lane = ((ci % 16) / 8) * 32 + (co % 32);
+                const size_t base = ((((size_t)(ci / 16) * 16 + pos) * nct + co / 32) * 3) * 512 + (size_t)lane * 8 + (ci % 8);
+                p[base] = h; p[base + 512] = m; p[base + 1024] = l;
+            }
+    return out;
+}
+
 }  // namespace im
 
 // ------------------------------------------------------------------------------------------------ IM_DEBUG_GUARDS
