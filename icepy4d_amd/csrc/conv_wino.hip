@@ -162,7 +162,12 @@ __device__ __forceinline__ void dma16(wu32x4 rsrc, unsigned lds_byte_addr, unsig
 // 8 hh .. 8 hh + 7 of a 16-channel chunk).
 typedef __bf16 wbf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 wbf16x2 __attribute__((ext_vector_type(2)));
+// -DIM_XABL_*: timing-only ablations of the BX main loop (WRONG results by construction; tools/build_conv_variant.sh builds them into build_abl/)
 __device__ __forceinline__ f32x16 mfma_bx(wu32x4 a, wu32x4 b, f32x16 c) {
+#ifdef IM_XABL_NO_MFMA
+    c[0] += __uint_as_float(a.x ^ b.x);      // keeps the operands alive: one vector instruction instead of the MFMA
+    return c;
+#endif
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wbf16x8, a), __builtin_bit_cast(wbf16x8, b), c, 0, 0, 0);
 }
 __device__ __forceinline__ unsigned wcvt_pk(float a, float b) {
@@ -170,6 +175,10 @@ __device__ __forceinline__ unsigned wcvt_pk(float a, float b) {
     return __builtin_bit_cast(unsigned, v);
 }
 __device__ __forceinline__ void wsplit2(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
+#ifdef IM_XABL_NO_CUT
+    h = __float_as_uint(a); m = __float_as_uint(b); l = h ^ m;
+    return;
+#endif
     h = wcvt_pk(a, b);
     float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
     m = wcvt_pk(ra, rb);
@@ -184,6 +193,13 @@ __device__ __forceinline__ WPlanes wsplit8(const float (&x)[8]) {
     for (int i = 0; i < 4; ++i) wsplit2(x[2 * i], x[2 * i + 1], h[i], m[i], l[i]);
     return WPlanes{wu32x4{h[0], h[1], h[2], h[3]}, wu32x4{m[0], m[1], m[2], m[3]}, wu32x4{l[0], l[1], l[2], l[3]}};
 }
+#ifdef IM_XABL_ONE_U          // every step reads the same 3 KB fragment of its wave (L1-resident): what is the L2 stream of the U planes worth?
+#define IM_XABL_U_OFFSET(x) (ux_base + 0u * (x))
+#elif defined(IM_XABL_NO_U)   // beyond the descriptor's range: zeros, no traffic
+#define IM_XABL_U_OFFSET(x) (0u * (x))
+#else
+#define IM_XABL_U_OFFSET(x) (x)
+#endif
 static constexpr int X_RING = 4;                     // register slots of U fragments (one (position, 32 output channels) fragment = 3 planes x 4 registers)
 static constexpr int X_AHEAD = X_RING - 1;           // fragments requested ahead of the one in use
 
@@ -395,29 +411,53 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
         const int nchunk = a.Cin / 16;
         const unsigned ux_pos = (unsigned)(a.Cout / 32) * 3072u, ux_chunk = 16u * ux_pos;
         const __amdgpu_buffer_rsrc_t rux = wmake_rsrc(a.wx, (unsigned)nchunk * ux_chunk);
+#ifdef IM_XABL_NO_U
+        const unsigned ux_voff = 0x80000000u + (unsigned)lane * 16u;
+#else
         const unsigned ux_voff = (unsigned)lane * 16u;
+#endif
         const unsigned ux_base = (unsigned)(4 * ph) * ux_pos + (unsigned)(co0 / 32) * 3072u;
         const int x_slotA = 2 * hh * S_QUAD + (2 * t_ty + rowA) * S_ROW + t_tx, x_slotB = 2 * hh * S_QUAD + (2 * t_ty + rowB) * S_ROW + t_tx;
         wu32x4 ur[X_RING][3];
-#define IM_XULOAD(slot, chunk, s)                                                                        \
+#define IM_XULOAD(slot, cbase, nbase, nvoff, s)   /* cbase / nbase: byte offsets of this chunk's and the next chunk's U planes; nvoff: the lane offset for the next chunk's */ \
         {                                                                                                \
-            const unsigned so_ = (unsigned)((chunk) + ((s) >> 3)) * ux_chunk + ux_base + (unsigned)(((s) >> 1) & 3) * ux_pos + (unsigned)((s) & 1) * 3072u; \
+            const unsigned so_ = IM_XABL_U_OFFSET((((s) >> 3) ? (nbase) : (cbase)) + ux_base + (unsigned)(((s) >> 1) & 3) * ux_pos + (unsigned)((s) & 1) * 3072u); \
+            const unsigned vo_ = ((s) >> 3) ? (nvoff) : ux_voff;                                         \
             _Pragma("unroll") for (int pl_ = 0; pl_ < 3; ++pl_)                                            \
-                ur[slot][pl_] = __builtin_amdgcn_raw_buffer_load_b128(rux, ux_voff + pl_ * 1024u, so_, 0); \
+                ur[slot][pl_] = __builtin_amdgcn_raw_buffer_load_b128(rux, vo_ + pl_ * 1024u, so_, 0);   \
         }
-        auto xstage = [&](int chunk) {       // the patch of `chunk` (four channel quads) into stage chunk & 1
-            if (tid < S_QUAD) {
-                const unsigned pb_ = lds_sP + ((chunk & 1) * X_SP + wave * 256) * 4u;
+        // IM_XROT (experiment): the blocks walk the input-channel chunks in rotated orders (by tile position), so that the CUs of an XCD do not all
+        // ask its L2 for the same few KB of U at the same time
+#ifdef IM_XROT
+        const int rot = rtile % nchunk;
+#else
+        const int rot = 0;
+#endif
+        auto cc_of = [&](int it) { const int c_ = it + rot; return c_ >= nchunk ? c_ - nchunk : c_; };
+        auto xstage = [&](int it) {       // the patch of iteration it's chunk (four channel quads) into stage it & 1
+            const int chunk = cc_of(it);
+#ifdef IM_XABL_NO_PATCH
+            if (tid > 12345)
+#else
+            if (tid < S_QUAD)
+#endif
+            {
+                const unsigned pb_ = lds_sP + ((it & 1) * X_SP + wave * 256) * 4u;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) dma16(rin, pb_ + q * (S_QUAD * 16u), pv, chunk * 64u + q * 16u);
             }
         };
-        auto xchunk = [&](int chunk, auto FIRST_) {
+        auto xchunk = [&](int it, auto FIRST_) {
             constexpr bool FIRST = decltype(FIRST_)::value;
-            const bool more = chunk + 1 < nchunk;                                   // uniform
-            if constexpr (!RESIDENT) { if (more) xstage(chunk + 1); }
+            const bool more = it + 1 < nchunk;                                   // uniform
+            const int chunk = cc_of(it);
+            // past the last chunk the requests go out of range through the LANE offset (>= the descriptor's record count whatever the scalar offset
+            // is: zeros, no traffic; the hardware's check is `lane offset >= records - scalar offset`, whose right side must not wrap)
+            const unsigned cbase = (unsigned)chunk * ux_chunk, nbase = more ? (unsigned)cc_of(it + 1) * ux_chunk : 0u;
+            const unsigned nvoff = more ? ux_voff : 0x80000000u;
+            if constexpr (!RESIDENT) { if (more) xstage(it + 1); }
             const float4* pa = RESIDENT ? reinterpret_cast<const float4*>(smem) + chunk * (4 * S_QUAD)
-                                        : reinterpret_cast<const float4*>(sP + (chunk & 1) * X_SP);
+                                        : reinterpret_cast<const float4*>(sP + (it & 1) * X_SP);
             float v[4][8];
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
@@ -454,7 +494,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
 #pragma unroll
                     for (int i = 2 * n; i < 2 * n + 2; ++i) wsplit2(v[j + 1][2 * i], v[j + 1][2 * i + 1], ph_[cur ^ 1][i], pm_[cur ^ 1][i], pl_[cur ^ 1][i]);
                 }
-                IM_XULOAD((s + X_AHEAD) % X_RING, chunk, s + X_AHEAD)      // past the last chunk: beyond the descriptor's range, i.e. zeros and no traffic
+                IM_XULOAD((s + X_AHEAD) % X_RING, cbase, nbase, nvoff, s + X_AHEAD)
                 __builtin_amdgcn_sched_barrier(0);
             }
             if constexpr (!RESIDENT) {
@@ -466,7 +506,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
             }
         };
 #pragma unroll
-        for (int s = 0; s < X_AHEAD; ++s) IM_XULOAD(s, 0, s)
+        for (int s = 0; s < X_AHEAD; ++s) IM_XULOAD(s, (unsigned)cc_of(0) * ux_chunk, 0u, ux_voff, s)
         if constexpr (!RESIDENT) {
             xstage(0);
             IM_DMA_WAIT();
@@ -530,6 +570,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
 #undef IM_SDB
 #undef IM_SMMA
 
+#ifdef IM_XABL_NO_EPI
+    if constexpr (BX) {
+        float keep_ = 0.f;
+#pragma unroll
+        for (int p_ = 0; p_ < 8; ++p_) keep_ += acc[p_][0] + acc[p_][15];
+        if (keep_ == 12345.678f) a.out[0] = keep_;
+        return;
+    }
+#endif
     // ---- inverse transform Y = A^T M A. acc[2 j + n]: position (ph, j), output channels n * 32 + c. Pass over j in registers:
     //   s_ph[0] = (M0 + M1) + M2,  s_ph[1] = (M1 - M2) - M3;   then over the four V rows = the four waves:
     //   Y[0][b] = (s0[b] + s1[b]) + s2[b],   Y[1][b] = s1[b] - (s2[b] + s3[b])       (the associations of the two-row form: same bits)

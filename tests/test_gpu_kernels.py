@@ -120,10 +120,16 @@ def test_conv3x3(ctx, cin, cout, h, w, pool, relu):
                                                    # a row below the image alone exceeds the descriptor's record count there - these must take the
                                                    # compared-store path and leave the second image and the NaN fill around it alone
                                                    (64, 64, 2, 32, 0), (128, 128, 4, 48, 0), (64, 128, 6, 32, 0), (64, 64, 6, 64, 1), (64, 64, 4, 32, 1)])
-def test_conv3x3_winograd(ctx, cin, cout, h, w, pool, relu):
+@pytest.mark.parametrize("form", ["bf16x6", "f32"])
+def test_conv3x3_winograd(ctx, cin, cout, h, w, pool, relu, form, monkeypatch):
     """Winograd F(2x2, 3x3) on the matrix cores against an fp64 direct convolution; its rounding error is a few 1e-6
-    on O(1) outputs (the direct kernel is ~1e-6), far inside the 1e-4 budget of the path."""
+    on O(1) outputs (the direct kernel is ~1e-6), far inside the 1e-4 budget of the path. Both forms of the sixteen products: six bf16
+    products per fp32 product on the bf16 matrix cores (the product kernel since round 6) and the f32-input MFMA (`IM_CONV_F32=1`)."""
     from icepy4d_amd._lib import ptr, stream_ptr
+    if form == "f32":
+        monkeypatch.setenv("IM_CONV_F32", "1")
+    else:
+        monkeypatch.delenv("IM_CONV_F32", raising=False)
     g = torch.Generator().manual_seed(cin + cout + h)
     x = torch.randn(2, cin, h, w, generator=g)
     wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5

@@ -56,14 +56,17 @@ def assert_exact_or_explained(rep):
         assert e2e["pairs_device"] <= e2e["pairs_oracle"] + 4 * max(flips, 1), e2e
 
 
-@pytest.fixture(params=["winograd", "direct"])
+@pytest.fixture(params=["winograd", "winograd_f32", "direct"])
 def conv_form(request, monkeypatch):
-    """Both forms of the 3x3 convolutions stay under the same parity bar: Winograd F(2x2, 3x3) (the default) and the direct
-    implicit GEMM (`IM_CONV_DIRECT=1`, read by the library at every SuperPoint call)."""
+    """All three forms of the 3x3 convolutions stay under the same parity bar: Winograd F(2x2, 3x3) with its products on the bf16 matrix
+    cores (six bf16 products per fp32 product: the default since round 6), the same on the f32-input MFMA (`IM_CONV_F32=1`, rounds 2-5)
+    and the direct implicit GEMM (`IM_CONV_DIRECT=1`); both switches are read by the library at every SuperPoint call."""
+    monkeypatch.delenv("IM_CONV_DIRECT", raising=False)
+    monkeypatch.delenv("IM_CONV_F32", raising=False)
     if request.param == "direct":
         monkeypatch.setenv("IM_CONV_DIRECT", "1")
-    else:
-        monkeypatch.delenv("IM_CONV_DIRECT", raising=False)
+    elif request.param == "winograd_f32":
+        monkeypatch.setenv("IM_CONV_F32", "1")
     return request.param
 
 
