@@ -119,6 +119,8 @@ hipError_t launch_conv3x3(const ConvArgs& a, hipStream_t s);
 // Winograd F(2x2, 3x3) variant (conv_wino.hip); a.w = weights packed by pack_conv3x3_wino: [Cin / 8][16][Cout][8] and / or
 // a.wx = the same as bf16 planes (pack_conv3x3_wino_bx): [Cin / 16][16][Cout / 32][3][64][8] bf16
 hipError_t launch_conv3x3_wino(const ConvArgs& a, hipStream_t s);
+// the same layer (plain: no fused first layer), bf16 planes, eight waves per block with the U planes shared by two tile groups (conv_wino_bx2.hip)
+hipError_t launch_conv3x3_wino_bx2(const ConvArgs& a, hipStream_t s);
 // conv1a: u8 gray [B][H][W] -> (x / 255) * w + b, ReLU -> NHWC [B][H][W][64]; w packed [9][64]
 hipError_t launch_conv1a(const uint8_t* img, int channels, int gray_mode, const float* w, const float* bias, float* out, int B, int H,
                          int W, hipStream_t s);
