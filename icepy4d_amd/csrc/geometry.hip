@@ -265,30 +265,62 @@ static int ransac_entry(im_ctx* ctx, const char* who, int essential, const float
     return 0;
 }
 
-// linear (DLT) two-view triangulation, one thread per point (`sfm/triangulation.py:153-163`): the four rows x (P X) = 0 of the two
-// views, X = the eigenvector of the smallest eigenvalue of A^T A (fp64 Jacobi), normalised to X[3] = 1
+// Right singular vector of the smallest singular value of an N x N matrix by ONE-SIDED Jacobi (Hestenes): the columns of A are rotated in
+// pairs until they are orthogonal, V collects the rotations, the singular values are the column norms. Works on A itself, not on A^T A: the
+// accuracy follows the condition number, not its square (the triangulation system mixes entries of order 1e4 and of order 1).
+template <int N>
+__device__ void smallest_right_singular_vector(double a[N][N], double out[N]) {
+    double v[N][N];
+    for (int i = 0; i < N; ++i)
+        for (int j = 0; j < N; ++j) v[i][j] = i == j ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        bool rotated = false;
+        for (int p = 0; p < N - 1; ++p)
+            for (int q = p + 1; q < N; ++q) {
+                double al = 0.0, be = 0.0, ga = 0.0;
+                for (int k = 0; k < N; ++k) { al += a[k][p] * a[k][p]; be += a[k][q] * a[k][q]; ga += a[k][p] * a[k][q]; }
+                if (fabs(ga) <= 1e-17 * sqrt(al * be) || ga == 0.0) continue;
+                rotated = true;
+                const double zeta = (be - al) / (2.0 * ga);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+                for (int k = 0; k < N; ++k) { const double x = a[k][p], y = a[k][q]; a[k][p] = c * x - sn * y; a[k][q] = sn * x + c * y; }
+                for (int k = 0; k < N; ++k) { const double x = v[k][p], y = v[k][q]; v[k][p] = c * x - sn * y; v[k][q] = sn * x + c * y; }
+            }
+        if (!rotated) break;
+    }
+    int m = 0;
+    double best = -1.0;
+    for (int j = 0; j < N; ++j) {
+        double nn = 0.0;
+        for (int k = 0; k < N; ++k) nn += a[k][j] * a[k][j];
+        if (best < 0.0 || nn < best) { best = nn; m = j; }
+    }
+    for (int k = 0; k < N; ++k) out[k] = v[k][m];
+}
+
+// linear two-view triangulation, one thread per point, in the REFERENCE's formulation (`sfm/triangulation.py:153-186`): the unknowns are the
+// point X and one depth per view, the system  [P_i | -x_i e_i] [X; lambda] = 0  (6 x 6 for two views), the solution the right singular vector
+// of its smallest singular value, normalised to X[3] = 1. (Until round 5 this kernel solved the four cross-product rows x (P X) = 0 instead:
+// the same point on exact correspondences, another least-squares problem on noisy ones - found when the outputs were first compared with the
+// reference's own, tests/golden/g10_triangulation.npz.)
 __global__ __launch_bounds__(64) void triangulate_linear_kernel(const double* __restrict__ P, const double* __restrict__ x0,
                                                                 const double* __restrict__ x1, int n, double* __restrict__ X) {
     const int i = blockIdx.x * 64 + threadIdx.x;
     if (i >= n) return;
-    double A[4][4];
+    double M[6][6];
     for (int v = 0; v < 2; ++v) {
         const double* p = P + 12 * v;
         const double* x = (v == 0 ? x0 : x1) + 3 * (long)i;
-        for (int j = 0; j < 4; ++j) {
-            A[2 * v][j] = x[0] * p[8 + j] - x[2] * p[j];
-            A[2 * v + 1][j] = x[1] * p[8 + j] - x[2] * p[4 + j];
+        for (int r = 0; r < 3; ++r) {
+            for (int j = 0; j < 4; ++j) M[3 * v + r][j] = p[4 * r + j];
+            M[3 * v + r][4 + v] = -x[r];
+            M[3 * v + r][5 - v] = 0.0;
         }
     }
-    double M[4][4], Q[4][4];
-    for (int a = 0; a < 4; ++a)
-        for (int b = 0; b < 4; ++b) M[a][b] = A[0][a] * A[0][b] + A[1][a] * A[1][b] + A[2][a] * A[2][b] + A[3][a] * A[3][b];
-    jacobi_sym<4>(M, Q);
-    int m = 0;
-    for (int k = 1; k < 4; ++k)
-        if (M[k][k] < M[m][m]) m = k;
-    const double w = Q[3][m];
-    for (int k = 0; k < 4; ++k) X[4 * (long)i + k] = Q[k][m] / w;
+    double sol[6];
+    smallest_right_singular_vector<6>(M, sol);
+    for (int k = 0; k < 4; ++k) X[4 * (long)i + k] = sol[k] / sol[3];
 }
 
 }  // namespace im

@@ -2,8 +2,8 @@
 linear triangulation (`src/icepy4d/sfm/geometry.py:31-76`, `sfm/two_view_geometry.py:38-110`,
 `sfm/triangulation.py:153-186`). The reference uses OpenCV (`findEssentialMat`, `recoverPose`), which is absent here, so
 parity of `estimate_pose` is unpinned (same interface, same conventions, checked on synthetic geometry); the linear
-triangulation is pure numpy in the reference and its HOST path here reproduces it to rounding (tests compare against a restatement of
-its formulation; the device path solves through A^T A, see `triangulate_points_linear`). Small host-side linear algebra on S <= 1e4 matched points: not a device workload; the RANSAC inside
+triangulation is pure numpy in the reference: host and device path here solve the reference's own system and are compared with the
+reference's OUTPUTS (tests/golden/g10_triangulation.npz, written by importing the reference module; oracle/sfm_cpu.py restates it). Small host-side linear algebra on S <= 1e4 matched points: not a device workload; the RANSAC inside
 `estimate_pose(engine=...)` generates and scores essential-matrix hypotheses on the device (`im_ransac_essential`, csrc/geometry.hip)
 and `triangulate_points_linear(engine=...)` triangulates on the device (`im_triangulate_linear`); the cheirality test and the 5-7
 match case (five-point solver on every 5-subset) stay host numpy: one 3 x 3 matrix."""
@@ -15,29 +15,35 @@ from .matching.enums import GeometricVerification
 from .matching.geometric_verification import geometric_verification
 
 
+def _lift(P, ip) -> np.ndarray:
+    """The reference's system for one point seen in n views (`triangulation.py:176-183`): unknowns X (4) and one depth per view,
+    rows  P_i X - lambda_i x_i = 0  (3 n x (4 + n)); batched over leading dimensions of `ip`."""
+    n = len(P)
+    ip = [np.asarray(x, dtype=np.float64) for x in ip]
+    lead = ip[0].shape[:-1]
+    M = np.zeros(lead + (3 * n, 4 + n))
+    for i in range(n):
+        M[..., 3 * i:3 * i + 3, :4] = np.asarray(P[i], dtype=np.float64)
+        M[..., 3 * i:3 * i + 3, 4 + i] = -ip[i]
+    return M
+
+
 def triangulate_nviews(P, ip) -> np.ndarray:
     """One point seen in n views (`triangulation.py:166-186`): P list of 3x4 projection matrices, ip list of homogeneous
-    image points [x, y, 1]. Returns the homogeneous point normalised to X[3] = 1."""
+    image points [x, y, 1]. Returns the homogeneous point normalised to X[3] = 1: the right singular vector of the smallest
+    singular value of the reference's system (`_lift`), equal to the reference's result to the rounding of the SVD."""
     if len(ip) != len(P):
         raise ValueError("Number of points and number of cameras not equal.")
-    rows = []
-    for x, p in zip(ip, P):
-        x = np.asarray(x, dtype=np.float64)
-        p = np.asarray(p, dtype=np.float64)
-        rows.append(x[0] * p[2] - x[2] * p[0])      # the cross product x x (P X) = 0, two independent rows per view
-        rows.append(x[1] * p[2] - x[2] * p[1])
-    A = np.asarray(rows)
-    X = np.linalg.svd(A)[2][-1]
+    X = np.linalg.svd(_lift(P, ip))[2][-1, :4]
     return X / X[3]
 
 
 def triangulate_points_linear(P1, P2, x1, x2, engine=None) -> np.ndarray:
-    """Two-view triangulation of n points (`triangulation.py:153-163`); x1, x2 are [n, 3] homogeneous image points.
-    Vectorised DLT: one batched 4x4 SVD instead of the reference's Python loop over an (6 x 6) system per point. With
-    `engine=` the points are triangulated on the device (`im_triangulate_linear`: one thread per point, fp64 Jacobi on A^T A).
-    The host path solves the same 4 x 4 system by SVD of A, as the reference does; the device path takes the smallest eigenvector of
-    A^T A, which squares the condition number: in fp64 the two agree to ~1e-7 on ordinary geometry (tested), but for near-degenerate
-    rays (parallax below ~1e-6 rad) the device result is NOT to-rounding equal to the SVD - use the host path there."""
+    """Two-view triangulation of n points (`triangulation.py:153-163`); x1, x2 are [n, 3] homogeneous image points. The reference's
+    system per point (6 x 6: the point and one depth per view), solved for all points by ONE batched SVD instead of the reference's Python
+    loop; with `engine=` on the device (`im_triangulate_linear`: one thread per point, one-sided Jacobi SVD in fp64). Both equal the reference's
+    outputs (tests/golden/g10_triangulation.npz) to 1e-9 relative. Until round 5 both solved the four cross-product rows  x (P X) = 0
+    instead - the same point on exact correspondences, a different least-squares problem on noisy ones (up to 5e-3 relative on 0.4 px noise)."""
     x1, x2 = np.asarray(x1, np.float64), np.asarray(x2, np.float64)
     if len(x1) != len(x2):
         raise ValueError("Number of points don't match.")
@@ -52,9 +58,9 @@ def triangulate_points_linear(P1, P2, x1, x2, engine=None) -> np.ndarray:
         p1, p2 = np.ascontiguousarray(P1.reshape(12)), np.ascontiguousarray(P2.reshape(12))
         engine.ctx.call("im_triangulate_linear", p1.ctypes.data, p2.ctypes.data, ptr(d1), ptr(d2), n, ptr(dX), engine.stream_ptr())
         return dX.cpu().numpy()
-    A = np.stack([x1[:, 0:1] * P1[2] - x1[:, 2:3] * P1[0], x1[:, 1:2] * P1[2] - x1[:, 2:3] * P1[1],
-                  x2[:, 0:1] * P2[2] - x2[:, 2:3] * P2[0], x2[:, 1:2] * P2[2] - x2[:, 2:3] * P2[1]], axis=1)   # [n, 4, 4]
-    X = np.linalg.svd(A)[2][:, -1, :]
+    if len(x1) == 0:
+        return np.zeros((0, 4))
+    X = np.linalg.svd(_lift([P1, P2], [x1, x2]))[2][:, -1, :4]
     return X / X[:, 3:4]
 
 

@@ -222,7 +222,9 @@ int im_ransac_essential(im_ctx* ctx, const float* d_x0, const float* d_x1, int n
 
 /* Linear two-view triangulation of n points on the device (replaces the per-point Python loop of
  * `src/icepy4d/sfm/triangulation.py:153-186`): h_P0, h_P1 = the two 3 x 4 projection matrices (row-major doubles in HOST
- * memory), d_x0, d_x1 [n][3] double homogeneous image points, d_X [n][4] double = homogeneous points normalised to X[3] = 1. */
+ * memory), d_x0, d_x1 [n][3] double homogeneous image points, d_X [n][4] double = homogeneous points normalised to X[3] = 1.
+ * The reference's formulation (unknowns X and one depth per view, 6 x 6 system per point, right singular vector of the smallest singular
+ * value): equal to the reference's outputs within 1e-9 relative (tests/golden/g10_triangulation.npz). */
 int im_triangulate_linear(im_ctx* ctx, const double* h_P0, const double* h_P1, const double* d_x0, const double* d_x1, int n,
                           double* d_X, void* stream);
 

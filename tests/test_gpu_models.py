@@ -1134,9 +1134,13 @@ def test_relative_orientation_and_triangulation_on_device():
         P0, P1 = K @ np.eye(3, 4), K @ np.c_[R, t]
         h0, h1 = np.c_[k0, np.ones(n)], np.c_[k1, np.ones(n)]
         Xd = sfm.triangulate_points_linear(P0, P1, h0, h1, engine=e)
-        Xh = sfm.triangulate_points_linear(P0, P1, h0, h1)
-        assert Xd.shape == (n, 4) and np.abs(Xd[n_out:] - Xh[n_out:]).max() < 1e-7 * np.abs(Xh[n_out:]).max()
-        assert np.median(np.linalg.norm(Xd[n_out:, :3] - X[n_out:], axis=1)) < 0.05
+        assert Xd.shape == (n, 4) and np.median(np.linalg.norm(Xd[n_out:, :3] - X[n_out:], axis=1)) < 0.05
+    # `im_triangulate_linear` against the REFERENCE's own outputs (G10: `sfm/triangulation.py:153-186` imported by tools/gen_golden.py on seeded
+    # cameras and 500 noisy correspondences), not against the product's host path: the device solves through A^T A in fp64 (one thread per point)
+    g10 = load_golden("g10_triangulation")
+    Xd = sfm.triangulate_points_linear(g10["P0"], g10["P1"], g10["x0"], g10["x1"], engine=e)
+    assert Xd.shape == g10["X_two_views"].shape
+    assert np.abs(Xd - g10["X_two_views"]).max() <= 1e-9 * np.abs(g10["X_two_views"]).max(), np.abs(Xd - g10["X_two_views"]).max()
     # the reference's own tests: None below five matches, a pose for five (host five-point solver: below the 8 of a device hypothesis)
     assert sfm.estimate_pose(np.array([[0, 0], [0, 1]]), np.array([[0, 0], [0, 1]]), np.eye(3), np.eye(3), 0.5, 0.9999, engine=e) is None
     kpts0 = np.array([[1853, 2632], [2122, 2744], [416, 2867], [1880, 2582], [2100, 2770]]).astype(np.float32)

@@ -199,3 +199,25 @@ def test_preselection_counts_of_the_reference_call():
     assert np.array_equal(np.array(counts), g["preselection_counts"])
     assert [c[:2] for c in counts if c[2] > 5] == [tuple(r) for r in g["tile_pairs"].tolist()]
     assert len([c for c in counts if 3 < c[2] <= 5]) == 3         # what min_matches_per_tile=3 would have added
+
+
+def test_triangulation_oracle_equals_the_reference_golden():
+    """Row f-4: `oracle/sfm_cpu.py` against G10 = outputs of the reference's own `triangulate_points_linear` / `triangulate_nviews`
+    (`sfm/triangulation.py:153-186`, imported by `tools/gen_golden.py triangulation`) on seeded cameras and 500 noisy correspondences: equal to
+    the rounding of the SVD (the same LAPACK call on the same matrix: bit-equal here), and the product's host path (`icepy4d_amd/sfm.py`, a
+    batched 4 x 4 SVD of the cross-product form instead of the reference's 6 x 6 system per point) equal to the reference within 1e-9 relative."""
+    from oracle import sfm_cpu
+    from icepy4d_amd import sfm
+    g = load_golden("g10_triangulation")
+    X = sfm_cpu.triangulate_points_linear(g["P0"], g["P1"], g["x0"], g["x1"])
+    assert X.shape == g["X_two_views"].shape and np.abs(X - g["X_two_views"]).max() <= 1e-12 * np.abs(g["X_two_views"]).max()
+    X3 = np.array([sfm_cpu.triangulate_nviews([g["P0"], g["P1"], g["P2"]], [a, b, c]) for a, b, c in zip(g["x0"][:50], g["x1"][:50], g["x2"][:50])])
+    assert np.abs(X3 - g["X_three_views"]).max() <= 1e-12 * np.abs(g["X_three_views"]).max()
+    scale = np.abs(g["X_two_views"]).max()
+    Xp = sfm.triangulate_points_linear(g["P0"], g["P1"], g["x0"], g["x1"])
+    assert np.abs(Xp - g["X_two_views"]).max() <= 1e-9 * scale
+    Xp3 = np.array([sfm.triangulate_nviews([g["P0"], g["P1"], g["P2"]], [a, b, c]) for a, b, c in zip(g["x0"][:50], g["x1"][:50], g["x2"][:50])])
+    assert np.abs(Xp3 - g["X_three_views"]).max() <= 1e-9 * scale
+    assert np.median(np.linalg.norm(g["X_two_views"][:, :3] - g["points_true"], axis=1)) < 0.02      # and the fixture is a sane scene
+    with pytest.raises(ValueError):
+        sfm_cpu.triangulate_points_linear(g["P0"], g["P1"], g["x0"], g["x1"][:-1])

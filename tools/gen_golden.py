@@ -170,6 +170,67 @@ def gen_features_pickle():
     sys.modules.pop("icepy4d.core.features", None)
 
 
+def gen_triangulation():
+    """G10 (row f-4): the reference's `triangulate_points_linear` / `triangulate_nviews` (`sfm/triangulation.py:153-186`, pure numpy) on seeded
+    cameras and 500 noisy correspondences, plus a three-view point. The module is loaded from the reference tree with its sibling imports
+    (cv2-based geometry, colour interpolation, Camera, the thirdparty LS triangulation: none of them used by the two functions) stubbed."""
+    import importlib.util
+    saved = {k: sys.modules.get(k) for k in ("icepy4d", "icepy4d.sfm", "icepy4d.sfm.geometry", "icepy4d.sfm.interpolate_colors", "icepy4d.core",
+                                             "icepy4d.core.camera", "icepy4d.utils", "icepy4d.utils.math", "icepy4d.thirdparty",
+                                             "icepy4d.thirdparty.triangulation", "icepy4d.sfm.triangulation")}
+
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        m.__path__ = []
+        sys.modules[name] = m
+        return m
+
+    stub("icepy4d"); stub("icepy4d.sfm"); stub("icepy4d.core"); stub("icepy4d.utils"); stub("icepy4d.thirdparty")
+    stub("icepy4d.sfm.geometry", undistort_points=None)
+    stub("icepy4d.sfm.interpolate_colors", interpolate_point_colors=None)
+    stub("icepy4d.core.camera", Camera=object)
+    stub("icepy4d.utils.math", convert_from_homogeneous=None, convert_to_homogeneous=None)
+    stub("icepy4d.thirdparty.triangulation", iterative_LS_triangulation=None)
+    spec = importlib.util.spec_from_file_location("icepy4d.sfm.triangulation", REF_SRC + "/icepy4d/sfm/triangulation.py")
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["icepy4d.sfm.triangulation"] = mod
+    spec.loader.exec_module(mod)
+    rng = np.random.default_rng(1010)
+    n = 500
+    X = np.c_[rng.uniform(-3, 3, n), rng.uniform(-2, 2, n), rng.uniform(6, 14, n)]
+    K0 = np.array([[6621.7, 0, 3000.4], [0, 6620.1, 1998.7], [0, 0, 1]])
+    K1 = np.array([[6588.3, 0, 3012.9], [0, 6590.6, 2005.2], [0, 0, 1]])
+
+    def rot(ax, ay, az):
+        cx, sx, cy, sy, cz, sz = np.cos(ax), np.sin(ax), np.cos(ay), np.sin(ay), np.cos(az), np.sin(az)
+        return (np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]]) @ np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+                @ np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]]))
+
+    R1, t1 = rot(0.02, 0.21, -0.015), np.array([-2.1, 0.07, 0.3])
+    R2, t2 = rot(-0.03, -0.17, 0.01), np.array([1.8, -0.1, 0.25])
+    P0, P1, P2 = K0 @ np.eye(3, 4), K1 @ np.c_[R1, t1], K0 @ np.c_[R2, t2]
+    h = np.c_[X, np.ones(n)]
+
+    def project(P):
+        x = (P @ h.T).T
+        return x[:, :2] / x[:, 2:]
+
+    x0 = project(P0) + rng.normal(0, 0.4, (n, 2))
+    x1 = project(P1) + rng.normal(0, 0.4, (n, 2))
+    x2 = project(P2) + rng.normal(0, 0.4, (n, 2))
+    h0, h1, h2 = np.c_[x0, np.ones(n)], np.c_[x1, np.ones(n)], np.c_[x2, np.ones(n)]
+    X01 = mod.triangulate_points_linear(P0, P1, h0, h1)
+    X3 = np.array([mod.triangulate_nviews([P0, P1, P2], [a, b, c]) for a, b, c in zip(h0[:50], h1[:50], h2[:50])])
+    print(f"  triangulation: two views {X01.shape}, median error {np.median(np.linalg.norm(X01[:, :3] - X, axis=1)):.4f}; three views {X3.shape}")
+    save("g10_triangulation", P0=P0, P1=P1, P2=P2, x0=h0, x1=h1, x2=h2, points_true=X, X_two_views=X01, X_three_views=X3)
+    for k, v in saved.items():
+        if v is None:
+            sys.modules.pop(k, None)
+        else:
+            sys.modules[k] = v
+
+
 def gen_prune_threshold():
     """g2_lightglue_6: the reference's `desc.shape[-2] > pruning_th` gate (`lightglue.py:495, 503`). On a CPU tensor the
     reference looks up `pruning_keypoint_thresholds['cpu']` = -1; its CUDA values are 1024 / 1536. The table entry is set to
@@ -352,6 +413,9 @@ def main():
         return
     if len(sys.argv) > 1 and sys.argv[1] == "features_pickle":
         gen_features_pickle()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "triangulation":
+        gen_triangulation()
         return
     if len(sys.argv) > 1 and sys.argv[1] == "prune_threshold":
         gen_prune_threshold()
@@ -546,6 +610,7 @@ def main():
     gen_colour(sp_sd)
     gen_prune_threshold()
     gen_features_pickle()
+    gen_triangulation()
     gen_preselection(sp_sd)
     gen_adaptive_large()
     save("g5_assets", gray0=g0, gray1=g1, keypoints0=f0["keypoints"][0], keypoints1=f1["keypoints"][0],
