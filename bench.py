@@ -42,9 +42,15 @@ PEAK_ATTN_F32_EQUIVALENT_TFLOPS = PEAK_BF16_MFMA_TFLOPS / ATTN_BF16_PRODUCTS
 ATTN_F32_FORM = os.environ.get("IM_ATTN_F32", "0") not in ("", "0")   # the f32-input MFMA kernel of rounds 1-5 (csrc/attention.hip), for A/B
 ATTN_KERNEL = "im::flash_attn_f32_kernel" if ATTN_F32_FORM else "im::flash_attn_bx_kernel"
 PEAK_ATTN_TFLOPS = PEAK_F32_MFMA_TFLOPS if ATTN_F32_FORM else PEAK_ATTN_F32_EQUIVALENT_TFLOPS
-DTYPE_NOTE = ("fp32 end to end, as the reference: SuperPoint (convolutions, its 1 x 1 heads) on the f32-input MFMA; the matchers' fp32 products (attention, "
-              "feed-forward, their GEMMs) as six bf16 products each on the bf16 matrix cores with fp32 accumulation - every fp32 operand is the exact sum of "
-              "three bf16 values; error at or below the f32 MFMA chain's (profiles/r05_bf16x_probe.txt, tests/test_gpu_kernels.py)")
+CONV_F32_FORM = os.environ.get("IM_CONV_F32", "0") not in ("", "0")   # the f32-input MFMA Winograd kernel of rounds 2-5 (csrc/conv_wino.hip, !BX), for A/B
+PEAK_CONV_TFLOPS = PEAK_F32_MFMA_TFLOPS if CONV_F32_FORM else PEAK_ATTN_F32_EQUIVALENT_TFLOPS
+SPEC_CLOCK_MHZ = 2400.0        # the clock the spec peaks are quoted at (MI355X_MICROARCH.md)
+BX_ARITHMETIC = ("six bf16 products per fp32 product (v_mfma_f32_32x32x16_bf16, fp32 accumulation): every fp32 operand is the exact sum of three bf16 "
+                 "values, the products h l, l h, m m, h m, m h, h h are added small terms first")
+DTYPE_NOTE = ("fp32 end to end, as the reference. Every large contraction - SuperPoint's 3 x 3 convolutions (Winograd F(2x2, 3x3), since round 6) and the "
+              "matchers' attention, feed-forward and K = 256 / score GEMMs (since round 5) - computes each fp32 product as six bf16 products on the bf16 "
+              "matrix cores with fp32 accumulation (every fp32 operand is the exact sum of three bf16 values; error at or below the f32-input MFMA chain's: "
+              "profiles/r05_bf16x_probe.txt, profiles/r06_bf16_stress.txt, tests/test_gpu_bf16_stress.py); SuperPoint's 1 x 1 heads stay on the f32-input MFMA")
 PEAK_HBM_GBS = 8000.0          # same guide: HBM3E spec peak (6.3 TB/s is what a copy kernel reaches)
 # Pairs per launch of the timed region (`--batch`): the batch dimension over pairs inside the kernels. Measured on one MI355X with two
 # launch groups in flight (round 3, three boxes): 2 -> 105.8, 4 -> 107.3, 5 -> 107.5, 8 -> 108.1, 10 -> 107.0-108 (the maximum on every box),
@@ -365,13 +371,14 @@ def main():
                     + ", SuperPoint (4096 kpts, nms 4) + LightGlue (9 layers, CPU-path semantics: pruning evaluated every layer), "
                       "seeded weights; epochs sharded round-robin, one all-gather of match tables at the end")
     result = {
-        "metric": metric, "value": n_pairs / dt, "unit": "pairs/s",
+        "metric": metric, "value": len(ok_rows) / dt, "unit": "pairs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "dtype_note": DTYPE_NOTE, "data": "synthetic",
         "config": {"workload": workload, "height": h, "width": w, "max_keypoints": kpts, "pairs_per_step": 1,
                    "pair_synthesis": args.pairs if not cfg5 else "translated", "hip_graph": not args.no_graph,
                    "launch_groups_in_flight": n_streams, "pairs_per_launch": args.batch,
-                   "attention": "fp32 MFMA",
+                   "attention": ("f32-input MFMA (IM_ATTN_F32=1)" if ATTN_F32_FORM else BX_ARITHMETIC),
+                   "convolutions": "Winograd F(2x2, 3x3), " + ("f32-input MFMA (IM_CONV_F32=1)" if CONV_F32_FORM else BX_ARITHMETIC),
                    "mean_keypoints": n0, "mean_matches": nm},
         "host_enqueue_ms_per_step": 1e3 * t_enq / args.steps, "untimed_pairs_before_timing": warm_pairs,
         "all_gather_ms": 1e3 * t_gather,
@@ -382,7 +389,7 @@ def main():
     }
     if failed_epochs:
         result["failed_epochs_note"] = (f"{len(failed_epochs)} of the {n_pairs} timed pairs have a record with n_matches = -1 (this rank's own: "
-                                        f"{sm.failed}); they are counted in `value` as steps, not as matched pairs")
+                                        f"{sm.failed}); `value` counts the {len(ok_rows)} matched pairs only, `ms_per_step` all {n_pairs} steps")
     if ranks is not None:
         result["ranks"] = ranks
 
@@ -446,9 +453,15 @@ def main():
         result["side_measurements"]["seconds_spent"] = round(time.perf_counter() - t_side, 1)
 
     if rank == 0:
-        # ---- roofline of the dominant kernel: HIP events around every launch (library-side, on the launch stream)
+        # ---- roofline of the dominant kernel: HIP events around every launch (library-side, on the launch stream); during the same isolated pass the
+        # two matrix-core kernel classes report the shader clock they hold inside their main loops (im_debug_clock_probe: cycles / 100 MHz reference ticks)
         prof_steps = 1 if cfg5 else 4
+        clocks = (ctypes.c_double * 4)()
+        eng0 = sm.slots[0][0]
+        eng0.ctx.call("im_debug_clock_probe", 1, None, eng0.stream_ptr())
         prof, ev_overhead_ms = event_profile(sm.slots[0], pool, epochs, scratch, 1 if cfg5 else 3, prof_steps)
+        eng0.ctx.call("im_debug_clock_probe", 0, clocks, eng0.stream_ptr())
+        clock_mhz = {"attention": clocks[0] if clocks[1] > 0 else None, "convolutions": clocks[2] if clocks[3] > 0 else None}
         tot = sum(v["total_ms"] for v in prof.values())
         try:
             with open(TRAFFIC_FILE) as fh:
@@ -458,69 +471,69 @@ def main():
         how = ("HIP events around each launch, minus the duration of an empty event pair measured on the same stream, in an "
                "isolated pass with ONE pair in flight (with several pairs in flight kernels of different pairs share the chip and "
                "per-launch durations are not kernel properties); rocprofv3 --stats of `bench.py --streams 1` in profiles/ agrees")
-        # group the launch classes by kernel symbol, as rocprofv3 --stats does, and take the symbol with the largest time
+        # group the launch classes by kernel symbol, as rocprofv3 --stats does; `roofline` is the class with the largest time, the other class is
+        # always emitted next to it (`roofline_attention` / `roofline_convolutions`)
+        CONV_SYM = "im::conv3x3_wino_kernel<POOL, FUSE1A, UREG, BX> (all instantiations)"
         if cfg5:
             groups = {ATTN_KERNEL: ["flash_attn_self", "flash_attn_cross"]}
         else:
             groups = {ATTN_KERNEL: ["flash_attn_self", "flash_attn_cross"],
-                      "im::conv3x3_wino_kernel<POOL, FUSE1A, UREG> (all instantiations)": ["conv1b", "conv2a", "conv2b", "conv3a", "conv3b", "conv4a",
-                                                                                             "conv4b", "convPa", "convDa"]}
+                      CONV_SYM: ["conv1b", "conv2a", "conv2b", "conv3a", "conv3b", "conv4a", "conv4b", "convPa", "convDa"]}
         gstat = {}
         for sym, names in groups.items():
             ms = sum(prof[k]["total_ms"] for k in names if k in prof)
             cnt = sum(prof[k]["count"] for k in names if k in prof)
             fl = sum(kernel_flops(k, 2, n0, n1, h, w, cfg5) * prof[k]["count"] for k in names if k in prof)
-            if sym.startswith("im::conv3x3_wino"):
+            if sym == CONV_SYM:
                 fl /= 2.25     # the Winograd F(2x2, 3x3) kernels execute 16 multiplies per 2 x 2 outputs where the direct form has 36: a utilisation prices what runs
             if cnt:
                 gstat[sym] = (ms, cnt, fl)
+
+        def class_roofline(sym):
+            ms_, cnt_, fl_ = gstat[sym]
+            is_attn = sym == ATTN_KERNEL
+            peak_ = PEAK_ATTN_TFLOPS if is_attn else PEAK_CONV_TFLOPS
+            ach_ = fl_ / (ms_ * 1e-3) / 1e12
+            mhz = clock_mhz["attention" if is_attn else "convolutions"]
+            out = {"bound": "mfma", "kernel": sym, "achieved": ach_, "peak": peak_, "unit": "TFLOP/s", "frac": ach_ / peak_,
+                   "avg_launch_ms": ms_ / cnt_, "launches_per_pair": cnt_ / prof_steps, "algorithmic_gflop_per_launch": fl_ / cnt_ / 1e9,
+                   "share_of_pair_time": ms_ / tot,
+                   "sustained_clock_mhz": mhz,
+                   "frac_at_sustained_clock": (ach_ / (peak_ * mhz / SPEC_CLOCK_MHZ)) if mhz else None,
+                   "sustained_clock_is": "median over the blocks of one isolated pass of (shader cycles / 100 MHz reference ticks) x 100 MHz inside the kernel's "
+                                         "main loop (s_memtime / s_memrealtime of the first wave, im_debug_clock_probe); `frac_at_sustained_clock` = achieved / "
+                                         f"(peak x that clock / {SPEC_CLOCK_MHZ:.0f} MHz): how well the kernel uses the matrix-pipe cycles the chip actually gives it"}
+            bx_form = not (ATTN_F32_FORM if is_attn else CONV_F32_FORM)
+            if bx_form:
+                out["peak_is"] = (f"{PEAK_BF16_MFMA_TFLOPS:.0f} TFLOP/s dense bf16 MFMA (MI355X_MICROARCH.md) / {ATTN_BF16_PRODUCTS}: the kernel computes every fp32 FLOP "
+                                  "it executes as six bf16 products on the bf16 matrix cores (fp32 operands as exact sums of three bf16 values, fp32 accumulation; "
+                                  "accuracy at or below the f32-input MFMA chain's: profiles/r05_bf16x_probe.txt, profiles/r06_bf16_stress.txt)")
+                out["vs_f32_input_mfma_peak"] = ach_ / PEAK_F32_MFMA_TFLOPS
+            if not is_attn:
+                out["flops_are"] = ("EXECUTED fp32 FLOPs of the Winograd F(2x2, 3x3) form = SURVEY 8d's direct-form count / 2.25 (against the direct-form count the "
+                                    "rate is `achieved` x 2.25: not a utilisation)")
+            return out
+
         dom = max(gstat, key=lambda k: gstat[k][0])
-        # since round 5 the attention class and the Winograd class take the same share of a pair to within a few per cent (2.8 ms each): keep the attention
-        # class as the line's `roofline` while it is within 5 % of the largest, so that the line does not flip between two kernels from box to box; the other
-        # class is always next to it (`roofline_attention` / `roofline_convolutions`)
-        if ATTN_KERNEL in gstat and gstat[ATTN_KERNEL][0] >= 0.95 * gstat[dom][0]:
-            dom = ATTN_KERNEL
         ms, cnt, fl = gstat[dom]
         ach = fl / (ms * 1e-3) / 1e12
-        peak = PEAK_ATTN_TFLOPS if dom == ATTN_KERNEL else PEAK_F32_MFMA_TFLOPS
         tkey = dom + ("<2>" if dom == "im::flash_attn_f32_kernel" else "<true, true>" if dom == ATTN_KERNEL else "")   # the instantiation rocprofv3 names
-        result["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                              "frac": ach / peak,
-                              "traffic": traffic_db.get(tkey + ("@16384" if cfg5 else ""), {}).get("traffic_bytes"),
-                              "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of a builder run, "
-                                                "FETCH_SIZE doubled per the gfx950 correction; NOT measured by this run)",
-                              "avg_launch_ms": ms / cnt,
-                              "launches_per_pair": cnt / prof_steps, "algorithmic_gflop_per_launch": fl / cnt / 1e9,
-                              "share_of_pair_time": ms / tot, "event_pair_overhead_us": round(1e3 * ev_overhead_ms, 2),
-                              "measured": how}
-        if dom.startswith("im::conv3x3_wino"):
-            result["roofline"]["flops_are"] = ("EXECUTED FLOPs of the Winograd F(2x2, 3x3) form = SURVEY 8d's direct-form count / 2.25 (the direct-form rate is "
-                                               "`achieved` x 2.25 and exceeds the f32-input MFMA peak: not a utilisation). The attention class "
-                                               f"({ATTN_KERNEL}) is within a few per cent of this one in time: its figures are in `roofline_attention`")
-        if dom != ATTN_KERNEL and ATTN_KERNEL in gstat:
-            ms_a, cnt_a, fl_a = gstat[ATTN_KERNEL]
-            result["roofline_attention"] = {"bound": "mfma", "kernel": ATTN_KERNEL, "achieved": fl_a / (ms_a * 1e-3) / 1e12, "peak": PEAK_ATTN_TFLOPS, "unit": "TFLOP/s",
-                                            "frac": fl_a / (ms_a * 1e-3) / 1e12 / PEAK_ATTN_TFLOPS, "avg_launch_ms": ms_a / cnt_a, "share_of_pair_time": ms_a / tot}
-        conv_sym = next((k for k in gstat if k.startswith("im::conv3x3_wino")), None)
-        if dom == ATTN_KERNEL and conv_sym:
-            ms_c, cnt_c, fl_c = gstat[conv_sym]
-            result["roofline_convolutions"] = {"bound": "mfma", "kernel": conv_sym, "achieved": fl_c / (ms_c * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                               "frac": fl_c / (ms_c * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, "share_of_pair_time": ms_c / tot,
-                                               "flops_are": "EXECUTED FLOPs of the Winograd F(2x2, 3x3) form = SURVEY 8d's direct-form count / 2.25, on the f32-input MFMA"}
+        result["roofline"] = class_roofline(dom)
+        result["roofline"].update({
+            "traffic": traffic_db.get(tkey + ("@16384" if cfg5 else ""), {}).get("traffic_bytes"),
+            "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of a builder run, "
+                              "FETCH_SIZE doubled per the gfx950 correction; NOT measured by this run)",
+            "event_pair_overhead_us": round(1e3 * ev_overhead_ms, 2), "measured": how})
+        for key, sym in (("roofline_attention", ATTN_KERNEL), ("roofline_convolutions", CONV_SYM)):
+            if sym in gstat:
+                result[key] = class_roofline(sym)
         if dom == ATTN_KERNEL and not ATTN_F32_FORM:
             result["roofline"].update({
-                "peak_is": f"{PEAK_BF16_MFMA_TFLOPS:.0f} TFLOP/s dense bf16 MFMA (MI355X_MICROARCH.md) / {ATTN_BF16_PRODUCTS}: the kernel computes every "
-                           "algorithmic fp32 FLOP as six bf16 products on the bf16 matrix cores (fp32 operands as exact sums of three bf16 "
-                           "values, fp32 accumulation; accuracy at or below the f32-input MFMA chain's error: profiles/r05_bf16x_probe.txt). "
-                           "`achieved` counts ALGORITHMIC fp32 FLOPs, as in every earlier round",
                 "executed_bf16_tflops": ach * ATTN_BF16_PRODUCTS * (4.0 * 256 * (n0 * n0 + n1 * n1) * prof.get("flash_attn_self", {}).get("count", 0)
                                                                    + 8.0 * 256 * n0 * n1 * prof.get("flash_attn_cross", {}).get("count", 0)) / fl,
-                "vs_f32_input_mfma_peak": ach / PEAK_F32_MFMA_TFLOPS,
                 "vs_f32_input_mfma_peak_is": "the same algorithmic rate against the 157.3 TFLOP/s of the f32-input MFMA, the roofline of rounds 1-5's "
                                              "kernel (csrc/attention.hip, IM_ATTN_F32=1: 0.745 there). A ratio, not a utilisation: this kernel does "
-                                             "not run on that pipe",
-                "sustained_clock_note": "bf16 MFMA loops on random data hold 1.5-1.95 GHz on this part, not 2.4 (guide, DVFS give-back): the "
-                                        "guide's own dense bf16 GEMM example sustains 1,247 TFLOP/s = 0.50 of the spec peak used here"})
+                                             "not run on that pipe"})
         if dom == ATTN_KERNEL:
             # the two launch kinds of the class apart: self-attention (4 . 256 . n^2 per image) and the cross block, whose two
             # launches execute 8 . 256 . n^2 for an algorithmic 6 . 256 . n^2 (S = Q0 Q1^T is computed once per direction)
@@ -551,18 +564,20 @@ def main():
         # 1 / 2.25 of those multiplies, so this figure is not a utilisation and may exceed 1; the executed-FLOP figure is next to it
         result["pair_algorithmic_tflops"] = pair_flops * (n_pairs / dt) / world / 1e12
         result["pair_algorithmic_tflops_is"] = ("SURVEY 8d's algorithmic fp32 FLOPs per pair x pairs/s. Not a utilisation of anything: the 3x3 convolutions run as "
-                                                "Winograd F(2x2, 3x3) (1 / 2.25 of the multiplies) on the f32-input MFMA (157.3 TFLOP/s), the attention on the "
-                                                "bf16 matrix cores at six products per fp32 product; `pair_matrix_pipe_time_at_peak_frac` is the utilisation figure")
+                                                "Winograd F(2x2, 3x3) (1 / 2.25 of the multiplies), they and the matchers' contractions on the bf16 matrix cores at "
+                                                "six products per fp32 product; `pair_matrix_pipe_time_at_peak_frac` is the utilisation figure")
         if not cfg5:
             conv3 = 2 * sum(conv_flops(*d) for d in ((h, w, 64, 64), (h // 2, w // 2, 64, 64), (h // 2, w // 2, 64, 64), (h // 4, w // 4, 64, 128),
                                                      (h // 4, w // 4, 128, 128), (h // 8, w // 8, 128, 128), (h // 8, w // 8, 128, 128),
                                                      (h // 8, w // 8, 128, 256), (h // 8, w // 8, 128, 256)))
             attn_exec = 9 * (4.0 * 256 * (n0 * n0 + n1 * n1) + 8.0 * 256 * n0 * n1)   # executed fp32-equivalent FLOPs of the 18 attention launches
             attn_alg = 9 * (4.0 * 256 * (n0 * n0 + n1 * n1) + 6.0 * 256 * n0 * n1)
-            rest_exec = pair_flops - attn_alg - conv3 * (1 - 1 / 2.25)                  # everything else, Winograd multiplies counted as executed
-            pipe_s = rest_exec / (PEAK_F32_MFMA_TFLOPS * 1e12) + attn_exec / (PEAK_ATTN_TFLOPS * 1e12)
-            # seconds the matrix pipes need for the executed work of one pair at their peaks (f32-input MFMA for convolutions / GEMMs / feed-forward,
-            # bf16 cores at six products per fp32 product for the attention) / seconds a pair takes
+            # executed fp32-equivalent FLOPs by pipe: the bf16 cores at six products per fp32 product (Winograd convolutions at 1 / 2.25 of their direct-form
+            # count, LightGlue's attention as executed, its feed-forward and GEMMs), the f32-input MFMA for what is left of SuperPoint (1 x 1 heads)
+            bx_exec = (0.0 if CONV_F32_FORM else conv3 / 2.25) + (734.4e9 - attn_alg) + attn_exec
+            f32_exec = (2 * 351.7e9 - conv3) + (conv3 / 2.25 if CONV_F32_FORM else 0.0)
+            pipe_s = bx_exec / (PEAK_ATTN_F32_EQUIVALENT_TFLOPS * 1e12) + f32_exec / (PEAK_F32_MFMA_TFLOPS * 1e12)
+            # seconds the matrix pipes need for the executed work of one pair at their spec peaks / seconds a pair takes
             result["pair_matrix_pipe_time_at_peak_frac"] = pipe_s * (n_pairs / dt) / world
             result["pair_executed_mfma_utilisation"] = result["pair_matrix_pipe_time_at_peak_frac"]     # the name of rounds 3-5, same meaning
 

@@ -49,6 +49,7 @@ SIGNATURES = {
     "im_superglue_forward": [_P, _P, _P, _P, _P, _P, C.POINTER(SuperGlueConf), _P, _P, _P, _P],
     "im_pack_record": [_P, _P, _P, _P, _P, _I, _P, _P],
     "im_debug_read": [_P, C.c_char_p, _P, C.c_size_t, _P],
+    "im_debug_clock_probe": [_P, _I, _P, _P],
     "im_debug_guard_failures": [],
     "im_debug_guard_selftest": [_P, _P],
     "im_debug_guards_check": [_P, _P],

@@ -425,6 +425,9 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bx_kernel(AttnArgs a) {
     float m_use = 0.f;
     if (nt >= 2) m_use = softmax_ref<false>(sc, 0, nk, hh, m_run, l_run, o0, o1);     // tile 0 lies inside the keys
     int r0 = 0, r1 = 1 % RD, r2 = 2 % RD;    // t % RD, (t + 1) % RD, (t + 2) % RD
+    // im_debug_clock_probe (a.clock set only by that call): the shader clock this kernel holds inside its main loop = cycles / 100 MHz ticks
+    unsigned long long ck0 = 0, cr0 = 0;
+    if (a.clock) { ck0 = __builtin_amdgcn_s_memtime(); cr0 = __builtin_amdgcn_s_memrealtime(); }
     for (int t = 0; t < nt - 2; ++t) {       // tiles t and t + 1 lie inside the keys: no masks anywhere
         const unsigned char* const kp = kring + r1 * 3 * KPL;
         const unsigned char* const vp = vring + r0 * 3 * VPL;
@@ -576,6 +579,13 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bx_kernel(AttnArgs a) {
         sc = sn;
         { const int rr = r0; r0 = r1; r1 = r2; r2 = RD == 3 ? rr : r0; }
         __syncthreads();
+    }
+    if (a.clock && nt > 8) {                 // blocks with a real loop only; the words go nowhere else
+        const unsigned long long ck1 = __builtin_amdgcn_s_memtime(), cr1 = __builtin_amdgcn_s_memrealtime();
+        if (threadIdx.x == 0) {
+            unsigned long long* cp = a.clock + 2 * (blockIdx.x % CLOCK_PROBE_SLOTS);
+            cp[0] = ck1 - ck0; cp[1] = cr1 - cr0;
+        }
     }
     {
         const int t = nt - 1;

@@ -368,8 +368,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
             IM_DMA_WAIT();
             __syncthreads();
         }
+        unsigned long long ck0 = 0, cr0 = 0;     // im_debug_clock_probe: the shader clock inside the chunk loop (AttnArgs::clock)
+        if (a.clock) { ck0 = __builtin_amdgcn_s_memtime(); cr0 = __builtin_amdgcn_s_memrealtime(); }
         xchunk(0, std::true_type{});
         for (int chunk = 1; chunk < nchunk; ++chunk) xchunk(chunk, std::false_type{});
+        if (a.clock) {
+            const unsigned long long ck1 = __builtin_amdgcn_s_memtime(), cr1 = __builtin_amdgcn_s_memrealtime();
+            if (tid == 0) {
+                unsigned long long* cp = a.clock + 2 * (blockIdx.x % CLOCK_PROBE_SLOTS);
+                cp[0] = ck1 - ck0; cp[1] = cr1 - cr0;
+            }
+        }
 #undef IM_XULOAD
     } else {
     if constexpr (UREG) { IM_ULOAD(uA, 0) }

@@ -98,6 +98,9 @@ struct im_ctx {
     float* stage_attn_part = nullptr; int* stage_attn_cnt = nullptr; size_t stage_attn_floats = 0, stage_attn_ints = 0;  // im_flash_attn
     unsigned char* stage_attn_planes = nullptr; size_t stage_attn_plane_bytes = 0;                                       // im_flash_attn (attention_bx.hip)
     im::MergeScratch* merge = nullptr;   // scratch of im_merge_tile_matches (tile_merge.hip), grown on demand
+    unsigned long long* clock_buf[2] = {nullptr, nullptr};   // im_debug_clock_probe: per-block (cycles, 100 MHz ticks) of the attention / Winograd BX main loops
+    bool clock_armed = false;
+    unsigned long long* clock_of(int cls) const { return clock_armed ? clock_buf[cls] : nullptr; }
     int dbg_cur = 0;  // which ping-pong descriptor buffer the last LightGlue forward ended in (im_debug_read)
 
     int fail(int code, const char* fmt, ...) {

@@ -84,7 +84,11 @@ struct AttnArgs {
     // Without it the attention kernel cuts the fp32 tiles itself, once per 128-query block
     void* planes = nullptr;
     int f32_form = 0;            // 1: attention.hip's kernel on the f32-input MFMA (rounds 1-5) for this launch; IM_ATTN_F32=1 sets it for all
+    // im_debug_clock_probe: when set, wave 0 of every block stores (shader cycles, 100 MHz reference ticks) spent in its main loop at
+    // clock[2 * (blockIdx.x % CLOCK_PROBE_SLOTS) ..]; no other code reads these words (the sustained clock of the kernel = their ratio x 100 MHz)
+    unsigned long long* clock = nullptr;
 };
+static constexpr int CLOCK_PROBE_SLOTS = 4096;
 static constexpr int ATTN_MAX_SPLIT = 4;
 inline size_t attn_part_floats(int n_max, int batch, int heads) { return (size_t)ATTN_MAX_SPLIT * batch * heads * n_max * 66; }
 inline size_t attn_planes_bytes(int n_max, int batch, int heads) { return (size_t)2 * batch * heads * n_max * 384; }
@@ -114,6 +118,7 @@ struct ConvArgs {
     // unless the f32-input form is asked for (IM_CONV_F32=1 / f32_form)
     const void* wx = nullptr;
     int f32_form = 0;             // 1: the f32-input MFMA Winograd kernel (rounds 2-5) although wx is set
+    unsigned long long* clock = nullptr;   // im_debug_clock_probe (as AttnArgs::clock): the BX kernel's main loop
 };
 hipError_t launch_conv3x3(const ConvArgs& a, hipStream_t s);
 // Winograd F(2x2, 3x3) variant (conv_wino.hip); a.w = weights packed by pack_conv3x3_wino: [Cin / 8][16][Cout][8] and / or

@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <algorithm>
 #include "ctx.h"
 #include "lg_misc.h"
 #include "sp_post.h"
@@ -399,6 +400,7 @@ int im_superpoint_forward(im_ctx* ctx, const uint8_t* d_img, int n_images, int h
     auto conv = [&](ConvArgs& a, int layer) {
         a.w = direct ? W.cw[layer] : W.cww[layer];
         a.wx = W.cwx[layer];
+        a.clock = ctx->clock_of(1);
         return direct ? launch_conv3x3(a, s) : launch_conv3x3_wino(a, s);
     };
     // conv1a is fused into conv1b's patch producer: the full-resolution 64-channel activation never touches HBM
@@ -472,7 +474,7 @@ static int lg_block(im_ctx* ctx, hipStream_t s, int NI, int layer, bool cross, f
     AttnArgs at;
     at.q = ws->q; at.k = cross ? ws->q : ws->k; at.v = ws->v; at.hstride = (long)K * 64; at.bstride = (long)K * 256;
     at.out = ws->att; at.out_bstride = xb; at.ldo = 256; at.n_ptr = n_ptr; at.pstride = ST_INTS; at.n_max = K; at.batch = NI; at.heads = 4;
-    at.cross = cross ? 1 : 0; at.active = active; at.part = ws->attn_part; at.counters = ws->attn_cnt; at.planes = ws->attn_planes;
+    at.cross = cross ? 1 : 0; at.active = active; at.part = ws->attn_part; at.counters = ws->attn_cnt; at.planes = ws->attn_planes; at.clock = ctx->clock_of(0);
     if (!cross) {
         GemmArgs g = base;
         g.A = x; g.a_bstride = xb; g.lda = 256; g.W = W.qkv_w + (long)layer * 768 * 256; g.ldw = 256;
@@ -657,6 +659,43 @@ int im_debug_read(im_ctx* ctx, const char* name, float* d_dst, size_t nfloats, v
     if (nfloats > avail) return ctx->fail(-62, "im_debug_read: %zu floats requested, %zu available", nfloats, avail);
     IM_HIP(ctx, hipMemcpyAsync(d_dst, src, nfloats * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     IM_HIP(ctx, hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}
+
+// Sustained shader clock of the two matrix-core kernel classes: arm = 1 allocates / clears the probe words and hands them to
+// every attention (attention_bx.hip) and Winograd BX (conv_wino.hip) launch of this context until arm = 0; the kernels' first wave stores the
+// shader cycles (s_memtime) and the 100 MHz reference ticks (s_memrealtime) spent in its main loop. Reading (arm = 0 or 2): the median over the
+// blocks that wrote of cycles / ticks x 100 MHz, per class; h_out = {attention MHz, attention blocks, convolution MHz, convolution blocks}.
+int im_debug_clock_probe(im_ctx* ctx, int arm, double* h_out, void* stream) {
+    IM_CHECK_CTX(ctx);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t bytes = (size_t)CLOCK_PROBE_SLOTS * 2 * sizeof(unsigned long long);
+    if (arm == 1) {
+        if (!ctx->clock_buf[0]) {
+            ctx->clock_buf[0] = ctx->dalloc<unsigned long long>((size_t)CLOCK_PROBE_SLOTS * 2, "clock_probe_attention");
+            ctx->clock_buf[1] = ctx->dalloc<unsigned long long>((size_t)CLOCK_PROBE_SLOTS * 2, "clock_probe_convolution");
+            if (!ctx->clock_buf[0] || !ctx->clock_buf[1]) return ctx->fail(-22, "im_debug_clock_probe: allocation failed");
+        }
+        IM_HIP(ctx, hipMemsetAsync(ctx->clock_buf[0], 0, bytes, s));
+        IM_HIP(ctx, hipMemsetAsync(ctx->clock_buf[1], 0, bytes, s));
+        IM_HIP(ctx, hipStreamSynchronize(s));
+        ctx->clock_armed = true;
+        return 0;
+    }
+    if (!ctx->clock_buf[0] || !h_out) return ctx->fail(-51, "im_debug_clock_probe: not armed");
+    std::vector<unsigned long long> h((size_t)CLOCK_PROBE_SLOTS * 2);
+    unsigned long long* src[2] = {ctx->clock_buf[0], ctx->clock_buf[1]};
+    for (int c = 0; c < 2; ++c) {
+        IM_HIP(ctx, hipMemcpyAsync(h.data(), src[c], bytes, hipMemcpyDeviceToHost, s));
+        IM_HIP(ctx, hipStreamSynchronize(s));
+        std::vector<double> mhz;
+        for (int i = 0; i < CLOCK_PROBE_SLOTS; ++i)
+            if (h[2 * i + 1] > 0) mhz.push_back(100.0 * (double)h[2 * i] / (double)h[2 * i + 1]);
+        std::sort(mhz.begin(), mhz.end());
+        h_out[2 * c] = mhz.empty() ? 0.0 : mhz[mhz.size() / 2];
+        h_out[2 * c + 1] = (double)mhz.size();
+    }
+    if (arm == 0) ctx->clock_armed = false;       // the buffers stay with the context (a graph captured while armed keeps writing into them, harmlessly)
     return 0;
 }
 

@@ -642,7 +642,7 @@ int im_superglue_forward(im_ctx* ctx, const float* d_kpts, const float* d_scores
             at.q = ws->q; at.k = ws->k; at.v = ws->v; at.hstride = (long)K * 64; at.bstride = (long)K * 256;
             at.out = ws->att; at.out_bstride = xb; at.ldo = 256; at.n_ptr = st->n; at.n_max = K; at.batch = 2; at.heads = 4;
             at.cross = cross ? 1 : 0; at.scale = 0.125f;  // / dim ** .5, dim = 64 (`superglue.py:91`)
-            at.part = ws->attn_part; at.counters = ws->attn_cnt; at.planes = ws->attn_planes;
+            at.part = ws->attn_part; at.counters = ws->attn_cnt; at.planes = ws->attn_planes; at.clock = ctx->clock_of(0);
             IM_LAUNCH(ctx, "attn_kv_planes", s, launch_attn_planes(at, s));
             IM_LAUNCH(ctx, cross ? "flash_attn_cross" : "flash_attn_self", s, launch_flash_attn(at, s));
         }

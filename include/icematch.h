@@ -126,6 +126,12 @@ int im_pack_records(im_ctx* ctx, int n_pairs, const int32_t* d_n, const int32_t*
 /* Copies an internal buffer of the last forward ("lg_x", "lg_cos", "lg_sin", "sim", "md", "sp_smap", "sp_nms") for
  * stage-level parity tests. */
 int im_debug_read(im_ctx* ctx, const char* name, float* d_dst, size_t nfloats, void* stream);
+/* Measurement aid (no reference counterpart): the shader clock the two matrix-core kernel classes hold INSIDE their main loops. arm = 1: from
+ * now on every attention launch (the matchers' self / cross blocks) and every Winograd convolution launch of this context has the first wave of
+ * each block store the shader cycles and the 100 MHz reference ticks of its main loop into probe words nothing else reads; arm = 2: read,
+ * stay armed; arm = 0: read and disarm. h_out[4] = {attention MHz (median over blocks), blocks, convolution MHz, blocks}. bench.py emits them
+ * as `roofline.sustained_clock_mhz` (MI355X_MICROARCH.md, DVFS give-back item 6: cycles / reference ticks x 100 MHz). */
+int im_debug_clock_probe(im_ctx* ctx, int arm, double* h_out, void* stream);
 /* Debugging aid (no reference counterpart; GPU AddressSanitizer is unavailable on the MI355X pool): with IM_DEBUG_GUARDS=1 in the
  * environment when a context is created, every device buffer the library allocates (workspace of im_ctx_reserve, packed weights,
  * scratch) carries 256 bytes of guard words on both sides; they are compared by a small kernel at the end of every forward /
