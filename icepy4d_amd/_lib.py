@@ -17,6 +17,16 @@ LIB_PATH = os.environ.get("ICEMATCH_LIB") or os.path.join(CSRC, "libicematch.so"
 _lib: Optional[C.CDLL] = None
 
 
+class IcematchError(RuntimeError):
+    """A call into libicematch.so returned non-zero (`Context.check`): out of device memory, a HIP error, a guard failure, bad arguments.
+    Distinct from other RuntimeErrors (torch's, e.g. an `interpolate` size error out of a bad `resize` option) so that callers can tell a
+    library / device failure - never to be swallowed - from a failure of an option (`matching/matchers.py` q7, `sequence.py`)."""
+
+    def __init__(self, what: str, rc: int, message: str):
+        super().__init__(f"{what} failed ({rc}): {message}")
+        self.what, self.rc = what, rc
+
+
 class LightGlueConf(C.Structure):
     _fields_ = [("depth_confidence", C.c_double), ("width_confidence", C.c_double),
                 ("filter_threshold", C.c_double), ("n_layers", C.c_int), ("pruning_min_kpts", C.c_int)]
@@ -134,7 +144,7 @@ class Context:
     def check(self, rc: int, what: str):
         if rc != 0:
             msg = self.lib.im_last_error(self.h)
-            raise RuntimeError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+            raise IcematchError(what, rc, msg.decode() if msg else "")
 
     def call(self, name: str, *args):
         self.check(getattr(self.lib, name)(self.h, *args), name)

@@ -139,26 +139,34 @@ int im_flash_attn(im_ctx* ctx, const float* d_q, const float* d_k, const float* 
     a.out = d_out; a.ldo = heads * 64; a.out_bstride = (long)n_max * a.ldo;
     a.n_ptr = d_n; a.n_max = n_max; a.batch = batch; a.heads = heads; a.cross = cross & 1; a.f32_form = (cross >> 1) & 1; a.scale = scale;
     // split-KV scratch of the stage entry point (the model paths use the reserved workspace): grown on demand
+    // each of the three grows on its own, to max(old, new) (growing both when either was short re-allocated on alternating shapes,
+    // a failed second allocation leaked the first, and the planes were grown for calls that do not use them)
     const size_t nf = attn_part_floats(n_max, batch, heads), ni = attn_counter_ints(n_max, batch, heads);
-    if (nf > ctx->stage_attn_floats || ni > ctx->stage_attn_ints) {
+    if (nf > ctx->stage_attn_floats) {
         IM_HIP(ctx, hipDeviceSynchronize());
         float* p = ctx->dalloc<float>(nf, "stage_attn_part");
-        int* c = ctx->dalloc<int>(ni, "stage_attn_cnt");
-        if (!p || !c) return ctx->fail(-11, "im_flash_attn: out of device memory");
-        IM_HIP(ctx, hipMemset(c, 0, ni * sizeof(int)));
+        if (!p) return ctx->fail(-11, "im_flash_attn: out of device memory");
         ctx->dfree(ctx->stage_attn_part);        // the smaller scratch it replaces (the device is idle: synchronised above)
-        ctx->dfree(ctx->stage_attn_cnt);
-        ctx->stage_attn_part = p; ctx->stage_attn_cnt = c; ctx->stage_attn_floats = nf; ctx->stage_attn_ints = ni;
+        ctx->stage_attn_part = p; ctx->stage_attn_floats = nf;
     }
+    if (ni > ctx->stage_attn_ints) {
+        IM_HIP(ctx, hipDeviceSynchronize());
+        int* c = ctx->dalloc<int>(ni, "stage_attn_cnt");
+        if (!c) return ctx->fail(-11, "im_flash_attn: out of device memory");
+        IM_HIP(ctx, hipMemset(c, 0, ni * sizeof(int)));
+        ctx->dfree(ctx->stage_attn_cnt);
+        ctx->stage_attn_cnt = c; ctx->stage_attn_ints = ni;
+    }
+    const bool wants_planes = !(cross & 4) && !a.f32_form;      // bit 2: K / V cut inside the attention kernel; the f32 form has no planes
     const size_t nb = attn_planes_bytes(n_max, batch, heads);
-    if (nb > ctx->stage_attn_plane_bytes) {
+    if (wants_planes && nb > ctx->stage_attn_plane_bytes) {
         IM_HIP(ctx, hipDeviceSynchronize());
         unsigned char* p = ctx->dalloc<unsigned char>(nb, "stage_attn_planes");
         if (!p) return ctx->fail(-11, "im_flash_attn: out of device memory");
         ctx->dfree(ctx->stage_attn_planes);
         ctx->stage_attn_planes = p; ctx->stage_attn_plane_bytes = nb;
     }
-    a.part = ctx->stage_attn_part; a.counters = ctx->stage_attn_cnt; a.planes = (cross & 4) ? nullptr : ctx->stage_attn_planes;   // bit 2: K / V cut inside the attention kernel
+    a.part = ctx->stage_attn_part; a.counters = ctx->stage_attn_cnt; a.planes = wants_planes ? ctx->stage_attn_planes : nullptr;
     IM_HIP(ctx, launch_attn_planes(a, (hipStream_t)stream));
     IM_HIP(ctx, launch_flash_attn(a, (hipStream_t)stream));
     IM_GUARD_CHECK(ctx, (hipStream_t)stream, "im_flash_attn");

@@ -34,6 +34,7 @@ from typing import Dict, List, Optional, Tuple, Union
 import numpy as np
 import torch
 
+from .._lib import IcematchError
 from ..utils import AverageTimer, timeit
 from .enums import GeometricVerification, Quality, TileSelection
 from .geometric_verification import geometric_verification
@@ -738,9 +739,10 @@ class LightGlueMatcher(ImageMatcherBase):
                 return self._match_images_resized(image0, image1, int(config["resize"]), int(max_keypoints))
             try:
                 return self._match_images_resized(image0, image1, int(config["resize"]), int(max_keypoints))
-            except RuntimeError:     # a library / device error (`Context.check`: out of memory, guard failure, HIP error) is not the
+            except IcematchError:    # a library / device error (`Context.check`: out of memory, guard failure, HIP error) is not the
                 raise                # resize option's failure: hiding it behind a second forward would lose the message
-            except Exception as e:   # q7 (`matchers.py:1262-1267`): the reference's bare `except` calls `extract(image)` WITHOUT the option,
+            except Exception as e:   # q7 (`matchers.py:1262-1267`): the reference's bare `except` calls `extract(image)` WITHOUT the option
+                # (any other failure, torch's RuntimeErrors out of an unusable `resize` included, falls through to the reference's retry),
                 # i.e. with the preprocessor's default resize = 1024 (`lightglue/superpoint.py:106-110, 217-227`) - not "no resize"
                 logger.warning(f"extract(resize={config['resize']!r}) failed ({type(e).__name__}: {e}): retrying with the extractor's "
                                "default resize=1024, as the reference does")

@@ -259,7 +259,21 @@ class SequenceMatcher:
                     self.e.ctx.call("im_debug_guards_check", self.e.stream_ptr())
         except Exception as group_exc:      # noqa: BLE001 - any error of a launch group is isolated to the pairs that cause it
             # the group as a whole could not be enqueued: its pairs one by one with direct launches (their inputs are still parked in
-            # self._inp), so that only the pairs that fail by themselves are marked
+            # self._inp), so that only the pairs that fail by themselves are marked. The group's own error is logged whatever the retries
+            # give (it vanished when they succeeded); a failed graph capture is not tried again for every later group; and an
+            # error that is not a pair's (a sticky HIP error, out of device memory: the retries would fail the same way, or worse, half work)
+            # goes to the caller, who owns the process group.
+            import logging
+            log = logging.getLogger("icepy4d_amd")
+            log.error("launch group of %d pair(s) (epochs %s) failed as a whole: %s: %s - retrying its pairs one by one", len(pend),
+                      [int(e) for e, _, _ in pend], type(group_exc).__name__, group_exc)
+            if self.use_graph and self._graph is None:
+                self.use_graph = False
+                log.error("HIP graph capture failed: this matcher goes on with direct launches")
+            msg = str(group_exc).lower()
+            if isinstance(group_exc, (MemoryError, torch.cuda.OutOfMemoryError)) or "out of memory" in msg or "out of device memory" in msg \
+                    or "hiperror" in msg.replace(" ", "") or "illegal" in msg or "device-side" in msg:
+                raise
             for j, (epoch, table, row) in enumerate(pend):
                 try:
                     if len(pend) == 1:

@@ -952,11 +952,27 @@ def test_resize_failure_is_retried_with_the_default_resize_like_the_reference():
     with pytest.raises(Exception):
         strict._match_images(a, b, max_keypoints=256, resize="not a size")
 
+    from icepy4d_amd._lib import IcematchError
+
     def device_error(*a_, **k_):
-        raise RuntimeError("im_superpoint_forward failed (-31): out of device memory")
+        raise IcematchError("im_superpoint_forward", -31, "out of device memory")
     m._match_images_resized = device_error
-    with pytest.raises(RuntimeError, match="-31"):
+    with pytest.raises(IcematchError, match="-31"):
         m._match_images(a, b, max_keypoints=256, resize=500)
+    # ... while a torch RuntimeError out of an unusable `resize` (an interpolate size error) is the OPTION's failure: the reference's bare
+    # `except` retries with the default resize, and so does the product (only library errors are re-raised)
+    m2 = LightGlueMatcher({"state_dicts": sds})
+    real = m2._match_images_resized
+    calls = []
+
+    def torch_error_then_real(i0, i1, resize, k):
+        calls.append(resize)
+        if len(calls) == 1:
+            raise RuntimeError("Input and output sizes should be greater than 0, but got input (H: 200, W: 304) output (H: 0, W: 0)")
+        return real(i0, i1, resize, k)
+    m2._match_images_resized = torch_error_then_real
+    h0, h1, k0, conf3 = m2._match_images(a, b, max_keypoints=256, resize=3)
+    assert calls == [3, 1024] and np.array_equal(h0.keypoints, f0.keypoints) and np.array_equal(k0, m0)
 
 
 def test_preselection_selects_the_oracle_tile_pairs():

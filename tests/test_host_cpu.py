@@ -851,6 +851,11 @@ def test_kernels_keep_their_register_budget(tmp_path):
                 run = run + 1 if op.startswith("v_mfma") else 0
                 best_run = max(best_run, run)
             assert best_run <= 6, best_run         # only the last PV group (nothing left to deal) runs its six back to back
+            # the counted wait of the step: `vmcnt(6)` = "this step's six transfers may still fly, everything older has landed" is right only
+            # if a step issues EXACTLY six vector-memory operations, all of them LDS-DMA transfers: no register load, no store, no scratch in the loop
+            vm = [l.strip() for l in hot.split("\n") if l.strip().startswith(("buffer_", "global_", "scratch_", "flat_"))]
+            assert len(vm) == 6 and all(l.startswith("buffer_load_dwordx4") and l.endswith(" lds") for l in vm), vm
+            assert "s_waitcnt vmcnt(6)" in body and "scratch_" not in body
 
 
 
@@ -957,6 +962,43 @@ def test_sequence_matcher_isolates_a_failing_pair():
         rec = table.numpy()
         assert sq.pending_epochs(7, rec) == [4, 5]
         assert sq.decode_record(rec[4], 8)["n_matches"] == -1 and len(sq.decode_record(rec[4], 8)["matches0"]) == 0
+
+
+def test_sequence_matcher_logs_a_group_failure_and_lets_device_errors_through(caplog):
+    """ADVICE r05: (a) the error of a launch group is logged even when the one-by-one retries of its pairs succeed (it used to vanish);
+    (b) an error that is not a pair's - out of device memory, a sticky HIP error - is NOT retried pair by pair: it reaches the caller, as
+    `matchers.py` does for `IcematchError`."""
+    import logging
+    ns = {}
+    exec(FAKE_SEQUENCE, ns)
+    sq = ns["sq"]
+    sm = ns["fake_matcher"](2)
+    real = sm._enqueue
+    state = {"n": 0}
+
+    def flaky(pairs):                       # the first enqueue of a whole group fails, the retries work
+        state["n"] += 1
+        if state["n"] == 1:
+            raise ValueError("transient launch-group failure")
+        return real(pairs)
+    sm._enqueue = flaky
+    table = sq.new_table(2, 8, "cpu")
+    with caplog.at_level(logging.ERROR, logger="icepy4d_amd"):
+        for ep in range(2):
+            sm.match_pair(torch.full((2, 4, 4), ep + 1, dtype=torch.uint8), ep, table, ep)
+        sm.flush()
+    assert table[:, 3].tolist() == [1, 2] and sm.failed == []
+    assert any("failed as a whole" in r.getMessage() and "transient launch-group failure" in r.getMessage() for r in caplog.records)
+
+    sm = ns["fake_matcher"](2)
+
+    def oom(pairs):
+        raise RuntimeError("im_superpoint_forward failed (-11): out of device memory")
+    sm._enqueue = oom
+    table = sq.new_table(2, 8, "cpu")
+    sm.match_pair(torch.ones(2, 4, 4, dtype=torch.uint8), 0, table, 0)
+    with pytest.raises(RuntimeError, match="out of device memory"):
+        sm.match_pair(torch.ones(2, 4, 4, dtype=torch.uint8), 1, table, 1)
 
 
 ISOLATION_WORKER = FAKE_SEQUENCE + r'''
