@@ -63,7 +63,14 @@ static constexpr int S_MAIN = 2 * S_SP + 2 * W_SU;
 static constexpr int S_IH = S_TH + 4, S_IW = S_TW + 4;
 static constexpr int S_FUSE = S_IH * S_IW;
 static constexpr int S_LDS_FLOATS = S_MAIN;
-static constexpr int X_SP = 4 * S_QUAD * 4;          // BX: floats per patch stage (four channel quads = 16 channels)
+// BX, plain layers: the patch stage of a 16-channel chunk is PIXEL-major - one (patch row, column parity) = 10 slots x 4 channel quads = 640 bytes,
+// filled by ONE LDS-DMA piece whose lanes 4 s .. 4 s + 3 read the four quads of pixel slot s (64 contiguous bytes of global memory: a piece touches
+// ~10 cache lines where the quad-major pieces of the f32 form touch 64, and the texture-address unit is what these kernels are bound by,
+// profiles/r06_conv_bx_ablations.txt). Reads stay conflict-free: the 16 lanes a ds_read_b128 serves together are 4 tile columns (64 bytes apart)
+// x 4 tile rows, and the rows of a row pair start 16 bytes further per pair (XP_PITCH leaves room for the shift).
+static constexpr int XP_PITCH = 44;                  // float4 per (row, parity): 10 slots x 4 quads + up to 3 of shift, padded to a multiple of 4
+static constexpr int XP_STAGE = 2 * S_PH * XP_PITCH; // float4 per stage: 880 = 14,080 bytes
+static constexpr int X_SP = XP_STAGE * 4;            // BX: floats per patch stage (16 channels)
 static constexpr int X_LDS_FLOATS = 16384;           // BX: two patch stages (6,400 floats); the 64 KB exchange image of the epilogue aliases them
 static_assert(2 * X_SP <= X_LDS_FLOATS, "the patch stages must fit under the exchange image");
 

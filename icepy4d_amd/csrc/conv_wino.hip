@@ -273,7 +273,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
         const unsigned ux_voff = (unsigned)lane * 16u;
 #endif
         const unsigned ux_base = (unsigned)(4 * ph) * ux_pos + (unsigned)(co0 / 32) * 3072u;
+        // resident image (fused first layer): [quad][row][parity][column / 2] as in the f32 form; staged chunks (plain layers): pixel-major, see XP_PITCH
         const int x_slotA = 2 * hh * S_QUAD + (2 * t_ty + rowA) * S_ROW + t_tx, x_slotB = 2 * hh * S_QUAD + (2 * t_ty + rowB) * S_ROW + t_tx;
+        const int xp_rowA = 2 * t_ty + rowA, xp_rowB = 2 * t_ty + rowB;
+        const int xp_A = 2 * xp_rowA * XP_PITCH + ((xp_rowA >> 1) & 3) + t_tx * 4 + 2 * hh, xp_B = 2 * xp_rowB * XP_PITCH + ((xp_rowB >> 1) & 3) + t_tx * 4 + 2 * hh;
         wu32x4 ur[X_RING][3];
 #define IM_XULOAD(slot, cbase, nbase, nvoff, s)   /* cbase / nbase: byte offsets of this chunk's and the next chunk's U planes; nvoff: the lane offset for the next chunk's */ \
         {                                                                                                \
@@ -290,17 +293,30 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
         const int rot = 0;
 #endif
         auto cc_of = [&](int it) { const int c_ = it + rot; return c_ >= nchunk ? c_ - nchunk : c_; };
-        auto xstage = [&](int it) {       // the patch of iteration it's chunk (four channel quads) into stage it & 1
+        // the patch of iteration it's chunk into stage it & 1: 20 pieces (10 patch rows x 2 column parities), five per wave; lane 4 s + quad of piece
+        // (row, parity) reads quad `quad` of pixel (row, 2 s + parity) - zeros outside the image through the range check; lanes past the nine used
+        // slots stay out (EXEC)
+        unsigned xp_voff[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int pc = wave * 5 + i, row = pc >> 1, par = pc & 1, sl = lane >> 2, quad = lane & 3;
+            const int gy = y0 + row - 1, gx = x0 + 2 * sl + par - 1;
+            const bool in = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            xp_voff[i] = in ? (unsigned)(((unsigned)gy * a.W + gx) * a.Cin + quad * 4) * 4u : 0xFFFFF000u;
+        }
+        auto xstage = [&](int it) {
             const int chunk = cc_of(it);
 #ifdef IM_XABL_NO_PATCH
-            if (tid > 12345)
+            if (lane > 12345)
 #else
-            if (tid < S_QUAD)
+            if (lane < 4 * (S_PW / 2))
 #endif
             {
-                const unsigned pb_ = lds_sP + ((it & 1) * X_SP + wave * 256) * 4u;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) dma16(rin, pb_ + q * (S_QUAD * 16u), pv, chunk * 64u + q * 16u);
+                for (int i = 0; i < 5; ++i) {
+                    const int pc = wave * 5 + i, row = pc >> 1;
+                    dma16(rin, lds_sP + (unsigned)(((it & 1) * XP_STAGE + pc * XP_PITCH + ((row >> 1) & 3)) * 16), xp_voff[i], chunk * 64u);
+                }
             }
         };
         auto xchunk = [&](int it, auto FIRST_) {
@@ -320,7 +336,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(ConvArgs a) {
                 const float4* pq = pa + q * S_QUAD;
                 float4 t[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) t[j] = sub4(pq[x_slotA + (j & 1) * S_PAR + (j >> 1)], pq[x_slotB + (j & 1) * S_PAR + (j >> 1)], rsgn);
+                for (int j = 0; j < 4; ++j) {
+                    if constexpr (RESIDENT) t[j] = sub4(pq[x_slotA + (j & 1) * S_PAR + (j >> 1)], pq[x_slotB + (j & 1) * S_PAR + (j >> 1)], rsgn);
+                    else t[j] = sub4(pa[xp_A + (j & 1) * XP_PITCH + (j >> 1) * 4 + q], pa[xp_B + (j & 1) * XP_PITCH + (j >> 1) * 4 + q], rsgn);
+                }
                 const float4 w0 = sub4(t[0], t[2], m1), w1 = add4(t[1], t[2]), w2 = sub4(t[2], t[1], m1), w3 = sub4(t[1], t[3], m1);
                 v[0][4 * q] = w0.x; v[0][4 * q + 1] = w0.y; v[0][4 * q + 2] = w0.z; v[0][4 * q + 3] = w0.w;
                 v[1][4 * q] = w1.x; v[1][4 * q + 1] = w1.y; v[1][4 * q + 2] = w1.z; v[1][4 * q + 3] = w1.w;

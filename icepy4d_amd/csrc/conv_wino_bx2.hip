@@ -28,14 +28,14 @@ namespace im {
 
 static constexpr int Y_TH = 16, Y_TW = 16;                 // output pixels per region: two groups of 8 rows
 static constexpr int Y_PH = Y_TH + 2, Y_PW = Y_TW + 2;     // halo patch
-static constexpr int Y_QUAD = Y_PH * S_ROW;                // 360 slots (float4) per channel quad: row stride 20 slots as in conv_wino.hip
-static constexpr int Y_STAGE_SLOTS = 3 * 512;              // 4 quads x 360 = 1440 slots, padded to three lane-linear pieces per wave
-static constexpr int Y_STAGE_BYTES = Y_STAGE_SLOTS * 16;   // 24,576
+static constexpr int Y_PIECES = 2 * Y_PH;                  // patch pieces per chunk: one per (patch row, column parity), pixel-major as conv_wino.h XP_PITCH
+static constexpr int Y_PPW = (Y_PIECES + 7) / 8;           // pieces per wave and chunk (5; the 4 past the end are dummies: every wave issues the same number)
+static constexpr int Y_STAGE_BYTES = (8 * Y_PPW + 1) * XP_PITCH * 16;   // 28,864: 36 pieces, 4 dummy targets, room for the row-pair shift
 static constexpr int Y_NQ = 3;                             // quarter slots of the U ring
 static constexpr int Y_QBYTES = 24 * 1024;                 // 4 V rows x 2 column tiles x 3 planes x 1 KB
 static constexpr int Y_XBYTES = 24 * 1024;                 // exchange image of one group and one round of the epilogue
-static constexpr int Y_LDS_BYTES = Y_STAGE_BYTES + Y_NQ * Y_QBYTES + 2 * Y_XBYTES;   // 147,456: stage | ring | exchange, nothing aliased
-static_assert(4 * Y_QUAD <= Y_STAGE_SLOTS && Y_LDS_BYTES <= 160 * 1024, "LDS plan");
+static constexpr int Y_LDS_BYTES = Y_STAGE_BYTES + Y_NQ * Y_QBYTES + 2 * Y_XBYTES;   // 151,744: stage | ring | exchange, nothing aliased (+ 256 bytes of bias)
+static_assert(Y_LDS_BYTES + 256 <= 160 * 1024, "LDS plan");
 
 #ifdef IM_YSTAMP   // diagnostic build only (tools/conv_bx2_stamps.py): shader-clock stamps of wave 0 of the first blocks, never read by the kernel
 __device__ unsigned long long g_ystamp[256 * 256];
@@ -46,8 +46,8 @@ __device__ unsigned long long g_ystamp[256 * 256];
 
 struct YItem {            // one region of one image: what changes from item to item of a persistent block
     int b, y0, x0;
-    unsigned pv[3];       // lane offsets of the three patch pieces (out of range outside the image and in padding slots)
-    wu32x4 rin;           // descriptor of image b's input
+    unsigned pv[2];       // lane offset of a patch piece by column parity: quad `lane & 3` of pixel column 2 (lane >> 2) + parity of the patch, row 0
+                          // (out of range for columns outside the image and padding slots); the piece's row rides in the scalar offset
 };
 
 template <bool POOL>
@@ -76,28 +76,37 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_bx2_kernel(ConvArgs a, in
         z.b = rt / (tx * ty);
         const int trem = rt - z.b * tx * ty;
         z.x0 = (trem % tx) * Y_TW; z.y0 = (trem / tx) * Y_TH;
-        z.rin = wmake_rsrc4(a.in + (long)z.b * a.H * a.W * a.Cin, (unsigned)a.H * a.W * a.Cin * 4u);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {       // slot tid + 512 k of [quad][row][column parity][column / 2]
-            const int sl = tid + 512 * k, quad = sl / Y_QUAD, rem = sl - quad * Y_QUAD, row = rem / S_ROW, r2 = rem - row * S_ROW;
-            const int par = r2 >= S_PAR ? 1 : 0, s_ = r2 - par * S_PAR, px = 2 * s_ + par, gy = z.y0 + row - 1, gx = z.x0 + px - 1;
-            const bool in = sl < 4 * Y_QUAD && s_ < Y_PW / 2 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-            z.pv[k] = in ? (unsigned)(((unsigned)gy * a.W + gx) * a.Cin + quad * 4) * 4u : 0x80000000u;    // out of range: zeros
+        for (int par = 0; par < 2; ++par) {
+            const int sl = lane >> 2, quad = lane & 3, gx = z.x0 + 2 * sl + par - 1;
+            const bool in = sl < Y_PW / 2 && gx >= 0 && gx < a.W;
+            z.pv[par] = in ? (unsigned)(gx * a.Cin + quad * 4) * 4u : 0x80000000u;    // out of range: zeros
         }
     };
     const int nchunk = a.Cin / 16;
-    // three pieces per wave, ALWAYS (the pieces count in vmcnt): `live` false = out of range through the lane offset (zeros, no traffic)
+    // Y_PPW pieces per wave, ALWAYS (the pieces count in vmcnt): `live` false = out of range through the lane offset (zeros, no traffic). Lanes
+    // past the nine used slots of a row stay out (EXEC): their 16 bytes would land in the next piece's image
     auto patch_dma = [&](const YItem& z, int chunk, bool live) __attribute__((always_inline)) {
-        const unsigned so = (live ? (unsigned)chunk : 0u) * 64u, oob = live ? 0u : 0x80000000u;     // scalar selects, no branch
-        wu32x4 rs;                                                                                  // the descriptor back in scalar registers
-        rs.x = __builtin_amdgcn_readfirstlane(z.rin.x); rs.y = __builtin_amdgcn_readfirstlane(z.rin.y);
-        rs.z = __builtin_amdgcn_readfirstlane(z.rin.z); rs.w = __builtin_amdgcn_readfirstlane(z.rin.w);
+        const unsigned so = (live ? (unsigned)chunk : 0u) * 64u;
+        const wu32x4 rs = wmake_rsrc4(a.in + (long)z.b * a.H * a.W * a.Cin, (unsigned)a.H * a.W * a.Cin * 4u);   // image b's input, formed where it is used
+        const unsigned oobv = 0x80000000u;
+        if (lane < 4 * (Y_PW / 2)) {
 #pragma unroll
+            for (int k = 0; k < Y_PPW; ++k) {
+                // piece wave * Y_PPW + k = (patch row, column parity); lane 4 s + quad reads quad `quad` of pixel (row, 2 s + parity). Rows outside the
+                // image and the dummy pieces past the 36th go out of range as a whole (uniform select of the lane offset)
+                const int pc = wave * Y_PPW + k, row = pc >> 1, gy = z.y0 + row - 1;
+                const bool rowok = live && pc < Y_PIECES && gy >= 0 && gy < a.H;
+                const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((pc * XP_PITCH + ((row >> 1) & 3)) * 16));
+                const unsigned so_ = __builtin_amdgcn_readfirstlane(rowok ? so + (unsigned)gy * (unsigned)(a.W * a.Cin * 4) : 0u);
 #ifdef IM_YABL_NO_PDMA      // -DIM_YABL_* / -DIM_XABL_*: timing-only ablations (wrong results)
-        for (int k = 0; k < 3; ++k) dma16(rs, lds0 + (unsigned)(wave * 1024 + k * 8192), 0x80000000u, so);
+                dma16(rs, dst, oobv, so_);
 #else
-        for (int k = 0; k < 3; ++k) dma16(rs, lds0 + (unsigned)(wave * 1024 + k * 8192), z.pv[k] | oob, so);
+                if (rowok) dma16(rs, dst, (pc & 1) ? z.pv[1] : z.pv[0], so_);     // uniform branch: exactly one of the two is issued, no per-piece lane offset is formed
+                else dma16(rs, dst, oobv, so_);
 #endif
+            }
+        }
     };
     // ---- U: an endless stream of quarters (chunk uc, position step uj), the same for every item of this block; wave w moves V row w >> 1,
     // column tile w & 1, its three planes. uw = ring slot written next, ur_ = ring slot read next.
@@ -122,7 +131,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_bx2_kernel(ConvArgs a, in
     // lane (c, hh): tile c of the group's 4 x 8 tile grid, channels 8 hh .. 8 hh + 7 of the chunk
     const int t_ty = c >> 3, t_tx = c & 7;
     const int rowA = ph == 0 ? 0 : (ph == 2 ? 2 : 1), rowB = ph == 0 ? 2 : (ph == 3 ? 3 : (ph == 2 ? 1 : 2));   // wave-uniform
-    const int x_slotA = 2 * hh * Y_QUAD + (8 * g + 2 * t_ty + rowA) * S_ROW + t_tx, x_slotB = 2 * hh * Y_QUAD + (8 * g + 2 * t_ty + rowB) * S_ROW + t_tx;
+    const int xp_rowA = 8 * g + 2 * t_ty + rowA, xp_rowB = 8 * g + 2 * t_ty + rowB;
+    const int xp_A = 2 * xp_rowA * XP_PITCH + ((xp_rowA >> 1) & 3) + t_tx * 4 + 2 * hh, xp_B = 2 * xp_rowB * XP_PITCH + ((xp_rowB >> 1) & 3) + t_tx * 4 + 2 * hh;
     f32x2 rsgn;
     {
         float sg = __uint_as_float(__builtin_amdgcn_readfirstlane(ph == 1 ? 0x3F800000u : 0xBF800000u));
@@ -130,7 +140,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_bx2_kernel(ConvArgs a, in
         rsgn = f32x2{sg, sg};
     }
     const f32x2 m1 = minus_one();
-    const float bias2[2] = {a.bias[co0 + c], a.bias[co0 + 32 + c]};          // this lane's two output channels, for every item of the block
+    float* const sBias = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + Y_LDS_BYTES);     // the block's 64 biases (it keeps its output channels)
+    if (tid < 64) sBias[tid] = a.bias[co0 + tid];
     const float4* const pa = reinterpret_cast<const float4*>(smem);
     const wu32x4* const ring = reinterpret_cast<const wu32x4*>(reinterpret_cast<const char*>(smem) + Y_STAGE_BYTES) + (ph * 2) * 192 + lane;   // + slot * 1536 + (ct * 3 + plane) * 64
 
@@ -141,9 +152,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_bx2_kernel(ConvArgs a, in
     wu32x4 uf[2][3];
 
     auto row_reads = [&](int q, int jj, float4& da, float4& db) __attribute__((always_inline)) {
-        const float4* pq = pa + q * Y_QUAD;
-        da = pq[x_slotA + (jj & 1) * S_PAR + (jj >> 1)];
-        db = pq[x_slotB + (jj & 1) * S_PAR + (jj >> 1)];
+        da = pa[xp_A + (jj & 1) * XP_PITCH + (jj >> 1) * 4 + q];
+        db = pa[xp_B + (jj & 1) * XP_PITCH + (jj >> 1) * 4 + q];
     };
     auto col_half = [&](int q) __attribute__((always_inline)) {
         const float4 w0 = sub4(t[q][0], t[q][2], m1), w1 = add4(t[q][1], t[q][2]), w2 = sub4(t[q][2], t[q][1], m1), w3 = sub4(t[q][1], t[q][3], m1);
@@ -222,11 +232,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_bx2_kernel(ConvArgs a, in
     // position 0) and, j = 2 / 3, the row / column pass of the next chunk (possibly the next item's first). Transfers complete in issue order;
     // issue order: U(T + 2) at the start of quarter T, the patch two chunks ahead at the start of a quarter 3 behind its U pieces. In front of the
     // barrier that ends quarter T, U(T + 1) (issued at the start of T - 1) must have landed; younger than it:
-    //   j = 0: the patch pieces of quarter T - 1 (3), U(T + 2) (3)                  -> vmcnt(6)   (behind an item boundary the epilogue's stores sit between
+    //   j = 0: the patch pieces of quarter T - 1 (Y_PPW = 5), U(T + 2) (3)          -> vmcnt(8)   (behind an item boundary the epilogue's stores sit between
     //          the patch pieces and U(T + 2): the wait then also covers all but the last three of them, issued a whole quarter earlier)
     //   j = 1: U(T + 2)                                                             -> vmcnt(3)   (the patch, read in quarter 2, is older than U(T + 1))
     //   j = 2: U(T + 2)                                                             -> vmcnt(3)
-    //   j = 3: U(T + 2), this quarter's patch pieces                                -> vmcnt(6)
+    //   j = 3: U(T + 2), this quarter's patch pieces                                -> vmcnt(8)
     int stamp_i = 2;
     auto quarter = [&](auto J_, auto FIRST_, const YItem& pz, int pchunk, bool plive) __attribute__((always_inline)) {
         constexpr int j = decltype(J_)::value;
@@ -243,12 +253,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_bx2_kernel(ConvArgs a, in
             const wu32x4 ah = {ph_[cur_][0], ph_[cur_][1], ph_[cur_][2], ph_[cur_][3]}, am = {pm_[cur_][0], pm_[cur_][1], pm_[cur_][2], pm_[cur_][3]},
                          al = {pl_[cur_][0], pl_[cur_][1], pl_[cur_][2], pl_[cur_][3]};
             const wu32x4 bh = uf[n][0], bm = uf[n][1], bl = uf[n][2];
-            float4 da[2], db[2];
+            float4 da[1], db[1];
             f32x16 x = FIRST ? f32x16{} : acc[s];
             // six MFMA slots (h l, l h, m m, h m, m h, h h); behind each its share of the vector work, fenced:
             //   every quarter: the cut of pairs 2 n, 2 n + 1 of the next position (a a b b l l);
             //   j = 2: the row pass of channel half n of the NEXT chunk (the stage holds it since the barrier that ended quarter 1), one pixel
-            //          column per slot, its reads two slots ahead; in step 1 also the column pass of half 0;  j = 3, step 0: the column pass of half 1
+            //          column per slot, its reads one slot ahead; in step 1 also the column pass of half 0;  j = 3, step 0: the column pass of half 1
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
                 x = mfma_bx(k == 1 ? al : ((k == 2 || k == 4) ? am : ah), k == 0 ? bl : ((k == 2 || k == 3) ? bm : bh), x);
@@ -258,23 +268,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_bx2_kernel(ConvArgs a, in
                 if (k == 2) cut_b(cur_ ^ 1, 2 * n, 0);
                 if (k == 3) cut_b(cur_ ^ 1, 2 * n + 1, 1);
                 if (k == 4) { cut_l(cur_ ^ 1, 2 * n, 0); cut_l(cur_ ^ 1, 2 * n + 1, 1); }
-                if constexpr (j == 2) {
-                    if (k >= 2 && k < 4) t[n][k - 2] = sub4(da[k & 1], db[k & 1], rsgn);   // columns 0, 1 behind slots 2, 3 (read behind slots 0, 1) ...
-                    if (k < 4) row_reads(n, k, da[k & 1], db[k & 1]);
+                if constexpr (j == 2) {             // pixel column k - 1 behind slot k (read behind slot k - 1): one pair of reads in flight
+                    if (k >= 1 && k < 5) t[n][k - 1] = sub4(da[0], db[0], rsgn);
+                    if (k < 4) row_reads(n, k, da[0], db[0]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if constexpr (j == 2) {                              // ... columns 2, 3 and (step 1) the column pass of half 0 behind the last slot
-                t[n][2] = sub4(da[0], db[0], rsgn);
-                t[n][3] = sub4(da[1], db[1], rsgn);
-                if (n == 1) col_half(0);
-            }
+            if constexpr (j == 2) { if (n == 1) col_half(0); }   // (step 1) the column pass of half 0 behind the last slot
             if constexpr (j == 3) { if (n == 0) col_half(1); }
             acc[s] = x;
             __builtin_amdgcn_sched_barrier(0);
         }
         Y_STAMP(stamp_i)
-        if constexpr (j == 0 || j == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        if constexpr (j == 0 || j == 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 + Y_PPW) : "memory");
         else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
         Y_STAMP(stamp_i + 1)
         __syncthreads();
@@ -295,7 +301,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_bx2_kernel(ConvArgs a, in
             quarter(I0{}, FIRST_, cur, 0, false);
             quarter(I1{}, FIRST_, cur, 0, false);
             quarter(I2{}, FIRST_, cur, 0, false);
-            quarter(I3{}, FIRST_, mine ? cur : nxt, mine ? chunk + 2 : chunk + 2 - nchunk, mine || has_next);
+            YItem pz;                    // this item's or the next one's patch coordinates, field by field (a reference to one of two structs would
+            pz.b = mine ? cur.b : nxt.b; pz.y0 = mine ? cur.y0 : nxt.y0; pz.x0 = mine ? cur.x0 : nxt.x0;      // put both in scratch memory)
+            pz.pv[0] = mine ? cur.pv[0] : nxt.pv[0]; pz.pv[1] = mine ? cur.pv[1] : nxt.pv[1];
+            quarter(I3{}, FIRST_, pz, mine ? chunk + 2 : chunk + 2 - nchunk, mine || has_next);
         };
         chunk_quarters(0, TT{});          // fresh accumulators
         for (int chunk = 1; chunk < nchunk; ++chunk) chunk_quarters(chunk, FF{});
@@ -308,7 +317,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_bx2_kernel(ConvArgs a, in
             if (keep_ == 12345.678f) a.out[0] = keep_;
         }
 #else
-        wino_epilogue_rounds<POOL>(a, acc, xw, ph, lane, cur.b, cur.y0 + 8 * g, cur.x0, co0, m1, bias2);
+        {
+            // everything the epilogue derives from the lane index is formed HERE, per item: hoisted out of the item loop it would live (in
+            // scratch memory) across the whole main loop. The bias comes back from LDS for the same reason.
+            int lane_ = lane;
+            asm volatile("" : "+v"(lane_));
+            const float bias2[2] = {sBias[lane_ & 31], sBias[32 + (lane_ & 31)]};
+            wino_epilogue_rounds<POOL>(a, acc, xw, ph, lane_, cur.b, cur.y0 + 8 * g, cur.x0, co0, m1, bias2);
+        }
 #endif
         Y_STAMP(stamp_i + 1)
         stamp_i += 2;
@@ -343,8 +359,8 @@ static hipError_t launch_bx2(const ConvArgs& a, hipStream_t s) {
     if (grid < unit) grid = unit;
     if (grid > nitems) grid = nitems;
     static size_t lds_optin[IM_MAX_DEVICES] = {0};
-    if (hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(&conv3x3_wino_bx2_kernel<POOL>), Y_LDS_BYTES, lds_optin); e != hipSuccess) return e;
-    hipLaunchKernelGGL((conv3x3_wino_bx2_kernel<POOL>), dim3(grid), dim3(512), Y_LDS_BYTES, s, a, nitems);
+    if (hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(&conv3x3_wino_bx2_kernel<POOL>), Y_LDS_BYTES + 256, lds_optin); e != hipSuccess) return e;
+    hipLaunchKernelGGL((conv3x3_wino_bx2_kernel<POOL>), dim3(grid), dim3(512), Y_LDS_BYTES + 256, s, a, nitems);
     return hipGetLastError();
 }
 
