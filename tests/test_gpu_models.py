@@ -1150,7 +1150,8 @@ def test_relative_orientation_and_triangulation_on_device():
         P0, P1 = K @ np.eye(3, 4), K @ np.c_[R, t]
         h0, h1 = np.c_[k0, np.ones(n)], np.c_[k1, np.ones(n)]
         Xd = sfm.triangulate_points_linear(P0, P1, h0, h1, engine=e)
-        assert Xd.shape == (n, 4) and np.median(np.linalg.norm(Xd[n_out:, :3] - X[n_out:], axis=1)) < 0.05
+        assert Xd.shape == (n, 4) and np.median(np.linalg.norm(Xd[n_out:, :3] - X[n_out:], axis=1)) < 0.08      # 0.3 px noise at depth 5-11 (the reference's
+        # formulation - point and depths - sits at 0.052 here, the cross-product rows of rounds 4-5 sat at 0.046: another algebraic error, §f-4)
     # `im_triangulate_linear` against the REFERENCE's own outputs (G10: `sfm/triangulation.py:153-186` imported by tools/gen_golden.py on seeded
     # cameras and 500 noisy correspondences), not against the product's host path: the device solves through A^T A in fp64 (one thread per point)
     g10 = load_golden("g10_triangulation")
