@@ -791,7 +791,9 @@ def test_kernels_keep_their_register_budget(tmp_path):
     waits = [int(m) for m in re.findall(r"s_waitcnt vmcnt\((\d+)\)", hot)]
     assert waits and min(waits) >= 6, waits
     # BX2 (opt-in, conv_wino_bx2.hip): every transfer of the persistent loop is an LDS-DMA piece with a counted wait in front of each quarter's
-    # barrier - 3 U pieces per wave and quarter, 3 more (the patch two chunks ahead) in quarter 3, nothing else in vector memory, no scratch
+    # barrier - 3 U pieces per wave and quarter (vmcnt(3): the quarter's own pieces may still fly), the wave's patch pieces of the next chunk (each
+    # under its own predicate: blocks of their own) between quarters 3 and 4 (vmcnt(8) = 3 + 5 in quarters 4 and 1); nothing else in vector memory
+    # inside the chunk loop, no scratch
     out3 = tmp_path / "conv_wino_bx2.s"
     r = subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only", "-I" + os.path.join(ROOT, "include"),
                         os.path.join(ROOT, "icepy4d_amd", "csrc", "conv_wino_bx2.hip"), "-o", str(out3)], capture_output=True, text=True)
@@ -805,19 +807,17 @@ def test_kernels_keep_their_register_budget(tmp_path):
         bx2[field4("name")] = (int(field4("vgpr_count")), int(field4("vgpr_spill_count")), int(field4("private_segment_fixed_size")))
     assert len(bx2) == 2 and all(v <= 256 and sp == 0 and scratch == 0 for v, sp, scratch in bx2.values()), bx2
     for sym in ("_ZN2im23conv3x3_wino_bx2_kernelILb0EEEvNS_8ConvArgsEi", "_ZN2im23conv3x3_wino_bx2_kernelILb1EEEvNS_8ConvArgsEi"):
-        hot = hot_block(kernel_body(t3, sym), "v_mfma_f32_32x32x16_bf16")
-        assert hot.count("v_mfma_f32_32x32x16_bf16") == 48, hot.count("v_mfma_f32_32x32x16_bf16")
-        quarters = hot.split("s_barrier")[:-1]
-        assert len(quarters) == 4, len(quarters)
-        seq = []
-        for q in quarters:
-            vm = [l.strip() for l in q.split("\n") if l.strip().startswith(("buffer_", "global_", "scratch_", "flat_"))]
+        body = kernel_body(t3, sym)
+        assert "scratch_" not in body and "flat_" not in body
+        blocks = [b for b in re.split(r"\n\.LBB\d+_\d+:", body) if "v_mfma_f32_32x32x16_bf16" in b]
+        assert blocks and sum(b.count("v_mfma_f32_32x32x16_bf16") for b in blocks) % 48 == 0, [b.count("v_mfma_f32_32x32x16_bf16") for b in blocks]
+        for b in blocks:
+            n = b.count("v_mfma_f32_32x32x16_bf16")
+            vm = [l.strip() for l in b.split("\n") if l.strip().startswith(("buffer_", "global_", "scratch_", "flat_"))]
             assert all(l.startswith("buffer_load_dwordx4") and l.endswith(" lds") for l in vm), vm
-            w = re.findall(r"s_waitcnt vmcnt\((\d+)\)", q)
-            assert len(w) == 1, w
-            seq.append((len(vm), int(w[0])))
-        # (pieces issued, pieces that may still fly at the barrier) per quarter, j = 0..3 in some rotation of the loop
-        assert sorted(seq) == sorted([(3, 6), (3, 3), (3, 3), (6, 6)]), seq
+            w = [int(x) for x in re.findall(r"s_waitcnt vmcnt\((\d+)\)", b)]
+            assert (n, w) in ((36, [8, 3, 3]), (12, [8])), (n, w)
+            assert b.count("s_barrier") == len(w)
     # the kernels on the bf16 matrix cores (round 5): two waves per SIMD (<= 256 registers), no scratch; the attention's main loop must hold its 48
     # bf16 MFMAs apart (the vector work of a tile is dealt over the MFMA slots by hand: at most two MFMAs back to back outside the last PV group),
     # and the product form stages by LDS-DMA (no ds_write in its loop)
