@@ -42,7 +42,7 @@ def test_gemm_nt(ctx, m, n, k, big):
 
 @pytest.mark.parametrize("act", [0, 1])
 @pytest.mark.parametrize("rows,live", [(64, None), (200, (200, 77)), (4096, (4096, 3001)), (33, (1, 33))])
-def test_ffn_fused(ctx, rows, live, act):
+def test_ffn_fused(ctx, rows, live, act, monkeypatch):
     """ffn.0 on cat([x, att]) -> LayerNorm(512) + GELU (LightGlue, `lightglue.py:144-149, 160-162`) or ReLU (SuperGlue's mlp with
     BatchNorm folded, `superglue.py:51-61, 104-116`) -> second linear -> residual in one kernel, against the same chain in
     float64 torch; ragged live-row counts per image; rows past them must stay untouched."""
@@ -59,19 +59,24 @@ def test_ffn_fused(ctx, rows, live, act):
     h = torch.cat([x, att], -1).double() @ w0.double().t() + b0.double()
     h = F.gelu(F.layer_norm(h, (512,), lg.double(), lb.double(), 1e-5)) if act == 0 else F.relu(h)
     ref = x.double() + h @ w3.double().t() + b3.double()
-    dx, da = dev(x), dev(att)
     dn = None if live is None else dev(torch.tensor(live, dtype=torch.int32))
     hw = [t.contiguous().numpy() for t in (w0, b0, lg, lb, w3, b3)]
     if act == 1:
         hw[2] = hw[3] = None
-    ctx.call("im_ffn_fused", act, ptr(dx), ptr(da), *[ptr(t) for t in hw], 2, rows, ptr(dn), stream_ptr())
-    torch.cuda.synchronize()
-    out = dx.cpu()
-    for z in range(2):
-        n = rows if live is None else live[z]
-        err = (out[z, :n].double() - ref[z, :n]).abs().max().item()
-        assert err < 3e-5, (z, err)
-        assert torch.equal(out[z, n:], x[z, n:])
+    outs = {}
+    for split in ("0", "1"):      # one block per CU with full-K planes / two with half-K planes (launch_ffn_fused reads the switch per call; default: by grid size)
+        monkeypatch.setenv("IM_FFN_SPLIT", split)
+        dx, da = dev(x), dev(att)
+        ctx.call("im_ffn_fused", act, ptr(dx), ptr(da), *[ptr(t) for t in hw], 2, rows, ptr(dn), stream_ptr())
+        torch.cuda.synchronize()
+        out = outs[split] = dx.cpu()
+        for z in range(2):
+            n = rows if live is None else live[z]
+            err = (out[z, :n].double() - ref[z, :n]).abs().max().item()
+            assert err < 3e-5, (split, z, err)
+            assert torch.equal(out[z, n:], x[z, n:]), split
+    # the split form (the contraction in two halves, weight steps of one k chunk) forms every sum in the other form's order
+    assert torch.equal(outs["0"], outs["1"])
 
 
 def test_gemm_asymmetric_layout(ctx):
