@@ -52,9 +52,12 @@ DTYPE_NOTE = ("fp32 end to end, as the reference. Every large contraction - Supe
               "matrix cores with fp32 accumulation (every fp32 operand is the exact sum of three bf16 values; error at or below the f32-input MFMA chain's: "
               "profiles/r05_bf16x_probe.txt, profiles/r06_bf16_stress.txt, tests/test_gpu_bf16_stress.py); SuperPoint's 1 x 1 heads stay on the f32-input MFMA")
 PEAK_HBM_GBS = 8000.0          # same guide: HBM3E spec peak (6.3 TB/s is what a copy kernel reaches)
-# Pairs per launch of the timed region (`--batch`): the batch dimension over pairs inside the kernels. Measured on one MI355X with two
-# launch groups in flight (round 3, three boxes): 2 -> 105.8, 4 -> 107.3, 5 -> 107.5, 8 -> 108.1, 10 -> 107.0-108 (the maximum on every box),
-# 16 -> 106.6, 25 -> 106.3 pairs/s; with the round driver's `--steps 20 --warmup 5`: 2 -> 104.1, 4 -> 106.0, 5 -> 106.2, 10 -> 106.9.
+# Pairs per launch of the timed region (`--batch`): the batch dimension over pairs inside the kernels. Re-measured on the round-6 build
+# (profiles/r06_sweep_launch_mode.txt, one MI355X, `--steps 20 --warmup 5`), pairs/s by launch groups in flight x pairs per launch:
+#   1 group :  1 -> 143.7   2 -> 156.7   4 -> 160.4   5 -> 161.0   10 -> 162.2   20 -> 163.3
+#   2 groups:  1 -> 156.2   2 -> 162.4   4 -> 164.5   5 -> 165.9   10 -> 166.0   20 -> 162.8      <- the default (two groups, ten pairs)
+#   3 groups:  1 -> 150.3   2 -> 159.5   4 -> 164.4   5 -> 163.2   10 -> 162.8   20 -> 162.9
+# (round 3, three boxes: 2 -> 105.8, 4 -> 107.3, 5 -> 107.5, 8 -> 108.1, 10 -> 107.0-108, 16 -> 106.6, 25 -> 106.3: the same shape.)
 # 10 divides the default 50 steps and the driver's 20. tests/test_gpu_fullsize.py checks this very mode against one pair per launch.
 DEFAULT_PAIRS_PER_LAUNCH = 10
 VALUE_REPEATS = 5                # timed regions of `steps` steps each, back to back; `value` = the median region
