@@ -121,8 +121,19 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
 #define IM_ST_F32(buf, i, r) *reinterpret_cast<float4*>(buf + ((tid + (i) * 256) / F4) * LDS_LD + ((tid + (i) * 256) % F4) * 4) = r
     auto st_bx = [&](unsigned char* plane0, int plane_bytes, int i, float4 x) {
         unsigned h0, m0, l0, h1, m1, l1;
+#if defined(IM_GABL_NO_BCUT) || defined(IM_GABL_NO_CUT)      // timing ablations (bf16-accurate results): what the plane cut of W / of both operands costs
+#ifdef IM_GABL_NO_CUT
+        const bool skip_ = true;
+#else
+        const bool skip_ = plane0 == xB;
+#endif
+        if (skip_) { h0 = gcvt_pk(x.x, x.y); h1 = gcvt_pk(x.z, x.w); m0 = l0 = m1 = l1 = 0u; }     // bf16-accurate values: the data-dependent flow stays
+        else
+#endif
+        {
         gsplit2(x.x, x.y, h0, m0, l0);
         gsplit2(x.z, x.w, h1, m1, l1);
+        }
         unsigned char* d = plane0 + ((tid + i * 256) / F4) * XS + ((tid + i * 256) % F4) * 8;
         *reinterpret_cast<gu32x2*>(d) = gu32x2{h0, h1};
         *reinterpret_cast<gu32x2*>(d + plane_bytes) = gu32x2{m0, m1};

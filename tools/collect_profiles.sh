@@ -13,6 +13,7 @@ cd /tmp && export TMPDIR=/tmp
 python3 $root/bench.py > $out/bench.json 2> $out/bench.err
 python3 $root/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-side-measurements > $out/bench_steps20_warmup5.json 2> /dev/null   # the driver's flags
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats1 -- python3 $root/bench.py --no-cpu-baseline --no-side-measurements --streams 1 --batch 1 > $out/bench_streams1_under_rocprof.json 2> /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats10 -- python3 $root/bench.py --no-cpu-baseline --no-side-measurements --streams 1 --batch 10 > $out/bench_streams1_batch10_under_rocprof.json 2> /dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_default -- python3 $root/bench.py --no-cpu-baseline --no-side-measurements > $out/bench_default_under_rocprof.json 2> /dev/null
 python3 $root/bench.py --config 5 > $out/bench_config5.json 2> $out/bench_config5.err
 python3 $root/bench.py --config 3 --no-cpu-baseline > $out/bench_config3.json 2> $out/bench_config3.err

@@ -27,7 +27,8 @@ def durations(sub):
     return d
 
 
-for sub, outname in (("stats1", f"{tag}_kernel_stats_streams1_batch1.csv"), ("stats_default", f"{tag}_kernel_stats_default.csv"),
+for sub, outname in (("stats1", f"{tag}_kernel_stats_streams1_batch1.csv"), ("stats10", f"{tag}_kernel_stats_streams1_batch10.csv"),
+                     ("stats_default", f"{tag}_kernel_stats_default.csv"),
                      ("stats_config5", f"{tag}_kernel_stats_config5.csv"), ("stats_assign", f"{tag}_kernel_stats_assign_one_pair.csv")):
     d = durations(sub)
     if not d:
