@@ -72,7 +72,12 @@ __device__ __forceinline__ void bx_dma16(du32x4 rsrc, unsigned lds_byte_addr, un
 #pragma clang diagnostic pop
 
 __device__ __forceinline__ f32x16 mfma_bf(u32x4 a, u32x4 b, f32x16 c) {
+#ifdef BX_ABL_NO_MFMA       // timing ablation (wrong results): one vector instruction in place of every MFMA
+    c[0] += __uint_as_float(a.x ^ b.x);
+    return c;
+#else
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+#endif
 }
 __device__ __forceinline__ unsigned cvt_pk(float a, float b) {            // v_cvt_pk_bf16_f32: a in the low half, round to nearest even
     const bf16x2 v = __builtin_convertvector(f32x2{a, b}, bf16x2);
@@ -121,8 +126,21 @@ __device__ __forceinline__ void stage4(unsigned char* plane0, int plane_bytes, i
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 __device__ __forceinline__ u32x2 tr_read(const unsigned char* p) {
+#ifdef BX_ABL_NO_VREAD      // timing ablation (wrong results): no transposed V reads
+    const unsigned x = (unsigned)(unsigned long long)p;
+    return u32x2{x, 0x3f803f80u};
+#else
     const bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p));
     return __builtin_bit_cast(u32x2, v);
+#endif
+}
+__device__ __forceinline__ u32x4 kf_read(const unsigned char* p) {
+#ifdef BX_ABL_NO_KREAD      // timing ablation (wrong results): no K fragment reads
+    const unsigned x = (unsigned)(unsigned long long)p;
+    return u32x4{x, 0x3f803f80u, x, 0x3f803f80u};
+#else
+    return *reinterpret_cast<const u32x4*>(p);
+#endif
 }
 
 static constexpr float BX_SLACK = 8.f;   // as attention.hip: the running max is a reference, raised when a row exceeds it by 2^8
@@ -434,7 +452,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bx_kernel(AttnArgs a) {
         u32x4 kf[2][3];
         u32x2 vr[2][6];
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) kf[0][pl] = *reinterpret_cast<const u32x4*>(kp + pl * KPL + kq[0]);
+        for (int pl = 0; pl < 3; ++pl) kf[0][pl] = kf_read(kp + pl * KPL + kq[0]);
 #ifndef BX_ABL_NO_STAGE     // -DBX_ABL_*: timing-only ablations of the main loop (wrong results), as IM_ABL_* in attention.hip
         if constexpr (DMA) {
             dma_k(t + 3, r0);                // over K(t), last read in step t - 1
@@ -455,6 +473,9 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bx_kernel(AttnArgs a) {
         // No instruction is emitted, so nothing is hidden from the hazard recogniser.
 #define BX_PIN(x) asm volatile("" : "+v"(x))
         auto expo = [&](int r) {                       // 3 instructions
+#ifdef BX_ABL_NO_EXPCUT     // timing ablation (wrong results): no exp2, no row sums, no plane cut of P
+            return;
+#endif
             float x = sc[r];
             BX_PIN(x);
             x = __builtin_amdgcn_exp2f(x - m_use);
@@ -463,6 +484,9 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bx_kernel(AttnArgs a) {
             if (r & 1) rsum1 += x; else rsum0 += x;
         };
         auto cut_a = [&](int i) {                      // pair i = registers 2 i, 2 i + 1: 4-5 instructions
+#ifdef BX_ABL_NO_EXPCUT
+            ch[i] = __float_as_uint(sc[2 * i]); cm[i] = __float_as_uint(sc[2 * i + 1]); cl[i] = ch[i]; return;
+#endif
             float x = sc[2 * i], y = sc[2 * i + 1];
             BX_PIN(x); BX_PIN(y);
             ch[i] = cvt_pk(x, y);
@@ -471,6 +495,9 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bx_kernel(AttnArgs a) {
             BX_PIN(ra[i]); BX_PIN(rb[i]);
         };
         auto cut_b = [&](int i) {
+#ifdef BX_ABL_NO_EXPCUT
+            return;
+#endif
             BX_PIN(ra[i]); BX_PIN(rb[i]);
             cm[i] = cvt_pk(ra[i], rb[i]);
             ra[i] -= __uint_as_float(cm[i] << 16);
@@ -478,6 +505,9 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bx_kernel(AttnArgs a) {
             BX_PIN(ra[i]); BX_PIN(rb[i]);
         };
         auto cut_l = [&](int i) {
+#ifdef BX_ABL_NO_EXPCUT
+            return;
+#endif
             BX_PIN(ra[i]);
             cl[i] = cvt_pk(ra[i], rb[i]);
             BX_PIN(cl[i]);
@@ -491,7 +521,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bx_kernel(AttnArgs a) {
         for (int s4 = 0; s4 < 4; ++s4) {
             if (s4 < 3) {
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) kf[(s4 + 1) & 1][pl] = *reinterpret_cast<const u32x4*>(kp + pl * KPL + kq[s4 + 1]);
+                for (int pl = 0; pl < 3; ++pl) kf[(s4 + 1) & 1][pl] = kf_read(kp + pl * KPL + kq[s4 + 1]);
             }
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
