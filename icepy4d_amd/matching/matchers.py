@@ -311,6 +311,25 @@ class ImageMatcherBase(ImageMatcherABC):
         self._tiler = Tiler(grid=grid, overlap=overlap, origin=origin)
         t0_lims, t0_origin = self._tiler.compute_limits_by_grid(image0)
         t1_lims, t1_origin = self._tiler.compute_limits_by_grid(image1)
+        # each full image crosses PCIe ONCE per call: the preselection's pyramid and every tile crop read the device copy (round 6: the host
+        # crops, their stacking and per-tile uploads were ~50 of the production call's 306 ms, profiles/r06_production_call_kernel_stats.csv)
+        self._dev_images = {}
+        try:
+            return self._match_by_tile_body(image0, image1, t0_lims, t0_origin, t1_lims, t1_origin, tile_selection, **config)
+        finally:
+            self._dev_images = {}
+
+    def _device_image(self, image: np.ndarray):
+        """The device copy of a full image of the current tile call (uint8, contiguous, [H, W] or [H, W, 3])."""
+        cache = getattr(self, "_dev_images", None)
+        if cache is None:
+            cache = self._dev_images = {}
+        key = id(image)
+        if key not in cache:
+            cache[key] = torch.from_numpy(_as_device_image(image)).to(self.engine.device)
+        return cache[key]
+
+    def _match_by_tile_body(self, image0, image1, t0_lims, t0_origin, t1_lims, t1_origin, tile_selection, **config):
         tile_pairs = self._tile_selection(image0, image1, t0_lims, t1_lims, tile_selection, **config)
 
         mk0, mk1 = [np.zeros((0, 2), np.float32)], [np.zeros((0, 2), np.float32)]
@@ -380,7 +399,8 @@ class ImageMatcherBase(ImageMatcherABC):
                 n_down = 2
             else:
                 n_down = 1
-            i0, i1 = pyr_down(image0, self.engine, n_down), pyr_down(image1, self.engine, n_down)   # levels stay on the device
+            i0 = pyr_down(image0, self.engine, n_down, device_image=self._pyr_source(image0, **config))   # levels stay on the device
+            i1 = pyr_down(image1, self.engine, n_down, device_image=self._pyr_source(image1, **config))
             f0, f1, mtc, _ = self._match_images(i0, i1, max_keypoints=4096)
             vld = mtc > -1
             kp0 = f0.keypoints[vld] * (2 ** n_down)
@@ -393,6 +413,12 @@ class ImageMatcherBase(ImageMatcherABC):
             self.timer.update("preselection")
             return pairs
         raise ValueError(f"unknown tile selection {method}")
+
+    def _pyr_source(self, image: np.ndarray, **config):
+        """The device copy of `image` for the pyramid when the tile matcher is going to need it anyway (a subclass with a tile cache); None otherwise."""
+        if self._sp_params(**config) is None or image.dtype != np.uint8 or not (image.ndim == 2 or (image.ndim == 3 and image.shape[2] == 3)):
+            return None
+        return self._device_image(image)
 
     def _resize_images(self, quality: Quality, image0: np.ndarray, image1: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
         """`matchers.py:583-610`: HIGHEST = pyrUp, HIGH = identity, MEDIUM = pyrDown, LOW = pyrDown twice."""
@@ -471,18 +497,20 @@ class ImageMatcherBase(ImageMatcherABC):
         radius, thr, border, max_k, flavour = params            # max_k < 0: every candidate (SuperGlue's max_keypoints = -1)
         eng = self.engine
         todo = sorted({(0, a) for a, _ in tile_pairs} | {(1, b) for _, b in tile_pairs})
-        tiles = {k: _as_device_image(self._tiler.extract_patch(image0 if k[0] == 0 else image1, (t0_lims if k[0] == 0 else t1_lims)[k[1]]))
-                 for k in todo}
+        tiles = {}
+        for k in todo:        # views of the device copy of the full image (`Tiler.extract_patch`'s slice): no host crop, no per-tile upload
+            lim = (t0_lims if k[0] == 0 else t1_lims)[k[1]]
+            tiles[k] = self._device_image(image0 if k[0] == 0 else image1)[lim[1]:lim[3], lim[0]:lim[2]]
         hmax, wmax = max(t.shape[0] for t in tiles.values()), max(t.shape[1] for t in tiles.values())
         cap = int(self._opt.get("max_keypoints_cap", 16384)) if max_k < 0 else int(max_k)
         cache = {}
         by_shape = {}
         for k in todo:
-            by_shape.setdefault(tiles[k].shape, []).append(k)
+            by_shape.setdefault(tuple(tiles[k].shape), []).append(k)
         for shape, keys in by_shape.items():
             for i in range(0, len(keys), 2):  # two equal-sized tiles per launch
                 grp = keys[i:i + 2]
-                batch = torch.from_numpy(np.stack([tiles[k] for k in grp])).to(eng.device)
+                batch = torch.stack([tiles[k] for k in grp])      # one strided device copy per tile
                 while True:
                     eng.reserve(hmax, wmax, 2, max(cap, 1))
                     eng.superpoint(batch, radius, thr, border, max_k, flavour=flavour)
