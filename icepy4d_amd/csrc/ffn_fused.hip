@@ -428,7 +428,9 @@ __global__ __launch_bounds__(ff::NT, 4) void ffn_fused_split_kernel(FfnArgs a) {
     }
     __syncthreads();
     F_STAMP(5)
-    // 16 threads per row, thread `part` holds columns part * 4 + 64 i + {0..3}: LayerNorm(512) + GELU (ACT 0), then the cut into planes
+    // 16 threads per row, thread `part` holds columns part * 4 + 64 i + {0..3}: LayerNorm(512) + GELU (ACT 0), then the cut into planes.
+    // The body below is the full-K kernel's, statement for statement, ON PURPOSE: as one shared device function the compiler contracts its multiplies and adds
+    // differently (tried in round 6: both kernels still agreed with each other, but not with the previous build - tools/compare_builds.py)
     const int row = tid >> 4, part = tid & 15;
     {
         const float* rp = sA + row * LD + part * 4;
