@@ -47,6 +47,7 @@ struct LightGlueW {
     float* cf0_w = nullptr; float* cf0_b = nullptr;      // cross ffn.0 with to_out folded in
     float* cln_g = nullptr; float* cln_b = nullptr;
     float* cf3_w = nullptr; float* cf3_b = nullptr;
+    float* qkv_wp = nullptr; float* cqv_wp = nullptr;    // the two projections again as bf16 planes in MFMA-fragment order, per layer (gemm.hip proj_rows_kernel)
     float* sf0_wp = nullptr; float* sf3_wp = nullptr;    // the four FFN matrices again in MFMA-fragment order (ffn_fused.hip)
     float* cf0_wp = nullptr; float* cf3_wp = nullptr;
     float* fp_w = nullptr;  float* fp_b = nullptr;       // log_assignment.final_proj [L][256][256], [L][256]
@@ -59,6 +60,7 @@ struct SuperGlueW {
     bool ready = false;
     float* kenc_w[5] = {nullptr}; float* kenc_b[5] = {nullptr};  // BN folded; layer 0 K padded 3 -> 32
     float* proj_w = nullptr; float* proj_b = nullptr;    // [18][3][256][256] head-major output rows, [18][3][256]
+    float* proj_wp = nullptr;                            // proj_w again as bf16 planes in MFMA-fragment order, per layer (gemm.hip proj_rows_kernel)
     float* mlp0_w = nullptr; float* mlp0_b = nullptr;    // [18][512][512] BN folded, second half of K head-major-agnostic
     float* mlp3_w = nullptr; float* mlp3_b = nullptr;    // [18][256][512]
     float* mlp0_wp = nullptr; float* mlp3_wp = nullptr;  // the same matrices in MFMA-fragment order (ffn_fused.hip)

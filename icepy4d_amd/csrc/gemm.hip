@@ -15,6 +15,7 @@
 // Global loads of slab t+1 are issued before the MFMAs of slab t (register staging).
 #include "common.h"
 #include "kernels.h"
+#include "sp_post.h"
 
 namespace im {
 
@@ -279,6 +280,163 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
                 }
             }
         }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------------
+// The K = 256 projections of a transformer block as ROW BLOCKS (round 6; `lightglue/lightglue.py:153, 192-193`: Wqkv + rotary, to_qk / to_v). The tiled
+// kernel above runs them at 0.27 of the bf16 / 6 roofline (284 us per ten pairs for qkv): eight 32-deep slabs, each with its own staging, plane cut of BOTH
+// operands (the W tile again in every row block, the x tile again in every column block) and barrier, around 48 MFMAs per wave. Here a block owns 32 rows
+// for ALL N output columns, as the fused feed-forward does: x is cut ONCE into three 256-wide bf16 planes in LDS (50 KB: two to three blocks per CU), the
+// weights arrive cut (the host's pack_frag_weights: MFMA-fragment order, a wave's 16-byte-per-lane load is one contiguous KiB) and stream from L2 straight
+// into registers one 16-deep step ahead, one barrier per block. Wave w owns the column tiles w, w + 8, (w + 16): one of q / k / v each, sixteen steps of six
+// MFMAs per tile, then that tile's epilogue (the tiled kernel's, statement for statement: bias, rotary on q / k, head-major stores). The products and their
+// order per accumulator are those of the tiled kernel (x planes as A, W planes as B, k ascending, h l | l h | m m | h m | m h | h h): bit-identical outputs.
+namespace pr {
+constexpr int BM = 32, NT = 512;
+constexpr int PS = 528;              // bytes per row of a plane: 256 x 2 + 16 (132 dwords = 4 mod 64: conflict-free 16-byte row reads)
+constexpr int PLANE = BM * PS;       // 16,896
+constexpr int LDS_BYTES = 3 * PLANE; // 50,688
+constexpr unsigned TILE_BYTES = (256 / 16) * 3 * 1024;   // one packed 32-column tile at K = 256: 16 k chunks x 3 planes x 1 KiB
+}  // namespace pr
+
+#ifdef IM_PSTAMP   // diagnostic build only (tools/proj_stamps.py): shader-clock stamps of wave 0 of every block, never read by the kernel
+__device__ unsigned long long g_pstamp[4096 * 16];
+#define P_STAMP(i) { if (wave == 0) { const unsigned long long ts_ = __builtin_amdgcn_s_memtime(); const int b_ = blockIdx.y * gridDim.x + blockIdx.x; if (lane == 0 && b_ < 4096) g_pstamp[b_ * 16 + (i)] = ts_; } }
+extern "C" int im_debug_pstamps(unsigned long long* host, size_t n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_pstamp), n * sizeof(unsigned long long));
+}
+#else
+#define P_STAMP(i)
+#endif
+
+template <int EPI, int TILES>
+__global__ __launch_bounds__(pr::NT, 4) void proj_rows_kernel(GemmArgs a) {
+    using namespace pr;
+    static_assert(EPI == EPI_QKV_ROPE || EPI == EPI_HEADS_QV, "the two projections of a LightGlue block");
+    extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
+    const int z = blockIdx.y, pair = z >> 1;
+    if (a.active && a.active[pair * a.pstride] == 0) return;
+    const int M = a.m_ptr ? a.m_ptr[pair * a.pstride + (z & 1)] : a.m_max;
+    const int m0 = blockIdx.x * BM;
+    if (m0 >= M) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31, hh = lane >> 5;
+    const __amdgpu_buffer_rsrc_t rX = gmake_rsrc(a.A + (long)z * a.a_bstride, (unsigned)M * 1024u);
+    const __amdgpu_buffer_rsrc_t rW = gmake_rsrc(a.wp, (unsigned)a.N * 256u * 6u);
+
+    P_STAMP(0)
+    gu32x4 p[3], q[3];
+#define PR_LOAD(b_, tile_, kc_)                                                                                                  \
+    _Pragma("unroll") for (int g = 0; g < 3; ++g)                                                                                \
+        b_[g] = __builtin_amdgcn_raw_buffer_load_b128(rW, lane * 16u, (unsigned)(tile_) * TILE_BYTES + (unsigned)((kc_) * 3 + g) * 1024u, 0);
+    PR_LOAD(p, wave, 0)
+    {   // 32 rows x 256 floats -> three planes: thread -> (row = idx >> 6, float4 idx & 63), 4 float4 per thread
+        float4 v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + i * NT;
+            v[i] = gbuf_load4(rX, (unsigned)((m0 + (idx >> 6)) * 256 + (idx & 63) * 4) * 4u, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + i * NT;
+            unsigned h0, m0_, l0, h1, m1, l1;
+            gsplit2(v[i].x, v[i].y, h0, m0_, l0);
+            gsplit2(v[i].z, v[i].w, h1, m1, l1);
+            unsigned char* d = psm + (idx >> 6) * PS + (idx & 63) * 8;
+            *reinterpret_cast<gu32x2*>(d) = gu32x2{h0, h1};
+            *reinterpret_cast<gu32x2*>(d + PLANE) = gu32x2{m0_, m1};
+            *reinterpret_cast<gu32x2*>(d + 2 * PLANE) = gu32x2{l0, l1};
+        }
+    }
+    __syncthreads();
+    P_STAMP(1)
+
+#define PR_SIX(b_, kc_)                                                                                              \
+    {                                                                                                                \
+        const unsigned char* ap = psm + c * PS + ((kc_) * 16 + hh * 8) * 2;                                          \
+        const gu32x4 ah = *reinterpret_cast<const gu32x4*>(ap), am = *reinterpret_cast<const gu32x4*>(ap + PLANE),   \
+                     al = *reinterpret_cast<const gu32x4*>(ap + 2 * PLANE);                                          \
+        acc = gmfma_bf(ah, b_[2], acc);                                                                              \
+        acc = gmfma_bf(al, b_[0], acc);                                                                              \
+        acc = gmfma_bf(am, b_[1], acc);                                                                              \
+        acc = gmfma_bf(ah, b_[1], acc);                                                                              \
+        acc = gmfma_bf(am, b_[0], acc);                                                                              \
+        acc = gmfma_bf(ah, b_[0], acc);                                                                              \
+    }
+#pragma unroll 1
+    for (int j = 0; j < TILES; ++j) {
+        const int tile = j * 8 + wave;                       // wave-uniform: columns [32 tile, 32 tile + 32)
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll 1
+        for (int kc = 0; kc < 16; kc += 2) {
+            PR_LOAD(q, tile, kc + 1)
+            PR_SIX(p, kc)
+            if (kc + 2 < 16) { PR_LOAD(p, tile, kc + 2) } else if (j + 1 < TILES) { PR_LOAD(p, tile + 8, 0) }
+            PR_SIX(q, kc + 1)
+        }
+        P_STAMP(2 + 2 * j)
+        // ---- epilogue of this tile (gemm_nt_kernel's head-major branch): lane holds column colbase + c, rows m0 + 4 hh + (r & 3) + 8 (r >> 2)
+        const int colbase = tile * 32;
+        const int col = colbase + c;
+        const float bv = a.bias ? a.bias[col] : 0.f;
+        const unsigned rowl = m0 + 4 * hh;
+        const int which = colbase >> 8, hd = colbase & 255;
+        float* dst = a.q;
+        if constexpr (EPI == EPI_QKV_ROPE) dst = which == 0 ? a.q : (which == 1 ? a.k : a.v);
+        if constexpr (EPI == EPI_HEADS_QV) dst = which ? a.v : a.q;
+        const __amdgpu_buffer_rsrc_t rD = gmake_rsrc(dst + (long)z * a.head_bstride + (long)(hd >> 6) * a.head_stride, (unsigned)M * 256u);
+        const int d = (hd & 63) + c;
+        const unsigned vo = (rowl * 64 + d) * 4u;
+        float scale = a.alpha;
+        if constexpr (EPI == EPI_QKV_ROPE) scale = 1.f;
+        if constexpr (EPI == EPI_HEADS_QV) scale = which ? 1.f : a.alpha;
+        const bool rope = EPI == EPI_QKV_ROPE && which < 2 && a.cs;
+        if (rope) {
+            const __amdgpu_buffer_rsrc_t rCs = gmake_rsrc(a.cs + (long)z * a.enc_bstride, (unsigned)M * 128u);
+            const __amdgpu_buffer_rsrc_t rSn = gmake_rsrc(a.sn + (long)z * a.enc_bstride, (unsigned)M * 128u);
+            const unsigned ve = (rowl * 32 + (d >> 1)) * 4u;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const unsigned so = ((r & 3) + 8 * (r >> 2)) * 128u;
+                const float cs = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rCs, ve, so, 0));
+                const float sn = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rSn, ve, so, 0));
+                const float val = acc[r] + bv;
+                const float partner = __shfl_xor(val, 1);
+                const float outv = (d & 1) ? (val * cs) + (partner * sn) : (val * cs) + ((-partner) * sn);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(outv), rD, vo, ((r & 3) + 8 * (r >> 2)) * 256u, 0);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(scale * (acc[r] + bv)), rD, vo, ((r & 3) + 8 * (r >> 2)) * 256u, 0);
+        }
+        P_STAMP(3 + 2 * j)
+    }
+#undef PR_LOAD
+#undef PR_SIX
+}
+
+template <int EPI, int TILES>
+static hipError_t launch_proj_rows_t(const GemmArgs& a, hipStream_t s) {
+    static size_t lds_optin[IM_MAX_DEVICES] = {0};
+    if (hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(&proj_rows_kernel<EPI, TILES>), pr::LDS_BYTES, lds_optin); e != hipSuccess) return e;
+    const dim3 grid((a.m_max + pr::BM - 1) / pr::BM, a.batch), block(pr::NT);
+    hipLaunchKernelGGL((proj_rows_kernel<EPI, TILES>), grid, block, pr::LDS_BYTES, s, a);
+    return hipGetLastError();
+}
+
+// GemmArgs::wp set (W's planes in fragment order, pack_frag_weights(W, N, 256)): K = 256, lda = 256, N = 768 with EPI_QKV_ROPE or N = 512 with EPI_HEADS_QV,
+// no second A, no per-batch / selected weights, every column live
+hipError_t launch_proj_rows(const GemmArgs& a, hipStream_t s) {
+    if (!a.wp || a.K != 256 || a.lda != 256 || a.A1 || a.sel || a.w_bstride || a.n_ptr || a.pair_batched) return hipErrorInvalidValue;
+    if (a.m_max <= 0 || a.batch <= 0) return hipSuccess;
+    if (a.epi == EPI_QKV_ROPE && a.N == 768) return launch_proj_rows_t<EPI_QKV_ROPE, 3>(a, s);
+    if (a.epi == EPI_HEADS_QV && a.N == 512) return launch_proj_rows_t<EPI_HEADS_QV, 2>(a, s);
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {

@@ -45,8 +45,10 @@ struct GemmArgs {
     int big_tile = 0;              // 128x128 block tile (score GEMM) instead of 64x64
     int bx = 0;                    // the product on the bf16 matrix cores, six bf16 products per fp32 product (gemm.hip BX; the matchers' GEMMs;
                                    // SuperPoint's stay on the f32-input MFMA: its outputs are bit-identical to round 4's)
+    const void* wp = nullptr;      // launch_proj_rows only: the rows of W (after the layer offset) as bf16 planes in MFMA-fragment order (pack_frag_weights(W, N, 256))
 };
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
+hipError_t launch_proj_rows(const GemmArgs& a, hipStream_t s);   // gemm.hip: the K = 256 projections of a LightGlue block as row blocks (same bits as launch_gemm with bx)
 
 // ------------------------------------------------------------------ ffn_fused.hip
 struct FfnArgs {

@@ -110,6 +110,15 @@ static int finalize_lightglue(im_ctx* ctx) {
                     }
         w.qkv_w = ctx->upload(pw);
         w.qkv_b = ctx->upload(pb);
+        {   // per layer: fragment order for proj_rows_kernel
+            std::vector<float> packed;
+            packed.reserve(pw.size() * 3 / 2);
+            for (int l = 0; l < L; ++l) {
+                const std::vector<float> one = pack_frag_weights(&pw[(size_t)l * 768 * 256], 768, 256);
+                packed.insert(packed.end(), one.begin(), one.end());
+            }
+            w.qkv_wp = ctx->upload(packed);
+        }
     }
     // out_proj / to_out are folded into the second half of ffn.0 (`lightglue.py:160-162, 212-216`: the message is used
     // only as ffn input): ffn.0([x | Wo a + bo]) = W0a x + (W0b Wo) a + (W0b bo + b0). Products accumulated in double;
@@ -170,7 +179,16 @@ static int finalize_lightglue(im_ctx* ctx) {
         }
         w.cqv_w = ctx->upload(pw);
         w.cqv_b = ctx->upload(pb);
-        if (!w.cqv_w || !w.cqv_b) return ctx->fail(-22, "weights: upload failed");
+        {
+            std::vector<float> packed;
+            packed.reserve(pw.size() * 3 / 2);
+            for (int l = 0; l < L; ++l) {
+                const std::vector<float> one = pack_frag_weights(&pw[(size_t)l * 512 * 256], 512, 256);
+                packed.insert(packed.end(), one.begin(), one.end());
+            }
+            w.cqv_wp = ctx->upload(packed);
+        }
+        if (!w.cqv_w || !w.cqv_b || !w.cqv_wp) return ctx->fail(-22, "weights: upload failed");
     }
     if (int rc = fold("transformers.%d.cross_attn.to_out.weight", "transformers.%d.cross_attn.to_out.bias",
                       "transformers.%d.cross_attn.ffn.0.weight", "transformers.%d.cross_attn.ffn.0.bias", w.cf0_w, w.cf0_b, w.cf0_wp))
@@ -198,7 +216,7 @@ static int finalize_lightglue(im_ctx* ctx) {
             w.thr[i] = (float)(t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t));
         }
     }
-    if (!w.wr || !w.qkv_w || !w.qkv_b) return ctx->fail(-22, "weights: upload failed");
+    if (!w.wr || !w.qkv_w || !w.qkv_b || !w.qkv_wp) return ctx->fail(-22, "weights: upload failed");
     w.ready = true;
     return 0;
 }
@@ -462,6 +480,20 @@ int im_superpoint_candidates(im_ctx* ctx, int n_images, int32_t* h_counts, void*
 // ------------------------------------------------------------------------------------------------ LightGlue
 static constexpr int ST_INTS = (int)(sizeof(LGState) / sizeof(int));   // ints between the states of consecutive pairs
 
+// The two K = 256 projections of a block: as row blocks (proj_rows_kernel, round 6) when the launch has more 32-row blocks than the chip has CUs - two to
+// three of them share a CU then and hide each other's staging and epilogue -, through the tiled GEMM (gemm_nt_kernel, rounds 1-5) otherwise (one pair of 4096
+// keypoints = 256 row blocks: one per CU, slower than the tiled kernel's 1536 small blocks). Same bits either way. IM_PROJ_TILED=1 / 0 forces one (read per call).
+static bool proj_tiled(int m_max, int batch) {
+    const char* e = getenv("IM_PROJ_TILED");
+    if (e) return e[0] == '1';
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cu = 256;
+    }
+    return (long)((m_max + 31) / 32) * batch <= n_cu;
+}
+
 static int lg_block(im_ctx* ctx, hipStream_t s, int NI, int layer, bool cross, float* x, const float* cs, const float* sn) {
     Workspace* ws = ctx->ws;
     const LightGlueW& W = ctx->lg;
@@ -481,7 +513,12 @@ static int lg_block(im_ctx* ctx, hipStream_t s, int NI, int layer, bool cross, f
         g.bias = W.qkv_b + (long)layer * 768; g.N = 768; g.K = 256; g.epi = EPI_QKV_ROPE;
         g.q = ws->q; g.k = ws->k; g.v = ws->v; g.head_bstride = (long)K * 256; g.head_stride = (long)K * 64;
         g.cs = cs; g.sn = sn; g.enc_bstride = (long)K * 32; g.big_tile = NI >= 4;
-        IM_LAUNCH(ctx, "lg_qkv_rope_gemm", s, launch_gemm(g, s));
+        if (proj_tiled(K, NI)) {
+            IM_LAUNCH(ctx, "lg_qkv_rope_gemm", s, launch_gemm(g, s));
+        } else {
+            g.wp = reinterpret_cast<const unsigned char*>(W.qkv_wp) + (size_t)layer * 768 * 256 * 6;
+            IM_LAUNCH(ctx, "lg_qkv_rope_gemm", s, launch_proj_rows(g, s));
+        }
         at.scale = 0.125f;  // SDPA default 1/sqrt(64) (`lightglue.py:120-123`)
     } else {
         GemmArgs g = base;
@@ -490,7 +527,12 @@ static int lg_block(im_ctx* ctx, hipStream_t s, int NI, int layer, bool cross, f
         g.q = ws->q; g.v = ws->v; g.head_bstride = (long)K * 256; g.head_stride = (long)K * 64;
         g.alpha = (float)0.35355339059327373;  // scale**0.5 = 64**-0.25 on to_qk (`lightglue.py:201`); to_v unscaled
         g.big_tile = NI >= 4;
-        IM_LAUNCH(ctx, "lg_proj_gemm", s, launch_gemm(g, s));
+        if (proj_tiled(K, NI)) {
+            IM_LAUNCH(ctx, "lg_proj_gemm", s, launch_gemm(g, s));
+        } else {
+            g.wp = reinterpret_cast<const unsigned char*>(W.cqv_wp) + (size_t)layer * 512 * 256 * 6;
+            IM_LAUNCH(ctx, "lg_proj_gemm", s, launch_proj_rows(g, s));
+        }
         at.scale = 1.f;
     }
     IM_LAUNCH(ctx, "attn_kv_planes", s, launch_attn_planes(at, s));

@@ -576,7 +576,14 @@ int finalize_superglue(im_ctx* ctx) {
             p3.insert(p3.end(), a3.begin(), a3.end());
         }
         W.mlp0_wp = ctx->upload(p0); W.mlp3_wp = ctx->upload(p3);
-        if (!W.mlp0_wp || !W.mlp3_wp) return ctx->fail(-22, "weights: upload failed");
+        std::vector<float> pq;
+        pq.reserve(qkv_w.size() * 3 / 2);
+        for (int l = 0; l < L; ++l) {
+            const std::vector<float> one = pack_frag_weights(&qkv_w[(size_t)l * 768 * 256], 768, 256);
+            pq.insert(pq.end(), one.begin(), one.end());
+        }
+        W.proj_wp = ctx->upload(pq);
+        if (!W.mlp0_wp || !W.mlp3_wp || !W.proj_wp) return ctx->fail(-22, "weights: upload failed");
     }
     const auto* fw = sg_find(ctx, "final_proj.weight", 65536);
     const auto* fb = sg_find(ctx, "final_proj.bias", 256);
@@ -635,7 +642,14 @@ int im_superglue_forward(im_ctx* ctx, const float* d_kpts, const float* d_scores
             g.A = x; g.a_bstride = xb; g.lda = 256; g.W = W.proj_w + (long)l * 768 * 256; g.ldw = 256;
             g.bias = W.proj_b + (long)l * 768; g.N = 768; g.K = 256; g.epi = EPI_QKV_ROPE;  // no rotary tables => plain q/k/v
             g.q = ws->q; g.k = ws->k; g.v = ws->v; g.head_bstride = (long)K * 256; g.head_stride = (long)K * 64;
-            IM_LAUNCH(ctx, "sg_qkv_gemm", s, launch_gemm(g, s));
+            const char* const tiled_env = getenv("IM_PROJ_TILED");      // A/B switch (read per call): 1 = the tiled GEMM of rounds 1-5, 0 = the row-block kernel
+            const bool tiled = tiled_env ? tiled_env[0] == '1' : (long)((K + 31) / 32) * 2 <= 256;      // as models.hip: row blocks when they outnumber the CUs
+            if (tiled) {
+                IM_LAUNCH(ctx, "sg_qkv_gemm", s, launch_gemm(g, s));
+            } else {
+                g.wp = reinterpret_cast<const unsigned char*>(W.proj_wp) + (size_t)l * 768 * 256 * 6;
+                IM_LAUNCH(ctx, "sg_qkv_gemm", s, launch_proj_rows(g, s));
+            }
         }
         {
             AttnArgs at;

@@ -1043,6 +1043,38 @@ def test_lightglue_pairs_share_launches_bit_identically():
     e.close()
 
 
+def test_projection_row_blocks_equal_the_tiled_gemm_bit_for_bit(monkeypatch):
+    """Round 6: the two K = 256 projections of a LightGlue block (Wqkv + rotary, to_qk / to_v) run as row blocks (`proj_rows_kernel`: x cut once into LDS
+    planes, weight planes streamed in fragment order); `IM_PROJ_TILED=1` (read per call) puts them back on the tiled `gemm_nt_kernel`. Same products in the
+    same order per accumulator, the tiled kernel's epilogue statement for statement: every output of the matcher must be equal bit for bit - ragged sizes,
+    pruning at work, one and three pairs per launch."""
+    from icepy4d_amd.engine import Engine
+    e = Engine(0)
+    e.load_state_dict("lightglue", synthetic.lightglue_state_dict(0, "passthrough"))
+    e.reserve(64, 64, 6, 320)
+    feats = [synthetic.synthetic_features(s, m, n) for s, m, n in ((2, 300, 257), (1, 128, 128), (5, 96, 160), (3, 33, 1))]
+    outs = {}
+    for form in ("1", "0"):
+        monkeypatch.setenv("IM_PROJ_TILED", form)
+        singles = [run_lightglue(e, f) for f in feats]
+        e.kpts.zero_(); e.desc.zero_()
+        for p, f in enumerate(feats[:3]):
+            m, n = f["kpts0"].shape[0], f["kpts1"].shape[0]
+            e.kpts[2 * p, :m] = torch.from_numpy(f["kpts0"]).cuda(); e.kpts[2 * p + 1, :n] = torch.from_numpy(f["kpts1"]).cuda()
+            e.desc[2 * p, :m] = torch.from_numpy(f["desc0"]).cuda(); e.desc[2 * p + 1, :n] = torch.from_numpy(f["desc1"]).cuda()
+            e.n[2 * p] = m; e.n[2 * p + 1] = n
+        e.lightglue(tuple(feats[0]["size0"]), tuple(feats[0]["size1"]), n_pairs=3)
+        torch.cuda.synchronize()
+        batched = [e.matches_to_host(f["kpts0"].shape[0], f["kpts1"].shape[0], pair=p) for p, f in enumerate(feats[:3])]
+        outs[form] = singles + batched
+    for a, b in zip(outs["1"], outs["0"]):
+        assert a["stop"] == b["stop"]
+        for k in ("matches0", "matches1", "matching_scores0", "matching_scores1", "prune0", "prune1"):
+            assert np.array_equal(a[k], b[k]), k
+    assert (outs["0"][0]["matches0"] > -1).sum() > 50
+    e.close()
+
+
 def test_sequence_pairs_per_launch_equals_one_by_one():
     """SequenceMatcher / PairPipeline with pairs_per_launch = 2, 5 and 10 (graph and direct): records bit-identical to one pair per
     launch, including a partial last group (5 pairs: 2 + 2 + 1, one full group of 5, half a group of 10)."""
