@@ -283,14 +283,15 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------------------------
-// The K = 256 projections of a transformer block as ROW BLOCKS (round 6; `lightglue/lightglue.py:153, 192-193`: Wqkv + rotary, to_qk / to_v). The tiled
-// kernel above runs them at 0.27 of the bf16 / 6 roofline (284 us per ten pairs for qkv): eight 32-deep slabs, each with its own staging, plane cut of BOTH
-// operands (the W tile again in every row block, the x tile again in every column block) and barrier, around 48 MFMAs per wave. Here a block owns 32 rows
-// for ALL N output columns, as the fused feed-forward does: x is cut ONCE into three 256-wide bf16 planes in LDS (50 KB: two to three blocks per CU), the
-// weights arrive cut (the host's pack_frag_weights: MFMA-fragment order, a wave's 16-byte-per-lane load is one contiguous KiB) and stream from L2 straight
-// into registers one 16-deep step ahead, one barrier per block. Wave w owns the column tiles w, w + 8, (w + 16): one of q / k / v each, sixteen steps of six
-// MFMAs per tile, then that tile's epilogue (the tiled kernel's, statement for statement: bias, rotary on q / k, head-major stores). The products and their
-// order per accumulator are those of the tiled kernel (x planes as A, W planes as B, k ascending, h l | l h | m m | h m | m h | h h): bit-identical outputs.
+// The K = 256 projections of a transformer block as ROW BLOCKS (round 6; `lightglue/lightglue.py:153, 192-193`: Wqkv + rotary, to_qk / to_v; SuperGlue's
+// `proj`: `superglue.py:79-93`). The tiled kernel above runs them at 0.27 of the bf16 / 6 roofline (281 us per ten pairs for qkv): eight 32-deep slabs, each with
+// its own staging, plane cut of BOTH operands (the W tile again in every row block, the x tile again in every column block) and barrier, around 48 MFMAs per
+// wave. Here a block owns 32 rows for ALL N output columns, as the fused feed-forward does: x is cut ONCE into three 256-wide bf16 planes in LDS (50 KB: up to
+// three blocks per CU), the weights arrive cut (the host's pack_frag_weights: MFMA-fragment order, a wave's 16-byte-per-lane load is one contiguous KiB) and
+// stream from L2 straight into registers THREE 16-deep steps ahead (four register buffers; with one step ahead a step of six MFMAs waited 830 cycles for its
+// weights), one barrier per block. Wave w owns the column tiles w, w + 8, (w + 16): one of q / k / v each, sixteen steps of six MFMAs per tile, then that tile's
+// epilogue (the tiled kernel's, statement for statement: bias, rotary on q / k, head-major stores). The products and their order per accumulator are those of
+// the tiled kernel (x planes as A, W planes as B, k ascending, h l | l h | m m | h m | m h | h h): bit-identical outputs (profiles/r06_proj_rows.txt).
 namespace pr {
 constexpr int BM = 32, NT = 512;
 constexpr int PS = 528;              // bytes per row of a plane: 256 x 2 + 16 (132 dwords = 4 mod 64: conflict-free 16-byte row reads)
@@ -326,11 +327,17 @@ __global__ __launch_bounds__(pr::NT, 4) void proj_rows_kernel(GemmArgs a) {
     const __amdgpu_buffer_rsrc_t rW = gmake_rsrc(a.wp, (unsigned)a.N * 256u * 6u);
 
     P_STAMP(0)
-    gu32x4 p[3], q[3];
-#define PR_LOAD(b_, tile_, kc_)                                                                                                  \
-    _Pragma("unroll") for (int g = 0; g < 3; ++g)                                                                                \
-        b_[g] = __builtin_amdgcn_raw_buffer_load_b128(rW, lane * 16u, (unsigned)(tile_) * TILE_BYTES + (unsigned)((kc_) * 3 + g) * 1024u, 0);
-    PR_LOAD(p, wave, 0)
+    // weight steps (one 16-deep k chunk of one column tile = three 1 KB loads) run THREE steps ahead through four register buffers: the step index s = 16 j + kc
+    // walks this wave's tiles j * 8 + wave; steps past the last tile are out of the descriptor's range (zeros, no traffic, no branch)
+    gu32x4 b0[3], b1[3], b2[3], b3[3];
+#define PR_LOAD(b_, s_)                                                                                                          \
+    {                                                                                                                            \
+        const unsigned so_ = (unsigned)((((s_) >> 4) * 8 + wave)) * TILE_BYTES + (unsigned)(((s_) & 15) * 3) * 1024u;            \
+        _Pragma("unroll") for (int g = 0; g < 3; ++g) b_[g] = __builtin_amdgcn_raw_buffer_load_b128(rW, lane * 16u, so_ + (unsigned)g * 1024u, 0); \
+    }
+    PR_LOAD(b0, 0)
+    PR_LOAD(b1, 1)
+    PR_LOAD(b2, 2)
     {   // 32 rows x 256 floats -> three planes: thread -> (row = idx >> 6, float4 idx & 63), 4 float4 per thread
         float4 v[4];
 #pragma unroll
@@ -372,11 +379,25 @@ __global__ __launch_bounds__(pr::NT, 4) void proj_rows_kernel(GemmArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll 1
-        for (int kc = 0; kc < 16; kc += 2) {
-            PR_LOAD(q, tile, kc + 1)
-            PR_SIX(p, kc)
-            if (kc + 2 < 16) { PR_LOAD(p, tile, kc + 2) } else if (j + 1 < TILES) { PR_LOAD(p, tile + 8, 0) }
-            PR_SIX(q, kc + 1)
+        for (int kc = 0; kc < 16; kc += 4) {
+            const int s_ = j * 16 + kc;
+            // a scheduling fence per step: left alone the machine scheduler sinks every load to its use (one step of latency hiding instead of three)
+            PR_LOAD(b3, s_ + 3)
+            __builtin_amdgcn_sched_barrier(0);
+            PR_SIX(b0, kc)
+            __builtin_amdgcn_sched_barrier(0);
+            PR_LOAD(b0, s_ + 4)
+            __builtin_amdgcn_sched_barrier(0);
+            PR_SIX(b1, kc + 1)
+            __builtin_amdgcn_sched_barrier(0);
+            PR_LOAD(b1, s_ + 5)
+            __builtin_amdgcn_sched_barrier(0);
+            PR_SIX(b2, kc + 2)
+            __builtin_amdgcn_sched_barrier(0);
+            PR_LOAD(b2, s_ + 6)
+            __builtin_amdgcn_sched_barrier(0);
+            PR_SIX(b3, kc + 3)
+            __builtin_amdgcn_sched_barrier(0);
         }
         P_STAMP(2 + 2 * j)
         // ---- epilogue of this tile (gemm_nt_kernel's head-major branch): lane holds column colbase + c, rows m0 + 4 hh + (r & 3) + 8 (r >> 2)

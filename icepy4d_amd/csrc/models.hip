@@ -480,18 +480,11 @@ int im_superpoint_candidates(im_ctx* ctx, int n_images, int32_t* h_counts, void*
 // ------------------------------------------------------------------------------------------------ LightGlue
 static constexpr int ST_INTS = (int)(sizeof(LGState) / sizeof(int));   // ints between the states of consecutive pairs
 
-// The two K = 256 projections of a block: as row blocks (proj_rows_kernel, round 6) when the launch has more 32-row blocks than the chip has CUs - two to
-// three of them share a CU then and hide each other's staging and epilogue -, through the tiled GEMM (gemm_nt_kernel, rounds 1-5) otherwise (one pair of 4096
-// keypoints = 256 row blocks: one per CU, slower than the tiled kernel's 1536 small blocks). Same bits either way. IM_PROJ_TILED=1 / 0 forces one (read per call).
-static bool proj_tiled(int m_max, int batch) {
+// The two K = 256 projections of a block run as row blocks (proj_rows_kernel, round 6); IM_PROJ_TILED=1 (read per call) puts them back on the tiled GEMM
+// (gemm_nt_kernel, rounds 1-5): same bits, the A/B and test switch
+static bool proj_tiled() {
     const char* e = getenv("IM_PROJ_TILED");
-    if (e) return e[0] == '1';
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cu = 256;
-    }
-    return (long)((m_max + 31) / 32) * batch <= n_cu;
+    return e && e[0] == '1';
 }
 
 static int lg_block(im_ctx* ctx, hipStream_t s, int NI, int layer, bool cross, float* x, const float* cs, const float* sn) {
@@ -513,7 +506,7 @@ static int lg_block(im_ctx* ctx, hipStream_t s, int NI, int layer, bool cross, f
         g.bias = W.qkv_b + (long)layer * 768; g.N = 768; g.K = 256; g.epi = EPI_QKV_ROPE;
         g.q = ws->q; g.k = ws->k; g.v = ws->v; g.head_bstride = (long)K * 256; g.head_stride = (long)K * 64;
         g.cs = cs; g.sn = sn; g.enc_bstride = (long)K * 32; g.big_tile = NI >= 4;
-        if (proj_tiled(K, NI)) {
+        if (proj_tiled()) {
             IM_LAUNCH(ctx, "lg_qkv_rope_gemm", s, launch_gemm(g, s));
         } else {
             g.wp = reinterpret_cast<const unsigned char*>(W.qkv_wp) + (size_t)layer * 768 * 256 * 6;
@@ -527,7 +520,7 @@ static int lg_block(im_ctx* ctx, hipStream_t s, int NI, int layer, bool cross, f
         g.q = ws->q; g.v = ws->v; g.head_bstride = (long)K * 256; g.head_stride = (long)K * 64;
         g.alpha = (float)0.35355339059327373;  // scale**0.5 = 64**-0.25 on to_qk (`lightglue.py:201`); to_v unscaled
         g.big_tile = NI >= 4;
-        if (proj_tiled(K, NI)) {
+        if (proj_tiled()) {
             IM_LAUNCH(ctx, "lg_proj_gemm", s, launch_gemm(g, s));
         } else {
             g.wp = reinterpret_cast<const unsigned char*>(W.cqv_wp) + (size_t)layer * 512 * 256 * 6;

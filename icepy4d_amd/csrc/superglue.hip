@@ -642,9 +642,8 @@ int im_superglue_forward(im_ctx* ctx, const float* d_kpts, const float* d_scores
             g.A = x; g.a_bstride = xb; g.lda = 256; g.W = W.proj_w + (long)l * 768 * 256; g.ldw = 256;
             g.bias = W.proj_b + (long)l * 768; g.N = 768; g.K = 256; g.epi = EPI_QKV_ROPE;  // no rotary tables => plain q/k/v
             g.q = ws->q; g.k = ws->k; g.v = ws->v; g.head_bstride = (long)K * 256; g.head_stride = (long)K * 64;
-            const char* const tiled_env = getenv("IM_PROJ_TILED");      // A/B switch (read per call): 1 = the tiled GEMM of rounds 1-5, 0 = the row-block kernel
-            const bool tiled = tiled_env ? tiled_env[0] == '1' : (long)((K + 31) / 32) * 2 <= 256;      // as models.hip: row blocks when they outnumber the CUs
-            if (tiled) {
+            const char* const tiled_env = getenv("IM_PROJ_TILED");      // A/B switch (read per call): 1 = the tiled GEMM of rounds 1-5 instead of the row-block kernel
+            if (tiled_env && tiled_env[0] == '1') {
                 IM_LAUNCH(ctx, "sg_qkv_gemm", s, launch_gemm(g, s));
             } else {
                 g.wp = reinterpret_cast<const unsigned char*>(W.proj_wp) + (size_t)l * 768 * 256 * 6;
