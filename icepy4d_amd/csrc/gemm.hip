@@ -328,12 +328,14 @@ __global__ __launch_bounds__(pr::NT, 4) void proj_rows_kernel(GemmArgs a) {
 
     P_STAMP(0)
     // weight steps (one 16-deep k chunk of one column tile = three 1 KB loads) run THREE steps ahead through four register buffers: the step index s = 16 j + kc
-    // walks this wave's tiles j * 8 + wave; steps past the last tile are out of the descriptor's range (zeros, no traffic, no branch)
+    // walks this wave's tiles j * 8 + wave; steps past the last tile are out of the descriptor's range by their lane offset (zeros, no traffic, no branch)
     gu32x4 b0[3], b1[3], b2[3], b3[3];
 #define PR_LOAD(b_, s_)                                                                                                          \
     {                                                                                                                            \
-        const unsigned so_ = (unsigned)((((s_) >> 4) * 8 + wave)) * TILE_BYTES + (unsigned)(((s_) & 15) * 3) * 1024u;            \
-        _Pragma("unroll") for (int g = 0; g < 3; ++g) b_[g] = __builtin_amdgcn_raw_buffer_load_b128(rW, lane * 16u, so_ + (unsigned)g * 1024u, 0); \
+        const bool in_ = (s_) < TILES * 16;                                                                                      \
+        const unsigned so_ = in_ ? (unsigned)((((s_) >> 4) * 8 + wave)) * TILE_BYTES + (unsigned)(((s_) & 15) * 3) * 1024u : 0u;   \
+        const unsigned vo_ = in_ ? lane * 16u : 0x80000000u;    /* out of range by the LANE offset: a scalar offset beyond num_records would wrap the range check */ \
+        _Pragma("unroll") for (int g = 0; g < 3; ++g) b_[g] = __builtin_amdgcn_raw_buffer_load_b128(rW, vo_, so_ + (unsigned)g * 1024u, 0); \
     }
     PR_LOAD(b0, 0)
     PR_LOAD(b1, 1)
