@@ -446,23 +446,13 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bx_kernel(AttnArgs a) {
     // im_debug_clock_probe (a.clock set only by that call): the shader clock this kernel holds inside its main loop = cycles / 100 MHz ticks
     unsigned long long ck0 = 0, cr0 = 0;
     if (a.clock) { ck0 = __builtin_amdgcn_s_memtime(); cr0 = __builtin_amdgcn_s_memrealtime(); }
-#ifdef BX_PROTO_KF0_EARLY
-    u32x4 kf0n[3];
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl) kf0n[pl] = kf_read(kring + r1 * 3 * KPL + pl * KPL + kq[0]);
-#endif
     for (int t = 0; t < nt - 2; ++t) {       // tiles t and t + 1 lie inside the keys: no masks anywhere
         const unsigned char* const kp = kring + r1 * 3 * KPL;
         const unsigned char* const vp = vring + r0 * 3 * VPL;
         u32x4 kf[2][3];
         u32x2 vr[2][6];
-#ifdef BX_PROTO_KF0_EARLY   // TIMING PROTOTYPE (racy: the tile may not have landed): the first K fragments of step t + 1 read during the last slots of step t
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) kf[0][pl] = kf0n[pl];
-#else
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) kf[0][pl] = kf_read(kp + pl * KPL + kq[0]);
-#endif
 #ifndef BX_ABL_NO_STAGE     // -DBX_ABL_*: timing-only ablations of the main loop (wrong results), as IM_ABL_* in attention.hip
         if constexpr (DMA) {
             dma_k(t + 3, r0);                // over K(t), last read in step t - 1
@@ -579,9 +569,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bx_kernel(AttnArgs a) {
                     const int gn = g + 1;
                     vr[gn & 1][j] = tr_read(vp + (16 * (gn >> 1)) * VS + dv[gn & 1] + (j >> 1) * VPL + (j & 1) * 8 * VS);
                 }
-#ifdef BX_PROTO_KF0_EARLY
-                if (g == 3 && j < 3) kf0n[j] = kf_read(kring + r2 * 3 * KPL + j * KPL + kq[0]);
-#endif
+
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
