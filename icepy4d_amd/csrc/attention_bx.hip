@@ -569,7 +569,6 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bx_kernel(AttnArgs a) {
                     const int gn = g + 1;
                     vr[gn & 1][j] = tr_read(vp + (16 * (gn >> 1)) * VS + dv[gn & 1] + (j >> 1) * VPL + (j & 1) * 8 * VS);
                 }
-
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
