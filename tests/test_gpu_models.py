@@ -614,6 +614,14 @@ def test_tile_feature_cache_is_bit_identical():
     m3.match(g["image0"], g["image1"], quality=Quality.HIGH, tile_selection=TileSelection.EXHAUSTIVE, **cfg)
     for x, y in zip(a, (m3.mkpts0, m3.mkpts1, m3.descriptors0, m3.scores1)):
         assert np.array_equal(x, y)
+    # round 6: the tiles are crops of ONE device copy per image; [H, W, 1] and non-contiguous host arrays (a Fortran-ordered copy, a strided view of a
+    # wider array) must give the same tiles as the contiguous [H, W] array
+    i0, i1 = g["image0"], g["image1"]
+    wide0 = np.zeros((i0.shape[0], i0.shape[1] + 7), np.uint8); wide0[:, 3:3 + i0.shape[1]] = i0
+    for v0, v1 in ((i0[..., None], i1[..., None]), (np.asfortranarray(i0), np.asfortranarray(i1)), (wide0[:, 3:3 + i0.shape[1]], i1)):
+        m.match(v0, v1, quality=Quality.HIGH, tile_selection=TileSelection.EXHAUSTIVE, **cfg)
+        for x, y in zip(a, (m.mkpts0, m.mkpts1, m.descriptors0, m.scores1)):
+            assert np.array_equal(x, y)
     # preselection mode runs end to end (pyramid + preselection match + tile matching)
     m.match(g["image0"], g["image1"], quality=Quality.HIGH, tile_selection=TileSelection.PRESELECTION, min_matches_per_tile=3, **cfg)
     assert len(m.mkpts0) > 50 and len(m.mkpts0) == len(m.mkpts1)
